@@ -1,0 +1,234 @@
+"""Architecture description of the FunCodec encode/decode hot path, parsed from the reference's
+own ``config.yaml`` format.
+
+Mirrors what the reference reads in ``GANSpeechCodecTask.build_model``
+(/root/reference/funcodec/tasks/gan_speech_codec.py:300-343) and the constructor defaults of
+``SEANetEncoder`` (funcodec/models/encoder/seanet_encoder.py:88-97), ``SEANetDecoder``
+(funcodec/models/decoder/seanet_decoder.py:88-96), ``CostumeQuantizer``
+(funcodec/models/quantizer/costume_quantizer.py:7-22) and ``Encodec``
+(funcodec/models/codec_basic.py).  Only the time-domain ``encodec`` family is
+accepted; everything else raises ``NotImplementedError`` naming the unsupported key, so a
+checkpoint this engine cannot reproduce is refused instead of silently mis-decoded.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Any, Dict, List, Optional, Tuple
+
+
+@dataclasses.dataclass
+class ArchSpec:
+    # audio / model level (Encodec.__init__)
+    sample_rate: int = 16000
+    input_channels: int = 1
+    audio_normalize: bool = True
+    # SEANet (shared by encoder and decoder; the recipe gives both the same values)
+    n_filters: int = 32
+    dimension: int = 128
+    ratios: Tuple[int, ...] = (8, 5, 4, 2)       # decoder order; the encoder walks it reversed
+    kernel_size: int = 7
+    last_kernel_size: int = 7
+    residual_kernel_size: int = 3
+    n_residual_layers: int = 1
+    dilation_base: int = 2
+    compress: int = 2
+    lstm_layers: int = 2                          # seq_layer_num when seq_model == "lstm", else 0
+    lstm_skip: bool = True                        # res_seq
+    elu_alpha: float = 1.0
+    gn_eps: float = 1e-5
+    # quantizer (CostumeQuantizer -> ResidualVectorQuantizer)
+    codebook_size: int = 1024
+    codebook_dim: int = 128
+    num_quantizers: int = 32
+    encoder_hop_length: int = 320
+    quantizer_sampling_rate: int = 16000
+    use_ddp: bool = True
+
+    @property
+    def hop_length(self) -> int:
+        return int(math.prod(self.ratios))
+
+    @property
+    def n_stages(self) -> int:
+        return len(self.ratios)
+
+    @property
+    def bottleneck_channels(self) -> int:
+        return self.n_filters * (2 ** len(self.ratios))
+
+    def num_quantizers_for_bandwidth(self, bandwidth: Optional[float]) -> int:
+        """funcodec/modules/quantization/vq.py:105-117 (and the implicit ``layers[:n_q]`` cap)."""
+        bw_per_q = math.log2(self.codebook_size) * self.quantizer_sampling_rate / self.encoder_hop_length
+        n_q = self.num_quantizers
+        if bandwidth and bandwidth > 0.0:
+            n_q = int(max(1, math.floor(bandwidth / bw_per_q)))
+        return min(n_q, self.num_quantizers)
+
+    def frames_for(self, n_samples: int) -> int:
+        """Number of codec frames the encoder emits for ``n_samples`` (ceil at every stride)."""
+        t = n_samples
+        for r in reversed(self.ratios):
+            t = -(-t // r)
+        return t
+
+
+def _unsupported(key: str, value: Any, why: str = "") -> NotImplementedError:
+    return NotImplementedError(
+        f"config key {key}={value!r} is outside the MI355X hot-path scope (SURVEY.md §8){': ' + why if why else ''}")
+
+
+def _check_seanet_conf(conf: Dict[str, Any], which: str) -> Dict[str, Any]:
+    conf = dict(conf or {})
+    norm = conf.get("norm", "weight_norm")
+    if norm != "time_group_norm":
+        raise _unsupported(f"{which}.norm", norm, "only time_group_norm checkpoints are supported")
+    if conf.get("causal", False):
+        raise _unsupported(f"{which}.causal", True)
+    if conf.get("pad_mode", "reflect") != "reflect":
+        raise _unsupported(f"{which}.pad_mode", conf["pad_mode"])
+    if conf.get("activation", "ELU") != "ELU":
+        raise _unsupported(f"{which}.activation", conf["activation"])
+    if conf.get("true_skip", False):
+        raise _unsupported(f"{which}.true_skip", True)
+    if conf.get("add_snake_activation", False):
+        raise _unsupported(f"{which}.add_snake_activation", True)
+    if not conf.get("double_filters", True) or not conf.get("half_filters", True):
+        raise _unsupported(f"{which}.double_filters/half_filters", False)
+    if conf.get("final_activation", None) is not None:
+        raise _unsupported(f"{which}.final_activation", conf["final_activation"])
+    seq_model = conf.get("seq_model", "lstm")
+    if seq_model not in ("lstm", None, "none", "None"):
+        raise _unsupported(f"{which}.seq_model", seq_model)
+    if conf.get("n_residual_layers", 1) != 1:
+        raise _unsupported(f"{which}.n_residual_layers", conf["n_residual_layers"],
+                           "dilated residual stacks are not built yet")
+    nk = dict(conf.get("norm_params", {}) or {})
+    if nk.get("num_groups", 1) != 1:
+        raise _unsupported(f"{which}.norm_params.num_groups", nk["num_groups"])
+    return conf
+
+
+def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
+    """Build an :class:`ArchSpec` from a dict loaded from the reference's ``config.yaml``."""
+    if cfg.get("model", "encodec") != "encodec":
+        raise _unsupported("model", cfg.get("model"))
+    if cfg.get("encoder", "encodec_seanet_encoder") != "encodec_seanet_encoder":
+        raise _unsupported("encoder", cfg.get("encoder"))
+    if cfg.get("decoder", "encodec_seanet_decoder") != "encodec_seanet_decoder":
+        raise _unsupported("decoder", cfg.get("decoder"))
+    if cfg.get("quantizer", "costume_quantizer") != "costume_quantizer":
+        raise _unsupported("quantizer", cfg.get("quantizer"))
+    enc = _check_seanet_conf(cfg.get("encoder_conf", {}), "encoder_conf")
+    dec = _check_seanet_conf(cfg.get("decoder_conf", {}), "decoder_conf")
+    q = dict(cfg.get("quantizer_conf", {}) or {})
+    m = dict(cfg.get("model_conf", {}) or {})
+
+    def shared(key, default):
+        a, b = enc.get(key, default), dec.get(key, default)
+        if key == "ratios":
+            a, b = list(a), list(b)
+        if a != b:
+            raise _unsupported(f"encoder_conf.{key} != decoder_conf.{key}", (a, b))
+        return a
+
+    input_size = cfg.get("input_size", 1)
+    if input_size != 1 or dec.get("channels", 1) != 1:
+        raise _unsupported("input_size/channels", (input_size, dec.get("channels", 1)), "mono only")
+    if m.get("segment_dur", None) is not None:
+        raise _unsupported("model_conf.segment_dur", m["segment_dur"], "segmented overlap-add mode is §8f")
+    if m.get("codec_domain", "time") not in ("time", None):
+        raise _unsupported("model_conf.codec_domain", m["codec_domain"])
+    if m.get("bypass_quantizer", False):
+        raise _unsupported("model_conf.bypass_quantizer", True)
+    # the decoder's input_size is injected by build_model from quantizer.output_size()
+    # (gan_speech_codec.py:325-329) == encoder dimension when codec_dim is unset
+    dimension = int(enc.get("dimension", 128))
+    if q.get("codec_dim", None) not in (None, dimension):
+        raise _unsupported("quantizer_conf.codec_dim", q["codec_dim"], "input/output projections not built")
+    if q.get("codec_range", None) is not None:
+        raise _unsupported("quantizer_conf.codec_range", q["codec_range"])
+    if q.get("q0_ds_ratio", 1) != 1:
+        raise _unsupported("quantizer_conf.q0_ds_ratio", q["q0_ds_ratio"])
+    act_params = dict(enc.get("activation_params", {"alpha": 1.0}) or {})
+    norm_params = dict(enc.get("norm_params", {}) or {})
+    seq_model = enc.get("seq_model", "lstm")
+    ratios = tuple(int(r) for r in shared("ratios", [8, 5, 4, 2]))
+    arch = ArchSpec(
+        sample_rate=int(m.get("target_sample_hz", cfg.get("sampling_rate", 16000))),
+        input_channels=1,
+        audio_normalize=bool(m.get("audio_normalize", False)),
+        n_filters=int(shared("n_filters", 32)),
+        dimension=int(enc.get("dimension", 128)),
+        ratios=ratios,
+        kernel_size=int(shared("kernel_size", 7)),
+        last_kernel_size=int(shared("last_kernel_size", 7)),
+        residual_kernel_size=int(shared("residual_kernel_size", 3)),
+        n_residual_layers=1,
+        dilation_base=int(shared("dilation_base", 2)),
+        compress=int(shared("compress", 2)),
+        lstm_layers=int(shared("seq_layer_num", 2)) if seq_model == "lstm" else 0,
+        lstm_skip=bool(shared("res_seq", True)),
+        elu_alpha=float(act_params.get("alpha", 1.0)),
+        gn_eps=float(norm_params.get("eps", 1e-5)),
+        codebook_size=int(q.get("codebook_size", 1024)),
+        codebook_dim=int(enc.get("dimension", 128)),
+        num_quantizers=int(q.get("num_quantizers", 8)),
+        encoder_hop_length=int(q.get("encoder_hop_length", 320)),
+        quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
+        use_ddp=bool(q.get("use_ddp", True)),
+    )
+    return arch
+
+
+# ----------------------------------------------------------------------------------------------
+# Recipe configs (the two architectures BASELINE.json names), as config.yaml-shaped dicts.
+# Values follow egs/LibriTTS/codec/conf/encodec_16k_n32_600k_step_ds640.yaml:1-53 (ds640) and the
+# class-default ratios of SEANetEncoder (seanet_encoder.py:92) for ds320.
+# ----------------------------------------------------------------------------------------------
+def recipe_config(name: str) -> Dict[str, Any]:
+    if name == "ds640":
+        ratios, hop = [8, 5, 4, 2, 2], 640
+    elif name == "ds320":
+        ratios, hop = [8, 5, 4, 2], 320
+    elif name == "tiny":  # small architecture used by the committed golden fixtures
+        return {
+            "input_size": 1, "sampling_rate": 16000,
+            "encoder": "encodec_seanet_encoder",
+            "encoder_conf": {"ratios": [4, 2], "norm": "time_group_norm", "causal": False,
+                             "n_filters": 8, "dimension": 16},
+            "quantizer": "costume_quantizer",
+            "quantizer_conf": {"codebook_size": 64, "num_quantizers": 6, "ema_decay": 0.99,
+                               "kmeans_init": True, "sampling_rate": 16000, "use_ddp": True,
+                               "encoder_hop_length": 8},
+            "decoder": "encodec_seanet_decoder",
+            "decoder_conf": {"ratios": [4, 2], "norm": "time_group_norm", "causal": False,
+                             "n_filters": 8},
+            "discriminator": "multiple_disc",
+            "discriminator_conf": {"disc_conf_list": []},
+            "model": "encodec",
+            "model_conf": {"odim": 16, "multi_spectral_window_powers_of_two": [],
+                           "target_sample_hz": 16000, "audio_normalize": True,
+                           "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None},
+        }
+    else:
+        raise KeyError(name)
+    return {
+        "input_size": 1, "sampling_rate": 16000,
+        "encoder": "encodec_seanet_encoder",
+        "encoder_conf": {"ratios": list(ratios), "norm": "time_group_norm", "causal": False},
+        "quantizer": "costume_quantizer",
+        "quantizer_conf": {"codebook_size": 1024, "num_quantizers": 32, "ema_decay": 0.99,
+                           "kmeans_init": True, "sampling_rate": 16000, "quantize_dropout": True,
+                           "rand_num_quant": [2, 4, 8, 16, 32], "use_ddp": True,
+                           "encoder_hop_length": hop},
+        "decoder": "encodec_seanet_decoder",
+        "decoder_conf": {"ratios": list(ratios), "norm": "time_group_norm", "causal": False},
+        "discriminator": "multiple_disc",
+        "discriminator_conf": {"disc_conf_list": [
+            {"name": "encodec_multi_scale_stft_discriminator", "filters": 32}]},
+        "model": "encodec",
+        "model_conf": {"odim": 128, "multi_spectral_window_powers_of_two": [],
+                       "target_sample_hz": 16000, "audio_normalize": True,
+                       "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None},
+    }

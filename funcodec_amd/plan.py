@@ -1,0 +1,105 @@
+"""Layer plan of the SEANet encoder / decoder and the checkpoint keys each layer owns.
+
+The module indices reproduce the positions inside the reference's ``nn.Sequential``
+(funcodec/models/encoder/seanet_encoder.py:109-160, funcodec/models/decoder/seanet_decoder.py:111-164)
+because those integers are part of the checkpoint format (``encoder.model.{i}...`` keys,
+SURVEY.md §8a row a19).  The C++ engine (csrc/engine.cpp) builds the same plan from ``fc_arch``;
+``tests/test_host.py`` checks the two agree name-for-name.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Dict, List, Tuple
+
+from .config import ArchSpec
+
+
+@dataclasses.dataclass
+class ConvOp:
+    kind: str            # "conv" | "convtr" | "lstm"
+    key: str             # state_dict prefix, e.g. "encoder.model.3.conv"
+    cin: int
+    cout: int
+    k: int = 1
+    stride: int = 1
+    role: str = ""       # "first" | "shortcut" | "block1" | "block3" | "down" | "up" | "last" | "lstm"
+
+
+def encoder_plan(a: ArchSpec) -> List[ConvOp]:
+    ops: List[ConvOp] = []
+    idx = 0
+    mult = 1
+    ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", a.input_channels, a.n_filters, a.kernel_size, 1, "first"))
+    idx += 1
+    for ratio in reversed(a.ratios):
+        c = mult * a.n_filters
+        hid = c // a.compress
+        p = f"encoder.model.{idx}"
+        ops.append(ConvOp("conv", f"{p}.shortcut.conv", c, c, 1, 1, "shortcut"))
+        ops.append(ConvOp("conv", f"{p}.block.1.conv", c, hid, a.residual_kernel_size, 1, "block1"))
+        ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c, 1, 1, "block3"))
+        idx += 1          # resblock
+        idx += 1          # ELU
+        ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", c, 2 * c, 2 * ratio, ratio, "down"))
+        idx += 1
+        mult *= 2
+    c = mult * a.n_filters
+    if a.lstm_layers > 0:
+        ops.append(ConvOp("lstm", f"encoder.model.{idx}.lstm", c, c, role="lstm"))
+        idx += 1
+    idx += 1              # ELU
+    ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", c, a.dimension, a.last_kernel_size, 1, "last"))
+    return ops
+
+
+def decoder_plan(a: ArchSpec) -> List[ConvOp]:
+    ops: List[ConvOp] = []
+    idx = 0
+    mult = 2 ** len(a.ratios)
+    c = mult * a.n_filters
+    ops.append(ConvOp("conv", f"decoder.model.{idx}.conv", a.dimension, c, a.kernel_size, 1, "first"))
+    idx += 1
+    if a.lstm_layers > 0:
+        ops.append(ConvOp("lstm", f"decoder.model.{idx}.lstm", c, c, role="lstm"))
+        idx += 1
+    for ratio in a.ratios:
+        c = mult * a.n_filters
+        idx += 1          # ELU
+        ops.append(ConvOp("convtr", f"decoder.model.{idx}.convtr", c, c // 2, 2 * ratio, ratio, "up"))
+        idx += 1
+        c2 = c // 2
+        hid = c2 // a.compress
+        p = f"decoder.model.{idx}"
+        ops.append(ConvOp("conv", f"{p}.shortcut.conv", c2, c2, 1, 1, "shortcut"))
+        ops.append(ConvOp("conv", f"{p}.block.1.conv", c2, hid, a.residual_kernel_size, 1, "block1"))
+        ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c2, 1, 1, "block3"))
+        idx += 1
+        mult //= 2
+    idx += 1              # ELU
+    ops.append(ConvOp("conv", f"decoder.model.{idx}.conv", a.n_filters, a.input_channels, a.last_kernel_size, 1, "last"))
+    return ops
+
+
+def expected_tensors(a: ArchSpec) -> Dict[str, Tuple[int, ...]]:
+    """Every checkpoint tensor the hot path consumes: key -> shape (reference layout)."""
+    out: Dict[str, Tuple[int, ...]] = {}
+    for op in encoder_plan(a) + decoder_plan(a):
+        if op.kind == "conv":
+            out[f"{op.key}.conv.weight"] = (op.cout, op.cin, op.k)
+            out[f"{op.key}.conv.bias"] = (op.cout,)
+            out[f"{op.key}.norm.weight"] = (op.cout,)
+            out[f"{op.key}.norm.bias"] = (op.cout,)
+        elif op.kind == "convtr":
+            out[f"{op.key}.convtr.weight"] = (op.cin, op.cout, op.k)
+            out[f"{op.key}.convtr.bias"] = (op.cout,)
+            out[f"{op.key}.norm.weight"] = (op.cout,)
+            out[f"{op.key}.norm.bias"] = (op.cout,)
+        else:
+            h = op.cin
+            for l in range(a.lstm_layers):
+                out[f"{op.key}.weight_ih_l{l}"] = (4 * h, h)
+                out[f"{op.key}.weight_hh_l{l}"] = (4 * h, h)
+                out[f"{op.key}.bias_ih_l{l}"] = (4 * h,)
+                out[f"{op.key}.bias_hh_l{l}"] = (4 * h,)
+    out["quantizer.rq.model.embed"] = (a.num_quantizers, a.codebook_size, a.codebook_dim)
+    return out

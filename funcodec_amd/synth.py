@@ -1,0 +1,109 @@
+"""Deterministic synthetic checkpoints in the reference's ``config.yaml`` + ``model.pth`` format.
+
+No pretrained FunCodec checkpoint can be downloaded here (no network), so parity and the benchmark
+run on seeded random weights laid out exactly as ``torch.save(model.state_dict())`` of the reference
+writes them (funcodec/train/trainer.py:410; key list in SURVEY.md §8a row a19).  The generator is
+pure numpy (``np.random.Generator(PCG64(seed))``) so the very same tensors can be re-created on the
+GPU box, where the reference and the 230 MB of weights cannot travel; the golden fixtures under
+``tests/golden`` store only (config name, seed) plus the reference's outputs for them.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, Dict, Optional
+
+import numpy as np
+
+from .config import ArchSpec, arch_from_config, recipe_config
+from .plan import decoder_plan, encoder_plan
+
+
+def make_state_dict(arch: ArchSpec, seed: int = 0, codebook_sigma_decay: float = 1.0,
+                    with_training_extras: bool = True) -> Dict[str, np.ndarray]:
+    """Seeded random weights keyed like the reference's state_dict.
+
+    Conv / LSTM weights use the bound torch's default init would give (uniform(+-1/sqrt(fan_in)));
+    GroupNorm gamma/beta are randomised around (1, 0) so that a kernel which forgot the affine part
+    cannot pass.  ``codebook_sigma_decay`` < 1 gives depth-decaying codebooks (sigma_i = decay**i),
+    the case SURVEY.md §7 found to provoke exact fp32 ties in the nearest-neighbour search.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd: Dict[str, np.ndarray] = {}
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    for op in encoder_plan(arch) + decoder_plan(arch):
+        if op.kind in ("conv", "convtr"):
+            inner = "conv" if op.kind == "conv" else "convtr"
+            wshape = (op.cout, op.cin, op.k) if op.kind == "conv" else (op.cin, op.cout, op.k)
+            fan_in = op.cin * op.k if op.kind == "conv" else op.cout * op.k  # torch's fan_in for ConvTranspose
+            bound = 1.0 / np.sqrt(fan_in)
+            sd[f"{op.key}.{inner}.weight"] = uni(wshape, bound)
+            sd[f"{op.key}.{inner}.bias"] = uni((op.cout,), bound)
+            sd[f"{op.key}.norm.weight"] = (1.0 + 0.1 * rng.standard_normal(op.cout)).astype(np.float32)
+            sd[f"{op.key}.norm.bias"] = (0.1 * rng.standard_normal(op.cout)).astype(np.float32)
+        else:
+            h = op.cin
+            bound = 1.0 / np.sqrt(h)
+            for l in range(arch.lstm_layers):
+                sd[f"{op.key}.weight_ih_l{l}"] = uni((4 * h, h), bound)
+                sd[f"{op.key}.weight_hh_l{l}"] = uni((4 * h, h), bound)
+                sd[f"{op.key}.bias_ih_l{l}"] = uni((4 * h,), bound)
+                sd[f"{op.key}.bias_hh_l{l}"] = uni((4 * h,), bound)
+    nq, K, D = arch.num_quantizers, arch.codebook_size, arch.codebook_dim
+    sig = (codebook_sigma_decay ** np.arange(nq, dtype=np.float64)).astype(np.float32)[:, None, None]
+    embed = rng.standard_normal((nq, K, D)).astype(np.float32) * sig
+    pfx = "quantizer.rq.model"
+    sd[f"{pfx}.inited"] = np.ones((nq, 1), np.float32)
+    sd[f"{pfx}.cluster_size"] = np.ones((nq, K), np.float32)
+    sd[f"{pfx}.embed"] = embed
+    sd[f"{pfx}.embed_avg"] = embed.copy()
+    if with_training_extras:
+        # keys a real checkpoint carries and the inference engine must skip
+        # (discriminator.* and mel_spec_transforms.*)
+        sd["discriminator.discriminators.0.dummy.weight"] = np.zeros((4, 4), np.float32)
+    return sd
+
+
+def synthetic_audio(batch: int, n_samples: int, seed: int = 1234, kind: str = "noise") -> np.ndarray:
+    """Deterministic test audio [batch, n_samples] fp32.
+
+    ``noise``: 0.1*N(0,1) (BASELINE.md's benchmark input).  ``tones``: a few decaying sinusoids plus
+    low-level noise with a different loudness per utterance, closer to speech dynamics.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if kind == "noise":
+        return (0.1 * rng.standard_normal((batch, n_samples))).astype(np.float32)
+    t = np.arange(n_samples, dtype=np.float64) / 16000.0
+    out = np.zeros((batch, n_samples), np.float64)
+    for b in range(batch):
+        for _ in range(4):
+            f = rng.uniform(80.0, 3500.0)
+            ph = rng.uniform(0, 2 * np.pi)
+            am = rng.uniform(0.05, 0.3)
+            dec = rng.uniform(0.0, 3.0)
+            out[b] += am * np.sin(2 * np.pi * f * t + ph) * np.exp(-dec * t)
+        out[b] += 0.01 * rng.standard_normal(n_samples)
+        out[b] *= rng.uniform(0.2, 1.0)
+    return out.astype(np.float32)
+
+
+def write_checkpoint(out_dir: str, config: Dict[str, Any], state: Dict[str, np.ndarray]) -> (str, str):
+    """Write ``config.yaml`` + ``model.pth`` exactly like a released FunCodec model directory."""
+    import torch
+    import yaml
+    os.makedirs(out_dir, exist_ok=True)
+    cfg_path = os.path.join(out_dir, "config.yaml")
+    pth_path = os.path.join(out_dir, "model.pth")
+    with open(cfg_path, "wt", encoding="utf-8") as f:
+        yaml.safe_dump(config, f)
+    torch.save({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}, pth_path)
+    return cfg_path, pth_path
+
+
+def make_checkpoint(out_dir: str, name: str = "ds640", seed: int = 0,
+                    codebook_sigma_decay: float = 1.0) -> (str, str):
+    cfg = recipe_config(name)
+    arch = arch_from_config(cfg)
+    return write_checkpoint(out_dir, cfg, make_state_dict(arch, seed, codebook_sigma_decay))

@@ -1,0 +1,167 @@
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.npz by running the REAL reference
+(/root/reference, via oracle/ref_shim.py) on CPU in the build container, and pins
+oracle/torch_oracle.py against it bit-for-bit while doing so.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Weights and audio are never stored: they are re-created from (config name, seed) by
+funcodec_amd.synth, which is pure numpy and therefore identical on the GPU box.  Only the reference's
+OUTPUTS are committed.  The reference has no golden vectors of its own, so these
+files are the pin.
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+from funcodec_amd.config import arch_from_config, recipe_config  # noqa: E402
+from funcodec_amd.synth import make_state_dict, synthetic_audio, write_checkpoint  # noqa: E402
+from torch_oracle import Oracle  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# name, config, weight seed, codebook decay, audio kind, audio seed, B, T, bit_width
+CASES = [
+    ("tiny_b3_t1003", "tiny", 7, 1.0, "tones", 11, 3, 1003, None),
+    ("tiny_b1_t6", "tiny", 7, 1.0, "noise", 12, 1, 6, None),
+    ("tiny_b2_t64_decay", "tiny", 8, 0.8, "noise", 13, 2, 64, None),
+    ("ds320_b1_t16000", "ds320", 0, 1.0, "noise", 1234, 1, 16000, None),
+    ("ds640_b2_t16000", "ds640", 0, 1.0, "tones", 21, 2, 16000, None),
+    ("ds640_b1_t9999_bw4000", "ds640", 0, 1.0, "noise", 22, 1, 9999, 4000),
+]
+
+
+def reference_config(cfg):
+    """The two tweaks SURVEY.md §8c lists for running the reference on a GPU-less box."""
+    cfg = json.loads(json.dumps(cfg))
+    cfg["model_conf"]["multi_spectral_window_powers_of_two"] = []
+    for k in ("frontend", "normalize"):
+        cfg.setdefault(k, None)
+        cfg.setdefault(k + "_conf", {})
+    return cfg
+
+
+def build_reference(cfg_name, seed, decay, tmp):
+    from funcodec.bin.codec_inference import Speech2Token
+    cfg = recipe_config(cfg_name)
+    arch = arch_from_config(cfg)
+    sd = make_state_dict(arch, seed, decay)
+    d = os.path.join(tmp, f"{cfg_name}_{seed}_{decay}")
+    cfg_path, pth_path = write_checkpoint(d, reference_config(cfg), sd)
+    s2t = Speech2Token(cfg_path, pth_path, device="cpu")
+    # every hot-path tensor must have been accepted by the reference's tolerant loader
+    ref_sd = s2t.model.state_dict()
+    for k, v in sd.items():
+        if k.startswith("discriminator."):
+            continue
+        assert k in ref_sd, f"synthetic key {k} unknown to the reference"
+        assert tuple(ref_sd[k].shape) == v.shape, (k, ref_sd[k].shape, v.shape)
+        assert torch.equal(ref_sd[k], torch.from_numpy(v)), f"{k} not loaded"
+    for k in ref_sd:
+        if k.startswith(("encoder.", "decoder.", "quantizer.")):
+            assert k in sd, f"reference key {k} missing from the synthetic checkpoint"
+    return s2t, cfg, sd
+
+
+def main():
+    torch.manual_seed(0)
+    os.makedirs(GOLD, exist_ok=True)
+    manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "cases": {}}
+    cache = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, cfg_name, wseed, decay, akind, aseed, B, T, bw in CASES:
+            key = (cfg_name, wseed, decay)
+            if key not in cache:
+                cache[key] = build_reference(cfg_name, wseed, decay, tmp)
+            s2t, cfg, sd = cache[key]
+            wav = synthetic_audio(B, T, aseed, akind)
+            x = torch.from_numpy(wav)
+            idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=bw, use_scale=True, run_mod="inference")
+            idx_e, _, _, _ = s2t(x.unsqueeze(1), bit_width=bw, run_mod="encode")
+            assert torch.equal(idx[0], idx_e[0])
+            quant, scale = embs[0]
+            # decode path from the reference's own indices: [B,Tf,nq]
+            tok = idx[0].permute(1, 2, 0).contiguous()
+            _, _, recon_dec, _ = s2t(tok, run_mod="decode")
+            _, _, recon_emb, _ = s2t(quant, run_mod="decode_emb")
+            # intermediate: encoder output from the reference modules
+            with torch.no_grad():
+                emb_ref, scale_ref = s2t.model._encode_frame(x.unsqueeze(1))
+
+            # ---- pin the restated oracle against the reference, bit for bit -----------------
+            orc = Oracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
+            o = orc.inference(x, bit_width=bw, use_scale=True)
+            assert torch.equal(o["encoder_out"], emb_ref), f"{name}: oracle encoder != reference"
+            assert torch.equal(o["code_indices"][0], idx[0]), f"{name}: oracle indices != reference"
+            assert torch.equal(o["code_embeddings"][0][0], quant), f"{name}: oracle quantized != reference"
+            assert torch.equal(o["recon_speech"], recon), f"{name}: oracle recon != reference"
+            assert torch.equal(o["sub_quants"][0], subs[0]), f"{name}: oracle sub_quants != reference"
+            od, _ = orc.decode_codes(tok)
+            assert torch.equal(od, recon_dec), f"{name}: oracle decode != reference"
+            assert torch.equal(orc.decode_emb(quant), recon_emb)
+
+            np.savez_compressed(
+                os.path.join(GOLD, name + ".npz"),
+                indices=idx[0].numpy().astype(np.int16),
+                encoder_out=emb_ref.numpy(), scale=scale_ref.numpy(),
+                quantized=quant.numpy(), recon=recon.numpy(),
+                recon_from_codes=recon_dec.numpy(),
+            )
+            manifest["cases"][name] = dict(config=cfg_name, weight_seed=wseed, codebook_decay=decay,
+                                           audio_kind=akind, audio_seed=aseed, batch=B, samples=T,
+                                           bit_width=bw, n_q=int(idx[0].shape[0]), frames=int(idx[0].shape[2]))
+            print(f"[golden] {name}: idx{tuple(idx[0].shape)} recon{tuple(recon.shape)} oracle==reference OK")
+
+        # ---- RVQ-only hard case: depth-decaying codebooks (exact-tie provoking) ----
+        from funcodec.modules.quantization.ddp_core_vq import DistributedResidualVectorQuantization
+        for name, decay, seed in (("rvq_decay08", 0.8, 31), ("rvq_flat", 1.0, 32)):
+            arch = arch_from_config(recipe_config("ds640"))
+            rng = np.random.Generator(np.random.PCG64(seed))
+            sig = (decay ** np.arange(32, dtype=np.float64)).astype(np.float32)[:, None, None]
+            embed = rng.standard_normal((32, 1024, 128)).astype(np.float32) * sig
+            z = rng.standard_normal((8, 250, 128)).astype(np.float32) * 1.5
+            rvq = DistributedResidualVectorQuantization(num_quantizers=32, dim=128, codebook_size=1024,
+                                                        codebook_dim=None, decay=0.99, kmeans_init=True,
+                                                        kmeans_iters=50, threshold_ema_dead_code=2).eval()
+            for layer in rvq.layers:
+                layer.training = False
+                layer._codebook.training = False
+            rvq.training = False
+            rvq.inited.fill_(1.0)
+            rvq.embed.copy_(torch.from_numpy(embed))
+            with torch.no_grad():
+                qo, oi, _, osub = rvq(torch.from_numpy(z).permute(0, 2, 1), n_q=32)
+            orc = Oracle(recipe_config("ds640"), {"quantizer.rq.model.embed": torch.from_numpy(embed)})
+            q2, i2, s2 = orc.rvq_forward(torch.from_numpy(z), 32)
+            assert torch.equal(i2, oi) and torch.equal(q2, qo.permute(0, 2, 1)) and torch.equal(s2, osub)
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"),
+                                indices=oi.numpy().astype(np.int16), quantized=qo.permute(0, 2, 1).numpy())
+            manifest["cases"][name] = dict(kind="rvq", codebook_decay=decay, seed=seed, rows=[8, 250], n_q=32)
+            print(f"[golden] {name}: RVQ-only, oracle==reference OK")
+
+        # ---- checkpoint key list of the real reference models (format pin) ----------------------
+        for cfg_name in ("ds320", "ds640"):
+            s2t, _, _ = cache[(cfg_name, 0, 1.0)]
+            keys = {k: list(v.shape) for k, v in s2t.model.state_dict().items()
+                    if k.startswith(("encoder.", "decoder.", "quantizer."))}
+            with open(os.path.join(GOLD, f"state_dict_keys_{cfg_name}.json"), "wt") as f:
+                json.dump(keys, f, indent=0, sort_keys=True)
+    with open(os.path.join(GOLD, "MANIFEST.json"), "wt") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()
