@@ -1,0 +1,86 @@
+"""ctypes binding of include/funcodec_amd.h (the C ABI of the gfx950 engine)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+FC_MAX_RATIOS = 8
+FC_ABI_VERSION = 1
+
+
+class FcArch(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("sample_rate", C.c_int32), ("audio_normalize", C.c_int32),
+        ("n_filters", C.c_int32), ("dimension", C.c_int32), ("n_ratios", C.c_int32),
+        ("ratios", C.c_int32 * FC_MAX_RATIOS),
+        ("kernel_size", C.c_int32), ("last_kernel_size", C.c_int32), ("residual_kernel_size", C.c_int32),
+        ("compress", C.c_int32), ("lstm_layers", C.c_int32), ("lstm_skip", C.c_int32),
+        ("elu_alpha", C.c_float), ("gn_eps", C.c_float),
+        ("codebook_size", C.c_int32), ("num_quantizers", C.c_int32),
+    ]
+
+
+class FcWork(C.Structure):
+    _fields_ = [("total_flops", C.c_double), ("total_bytes", C.c_double), ("conv_flops", C.c_double),
+                ("conv_bytes", C.c_double), ("lstm_flops", C.c_double), ("rvq_flops", C.c_double),
+                ("conv_launches", C.c_int32), ("total_launches", C.c_int32)]
+
+
+# every symbol include/funcodec_amd.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "fc_abi_version": (C.c_int, []),
+    "fc_last_error": (C.c_char_p, []),
+    "fc_engine_create": (C.c_int, [C.POINTER(FcArch), C.c_int, C.POINTER(_P)]),
+    "fc_engine_destroy": (None, [_P]),
+    "fc_engine_num_weights": (C.c_int, [_P]),
+    "fc_engine_weight_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
+    "fc_engine_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
+    "fc_engine_finalize": (C.c_int, [_P]),
+    "fc_engine_hop_length": (C.c_int, [_P]),
+    "fc_engine_frames": (C.c_int, [_P, C.c_int]),
+    "fc_engine_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
+    "fc_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "fc_decode_emb": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "fc_decode_codes": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "fc_encode_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "fc_rvq_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "fc_layer_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "fc_layer_out_len": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "fc_lstm_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "fc_engine_work": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(FcWork)]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libfuncodec_amd.so (built in-tree).  There is no fallback: if the HIP library cannot be
+    loaded the product path raises."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m funcodec_amd.build` (hipcc, gfx950). "
+            "funcodec_amd has no CPU or PyTorch fallback path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError = ABI drift, loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fc_abi_version() != FC_ABI_VERSION:
+        raise RuntimeError("libfuncodec_amd.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().fc_last_error().decode("utf-8", "replace")

@@ -1,0 +1,771 @@
+// Engine: layer plan, checkpoint ingestion / weight re-layout, workspace planning and the C ABI
+// (include/funcodec_amd.h).  All device work is enqueued on the caller's stream; nothing here
+// synchronises with the host after fc_engine_finalize().
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/funcodec_amd.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) { g_err = msg; return 1; }
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+struct HostTensor {
+    std::vector<int64_t> dims;
+    std::vector<float> data;
+    bool set = false;
+};
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+};
+
+// One SConv1d / SConvTranspose1d (+ its GroupNorm) of the plan.
+struct ConvLayer {
+    std::string prefix;     // e.g. "encoder.model.3.conv" / "decoder.model.3.convtr"
+    bool transposed = false;
+    int cin = 0, cout = 0, k = 1, stride = 1;
+    bool has_norm = true;
+    // GEMM view
+    int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
+    int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
+    float *wt = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;   // device
+};
+
+struct LstmLayer {
+    ConvLayer inproj;       // W_ih as a k=1 GEMM with permuted rows, bias = b_ih + b_hh
+    float* whh = nullptr;   // [4H][H] rows permuted to (blk, unit, gate)
+};
+
+struct LstmBlock {
+    std::string prefix;     // "encoder.model.16.lstm"
+    int H = 0;
+    std::vector<LstmLayer> layers;
+};
+
+struct Act {               // raw tensor [B][C][T] + pending GroupNorm affine (null = already final)
+    float* raw = nullptr;
+    float* aff = nullptr;
+    int C = 0, T = 0;
+};
+
+struct Ctx {
+    int B = 0;
+    hipStream_t st = nullptr;
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    bool dry = false;
+    int err = 0;
+    int launches = 0, conv_launches = 0;
+    double conv_flops = 0, conv_bytes = 0, lstm_flops = 0, rvq_flops = 0, other_bytes = 0;
+    template <typename T>
+    T* alloc(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = dry ? nullptr : (T*)(base + off);
+        off += n * sizeof(T);
+        if (!dry && off > cap) { err = 1; g_err = "workspace too small"; return nullptr; }
+        return p;
+    }
+};
+
+int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+struct fc_engine {
+    fc_arch arch;
+    int device = 0;
+    bool finalized = false;
+    std::vector<std::pair<std::string, std::vector<int64_t>>> expected;   // checkpoint contract, in plan order
+    std::map<std::string, HostTensor> host;
+    // plan
+    ConvLayer enc_first, enc_last, dec_first, dec_last;
+    struct Stage { ConvLayer shortcut, block1, block3, resample; };       // resample = down (enc) / up (dec)
+    std::vector<Stage> enc_stages, dec_stages;
+    LstmBlock enc_lstm, dec_lstm;
+    std::map<std::string, ConvLayer*> by_prefix;
+    std::map<std::string, LstmBlock*> lstm_by_prefix;
+    // quantiser
+    float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
+    std::vector<void*> dev_allocs;
+};
+
+namespace {
+
+// ---- plan construction (mirrors nn.Sequential indices: seanet_encoder.py:109-160, seanet_decoder.py:111-164)
+void add_conv_expect(fc_engine* e, ConvLayer& L) {
+    const std::string inner = L.transposed ? ".convtr" : ".conv";
+    if (L.transposed)
+        e->expected.push_back({L.prefix + inner + ".weight", {L.cin, L.cout, L.k}});
+    else
+        e->expected.push_back({L.prefix + inner + ".weight", {L.cout, L.cin, L.k}});
+    e->expected.push_back({L.prefix + inner + ".bias", {L.cout}});
+    e->expected.push_back({L.prefix + ".norm.weight", {L.cout}});
+    e->expected.push_back({L.prefix + ".norm.bias", {L.cout}});
+    e->by_prefix[L.prefix] = &L;
+}
+
+void choose_tiling(ConvLayer& L);
+
+ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed = false) {
+    ConvLayer L;
+    L.prefix = prefix; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.transposed = transposed;
+    if (!transposed) { L.M = cout; L.gk = k; L.gstride = stride; }
+    else { L.M = cout * stride; L.gk = 2; L.gstride = 1; }   // 2-tap GEMM over the r output phases
+    choose_tiling(L);
+    return L;
+}
+
+void build_plan(fc_engine* e) {
+    const fc_arch& a = e->arch;
+    const int nf = a.n_filters;
+    auto name = [](const char* side, int idx, const char* suffix) {
+        return std::string(side) + ".model." + std::to_string(idx) + suffix;
+    };
+    // ---- encoder
+    int idx = 0, mult = 1;
+    e->enc_first = mk_conv(name("encoder", idx, ".conv"), 1, nf, a.kernel_size, 1);
+    idx++;
+    e->enc_stages.resize(a.n_ratios);
+    for (int s = 0; s < a.n_ratios; ++s) {
+        const int ratio = a.ratios[a.n_ratios - 1 - s];
+        const int c = mult * nf, hid = c / a.compress;
+        auto& S = e->enc_stages[s];
+        S.shortcut = mk_conv(name("encoder", idx, ".shortcut.conv"), c, c, 1, 1);
+        S.block1 = mk_conv(name("encoder", idx, ".block.1.conv"), c, hid, a.residual_kernel_size, 1);
+        S.block3 = mk_conv(name("encoder", idx, ".block.3.conv"), hid, c, 1, 1);
+        idx += 2;
+        S.resample = mk_conv(name("encoder", idx, ".conv"), c, 2 * c, 2 * ratio, ratio);
+        idx++;
+        mult *= 2;
+    }
+    const int cb = mult * nf;
+    if (a.lstm_layers > 0) {
+        e->enc_lstm.prefix = name("encoder", idx, ".lstm");
+        e->enc_lstm.H = cb;
+        idx++;
+    }
+    idx++;
+    e->enc_last = mk_conv(name("encoder", idx, ".conv"), cb, a.dimension, a.last_kernel_size, 1);
+    // ---- decoder
+    idx = 0;
+    e->dec_first = mk_conv(name("decoder", idx, ".conv"), a.dimension, cb, a.kernel_size, 1);
+    idx++;
+    if (a.lstm_layers > 0) {
+        e->dec_lstm.prefix = name("decoder", idx, ".lstm");
+        e->dec_lstm.H = cb;
+        idx++;
+    }
+    e->dec_stages.resize(a.n_ratios);
+    mult = 1 << a.n_ratios;
+    for (int s = 0; s < a.n_ratios; ++s) {
+        const int ratio = a.ratios[s];
+        const int c = mult * nf, c2 = c / 2, hid = c2 / a.compress;
+        auto& S = e->dec_stages[s];
+        idx++;
+        S.resample = mk_conv(name("decoder", idx, ".convtr"), c, c2, 2 * ratio, ratio, true);
+        idx++;
+        S.shortcut = mk_conv(name("decoder", idx, ".shortcut.conv"), c2, c2, 1, 1);
+        S.block1 = mk_conv(name("decoder", idx, ".block.1.conv"), c2, hid, a.residual_kernel_size, 1);
+        S.block3 = mk_conv(name("decoder", idx, ".block.3.conv"), hid, c2, 1, 1);
+        idx++;
+        mult /= 2;
+    }
+    idx++;
+    e->dec_last = mk_conv(name("decoder", idx, ".conv"), nf, 1, a.last_kernel_size, 1);
+
+    // ---- checkpoint contract, in execution order
+    add_conv_expect(e, e->enc_first);
+    for (auto& S : e->enc_stages) {
+        add_conv_expect(e, S.shortcut); add_conv_expect(e, S.block1); add_conv_expect(e, S.block3);
+        add_conv_expect(e, S.resample);
+    }
+    auto add_lstm = [&](LstmBlock& lb) {
+        if (lb.H == 0) return;
+        lb.layers.resize(a.lstm_layers);
+        for (int l = 0; l < a.lstm_layers; ++l) {
+            const std::string sfx = "_l" + std::to_string(l);
+            lb.layers[l].inproj = mk_conv(lb.prefix + ".inproj" + sfx, lb.H, 4 * lb.H, 1, 1);
+            lb.layers[l].inproj.has_norm = false;
+            e->expected.push_back({lb.prefix + ".weight_ih" + sfx, {4 * lb.H, lb.H}});
+            e->expected.push_back({lb.prefix + ".weight_hh" + sfx, {4 * lb.H, lb.H}});
+            e->expected.push_back({lb.prefix + ".bias_ih" + sfx, {4 * lb.H}});
+            e->expected.push_back({lb.prefix + ".bias_hh" + sfx, {4 * lb.H}});
+        }
+        e->lstm_by_prefix[lb.prefix] = &lb;
+    };
+    add_lstm(e->enc_lstm);
+    add_conv_expect(e, e->enc_last);
+    add_conv_expect(e, e->dec_first);
+    add_lstm(e->dec_lstm);
+    for (auto& S : e->dec_stages) {
+        add_conv_expect(e, S.resample);
+        add_conv_expect(e, S.shortcut); add_conv_expect(e, S.block1); add_conv_expect(e, S.block3);
+    }
+    add_conv_expect(e, e->dec_last);
+    e->expected.push_back({"quantizer.rq.model.embed", {a.num_quantizers, a.codebook_size, a.dimension}});
+}
+
+// ---- weight packing -------------------------------------------------------------------------------
+void choose_tiling(ConvLayer& L) {  // NOLINT
+    if (L.M > 64) { L.BM = 128; L.BN = 128; }
+    else if (L.M > 32) { L.BM = 64; L.BN = 256; }
+    else { L.BM = 32; L.BN = 256; }
+    int cc = 2;
+    while (cc * 2 * L.gk <= 64 && cc * 2 <= 32) cc *= 2;
+    int cin_p2 = 2;
+    while (cin_p2 < L.cin) cin_p2 *= 2;
+    if (cc > cin_p2) cc = cin_p2;
+    L.CC = cc;
+    L.nchunk = ceil_div_i(L.cin, cc);
+    L.Mpad = ceil_div_i(L.M, L.BM) * L.BM;
+}
+
+template <typename T>
+int upload(fc_engine* e, const std::vector<T>& h, T** out) {
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, h.size() * sizeof(T) + 16));
+    HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    e->dev_allocs.push_back(d);
+    *out = (T*)d;
+    return 0;
+}
+
+// gemm weight accessor: w(m, ci, tap) and bias(m)
+int pack_gemm(fc_engine* e, ConvLayer& L, const std::vector<float>& wg /*[M][cin][gk]*/, const std::vector<float>& bg) {
+    const int Kc = L.gk * L.CC, mtiles = L.Mpad / L.BM;
+    std::vector<float> packed((size_t)mtiles * L.nchunk * Kc * L.BM, 0.f);
+    for (int mt = 0; mt < mtiles; ++mt)
+        for (int ch = 0; ch < L.nchunk; ++ch)
+            for (int kk = 0; kk < L.gk; ++kk)
+                for (int cl = 0; cl < L.CC; ++cl) {
+                    const int ci = ch * L.CC + cl;
+                    if (ci >= L.cin) continue;
+                    float* dst = &packed[(((size_t)(mt * L.nchunk + ch) * L.gk + kk) * L.CC + cl) * L.BM];
+                    for (int mm = 0; mm < L.BM; ++mm) {
+                        const int m = mt * L.BM + mm;
+                        if (m < L.M) dst[mm] = wg[((size_t)m * L.cin + ci) * L.gk + kk];
+                    }
+                }
+    std::vector<float> bpad(L.Mpad, 0.f);
+    for (int m = 0; m < L.M; ++m) bpad[m] = bg[m];
+    if (upload(e, packed, &L.wt)) return 1;
+    if (upload(e, bpad, &L.bias)) return 1;
+    return 0;
+}
+
+int pack_conv(fc_engine* e, ConvLayer& L) {
+    const std::string inner = L.transposed ? ".convtr" : ".conv";
+    const auto& W = e->host[L.prefix + inner + ".weight"].data;
+    const auto& Bv = e->host[L.prefix + inner + ".bias"].data;
+    if (!L.transposed) {
+        if (pack_gemm(e, L, W, Bv)) return 1;
+    } else {
+        // ConvTranspose1d(k = 2r, stride = r) as a 2-tap GEMM over phases: row m = co*r + p,
+        // tap 0 multiplies x[i-1] with w[ci][co][p + r], tap 1 multiplies x[i] with w[ci][co][p].
+        const int r = L.stride;
+        if (L.k != 2 * r) return fail("ConvTranspose1d with kernel != 2*stride is not supported: " + L.prefix);
+        std::vector<float> wg((size_t)L.M * L.cin * 2), bg(L.M);
+        for (int co = 0; co < L.cout; ++co)
+            for (int p = 0; p < r; ++p) {
+                const int m = co * r + p;
+                bg[m] = Bv[co];
+                for (int ci = 0; ci < L.cin; ++ci) {
+                    wg[((size_t)m * L.cin + ci) * 2 + 0] = W[((size_t)ci * L.cout + co) * L.k + p + r];
+                    wg[((size_t)m * L.cin + ci) * 2 + 1] = W[((size_t)ci * L.cout + co) * L.k + p];
+                }
+            }
+        if (pack_gemm(e, L, wg, bg)) return 1;
+    }
+    if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
+    if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
+    return 0;
+}
+
+int pack_lstm(fc_engine* e, LstmBlock& lb) {
+    const int H = lb.H;
+    if (H == 0) return 0;
+    if (H % 16 != 0) return fail("LSTM width must be a multiple of 16");
+    for (int l = 0; l < (int)lb.layers.size(); ++l) {
+        const std::string sfx = "_l" + std::to_string(l);
+        const auto& Wih = e->host[lb.prefix + ".weight_ih" + sfx].data;
+        const auto& Whh = e->host[lb.prefix + ".weight_hh" + sfx].data;
+        const auto& bih = e->host[lb.prefix + ".bias_ih" + sfx].data;
+        const auto& bhh = e->host[lb.prefix + ".bias_hh" + sfx].data;
+        // permuted row m' = blk*16 + u*4 + gate  <->  original row gate*H + blk*4 + u   (gate order i,f,g,o)
+        std::vector<float> wih_p((size_t)4 * H * H), whh_p((size_t)4 * H * H), b_p(4 * H);
+        for (int mp = 0; mp < 4 * H; ++mp) {
+            const int blk = mp / 16, u = (mp % 16) / 4, gate = mp % 4;
+            const int orig = gate * H + blk * 4 + u;
+            memcpy(&wih_p[(size_t)mp * H], &Wih[(size_t)orig * H], H * sizeof(float));
+            memcpy(&whh_p[(size_t)mp * H], &Whh[(size_t)orig * H], H * sizeof(float));
+            b_p[mp] = bih[orig] + bhh[orig];
+        }
+        LstmLayer& L = lb.layers[l];
+        if (pack_gemm(e, L.inproj, wih_p, b_p)) return 1;
+        if (upload(e, whh_p, &L.whh)) return 1;
+    }
+    return 0;
+}
+
+// ---- execution ------------------------------------------------------------------------------------
+struct ConvGeom { int Tout, padL, padR, count_T; };
+
+// SConv1d.forward padding arithmetic (conv.py:243-258, get_extra_padding_for_conv1d :57-64)
+ConvGeom conv_geom(const ConvLayer& L, int T) {
+    ConvGeom g;
+    if (!L.transposed) {
+        const int pt = (L.k - 1) - (L.stride - 1);
+        const int num = T - L.k + pt;
+        const int nfr = num >= 0 ? ceil_div_i(num, L.stride) : -((-num) / L.stride);   // ceil(n_frames) - 1
+        const int ideal = nfr * L.stride + (L.k - pt);
+        const int extra = ideal - T;
+        g.padR = pt / 2 + extra;
+        g.padL = pt - pt / 2;
+        g.Tout = nfr + 1;
+        g.count_T = g.Tout;
+    } else {
+        g.padL = 1; g.padR = 1;
+        g.Tout = T * L.stride;           // trimmed length
+        g.count_T = (T + 1) * L.stride;  // GroupNorm sees the untrimmed output (conv.py:287-303)
+    }
+    return g;
+}
+
+Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, int elu, int Tin,
+             float* out_override = nullptr, long long sB = 0, long long sM = 0, long long sT = 0) {
+    const ConvGeom g = conv_geom(L, Tin);
+    fc::ConvLaunch c;
+    c.s0 = s0; c.s1 = s1; c.elu = elu; c.alpha = e->arch.elu_alpha;
+    c.wt = L.wt; c.bias = L.bias;
+    c.B = cx.B; c.Cin = L.cin; c.Tin = Tin; c.M = L.M;
+    c.k = L.gk; c.stride = L.gstride; c.padL = g.padL; c.padR = g.padR;
+    c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk;
+    Act out;
+    out.C = L.cout; out.T = g.Tout;
+    if (L.transposed) {
+        c.Tout = Tin + 1; c.pad_zero = 1;
+        c.up_r = L.stride; c.trimL = L.stride - L.stride / 2; c.Tfinal = g.Tout;
+    } else {
+        c.Tout = g.Tout;
+    }
+    if (out_override) {
+        out.raw = out_override;
+        c.out_sB = sB; c.out_sM = sM; c.out_sT = sT;
+    } else {
+        out.raw = cx.alloc<float>((size_t)cx.B * L.cout * g.Tout);
+        c.out_sB = (long long)L.cout * g.Tout; c.out_sM = g.Tout; c.out_sT = 1;
+    }
+    c.out = out.raw;
+    const int nblk = fc::conv_nblk(c);
+    if (L.has_norm) {
+        c.partials = cx.alloc<double>((size_t)cx.B * nblk * 2);
+        out.aff = cx.alloc<float>((size_t)cx.B * L.cout * 2);
+    }
+    // accounting (algorithmic: real channel counts, every operand touched once)
+    cx.conv_flops += 2.0 * cx.B * (double)L.M * L.cin * L.gk * c.Tout;
+    cx.conv_bytes += 4.0 * cx.B * ((double)L.cin * Tin * (s1.used ? 2 : 1) + (double)L.cout * g.Tout);
+    cx.launches += L.has_norm ? 2 : 1;
+    cx.conv_launches += 1;
+    if (cx.dry || cx.err) return out;
+    hipError_t er = fc::launch_conv(c, cx.st);
+    if (er != hipSuccess) { cx.err = 1; g_err = "conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); return out; }
+    if (L.has_norm) {
+        er = fc::launch_gn_finalize(c.partials, nblk, (double)L.cout * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps,
+                                    cx.B, out.aff, cx.st);
+        if (er != hipSuccess) { cx.err = 1; g_err = std::string("gn_finalize launch failed: ") + hipGetErrorString(er); }
+    }
+    return out;
+}
+
+inline fc::Src src_of(const Act& a) { fc::Src s; s.ptr = a.raw; s.aff = a.aff; s.used = 1; return s; }
+
+// SLSTM.forward (lstm.py:22-28) without the skip; returns plain y [B][H][T]
+Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
+    const int H = lb.H, B = cx.B;
+    Act cur = in;
+    for (size_t l = 0; l < lb.layers.size(); ++l) {
+        const LstmLayer& L = lb.layers[l];
+        float* xproj = cx.alloc<float>((size_t)T * B * 4 * H);
+        run_conv(e, cx, L.inproj, src_of(cur), fc::Src(), 0, T, xproj, (long long)4 * H, 1, (long long)B * 4 * H);
+        float* state = cx.alloc<float>((size_t)3 * B * H);   // h ping, h pong, c
+        Act y;
+        y.C = H; y.T = T;
+        y.raw = cx.alloc<float>((size_t)B * H * T);
+        cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H;
+        cx.launches += T + 1;
+        if (!cx.dry && !cx.err) {
+            hipError_t er = hipMemsetAsync(state, 0, (size_t)3 * B * H * sizeof(float), cx.st);
+            float *h0 = state, *h1 = state + (size_t)B * H, *c = state + (size_t)2 * B * H;
+            for (int t = 0; t < T && er == hipSuccess; ++t) {
+                er = fc::launch_lstm_step(L.whh, xproj, (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, c, y.raw, B, H, T, t, cx.st);
+            }
+            if (er != hipSuccess) { cx.err = 1; g_err = std::string("lstm step failed: ") + hipGetErrorString(er); }
+        }
+        cur = y;
+    }
+    return cur;
+}
+
+// SEANetResnetBlock (seanet_encoder.py:16-61): returns the two raw branches whose GroupNorm'd sum is the output
+void run_resblock(fc_engine* e, Ctx& cx, const fc_engine::Stage& S, const Act& x, Act* sc, Act* b3) {
+    *sc = run_conv(e, cx, S.shortcut, src_of(x), fc::Src(), 0, x.T);
+    Act b1 = run_conv(e, cx, S.block1, src_of(x), fc::Src(), 1, x.T);
+    *b3 = run_conv(e, cx, S.block3, src_of(b1), fc::Src(), 1, b1.T);
+}
+
+// SEANetEncoder.forward: wav [B][T] (optionally divided by scale[b]) -> last conv (raw + affine), T -> Tf
+Act run_encoder(fc_engine* e, Ctx& cx, const float* wav, int T, const float* scale) {
+    fc::Src s; s.ptr = wav; s.div = scale; s.used = 1;
+    Act x = run_conv(e, cx, e->enc_first, s, fc::Src(), 0, T);
+    for (auto& S : e->enc_stages) {
+        Act sc, b3;
+        run_resblock(e, cx, S, x, &sc, &b3);
+        x = run_conv(e, cx, S.resample, src_of(sc), src_of(b3), 1, sc.T);
+    }
+    if (e->enc_lstm.H) {
+        Act y = run_lstm(e, cx, e->enc_lstm, x, x.T);
+        if (e->arch.lstm_skip) return run_conv(e, cx, e->enc_last, src_of(y), src_of(x), 1, x.T);
+        return run_conv(e, cx, e->enc_last, src_of(y), fc::Src(), 1, x.T);
+    }
+    return run_conv(e, cx, e->enc_last, src_of(x), fc::Src(), 1, x.T);
+}
+
+// SEANetDecoder.forward: z [B][D][Tf] plain -> last conv (raw [B][1][Tf*hop] + affine)
+Act run_decoder(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf) {
+    fc::Src s; s.ptr = z_bdt; s.used = 1;
+    Act x = run_conv(e, cx, e->dec_first, s, fc::Src(), 0, Tf);
+    fc::Src a0 = src_of(x), a1;
+    if (e->dec_lstm.H) {
+        Act y = run_lstm(e, cx, e->dec_lstm, x, x.T);
+        a0 = src_of(y);
+        if (e->arch.lstm_skip) a1 = src_of(x);
+    }
+    int T = Tf;
+    for (auto& S : e->dec_stages) {
+        Act up = run_conv(e, cx, S.resample, a0, a1, 1, T);
+        Act sc, b3;
+        run_resblock(e, cx, S, up, &sc, &b3);
+        a0 = src_of(sc); a1 = src_of(b3);
+        T = up.T;
+    }
+    return run_conv(e, cx, e->dec_last, a0, a1, 1, T);
+}
+
+int total_hop(const fc_engine* e) {
+    int h = 1;
+    for (int i = 0; i < e->arch.n_ratios; ++i) h *= e->arch.ratios[i];
+    return h;
+}
+
+int frames_for(const fc_engine* e, int T) {
+    for (int i = e->arch.n_ratios - 1; i >= 0; --i) T = ceil_div_i(T, e->arch.ratios[i]);
+    return T;
+}
+
+// ---- composite paths (each usable in dry mode for workspace sizing / work accounting) ---------------
+int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* codes, float* quantized,
+              float* sub_quants, float* scale, float* enc_out, float** quant_bdt_out) {
+    const int B = cx.B, D = e->arch.dimension, Tf = frames_for(e, T);
+    float* sc = nullptr;
+    if (e->arch.audio_normalize) {
+        sc = scale ? scale : cx.alloc<float>(B);
+        cx.launches++;
+        if (!cx.dry && !cx.err) {
+            if (fc::launch_volume(wav, B, T, sc, cx.st) != hipSuccess) return fail("volume kernel launch failed");
+        }
+    }
+    Act last = run_encoder(e, cx, wav, T, sc);
+    float* emb = enc_out ? enc_out : cx.alloc<float>((size_t)B * Tf * D);
+    float* qbdt = cx.alloc<float>((size_t)B * D * Tf);
+    cx.launches += 2;
+    cx.rvq_flops += 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D;
+    if (!cx.dry && !cx.err) {
+        if (last.T != Tf) return fail("internal: frame count mismatch");
+        // encoder output permuted to [B,Tf,D] (seanet_encoder.py:175) with the last GroupNorm applied
+        if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, emb, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
+            return fail("combine launch failed");
+        if (fc::launch_rvq_encode(emb, B * Tf, D, e->arch.codebook_size, n_q, e->cb, e->enorm, codes, quantized, qbdt,
+                                  sub_quants, Tf, cx.st) != hipSuccess)
+            return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256})");
+    }
+    if (quant_bdt_out) *quant_bdt_out = qbdt;
+    return cx.err;
+}
+
+int do_decode(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf, const float* scale, int out_len, float* wav) {
+    Act last = run_decoder(e, cx, z_bdt, Tf);
+    cx.launches++;
+    if (!cx.dry && !cx.err) {
+        if (out_len > last.T) return fail("out_len exceeds Tf*hop");
+        // final GroupNorm apply (decoder.model.N.conv.norm has C = 1), x scale (codec_basic.py:406-407), trim (:711)
+        if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, scale, cx.B, 1, last.T, out_len, wav, out_len, 0, 1, cx.st) != hipSuccess)
+            return fail("combine launch failed");
+    }
+    return cx.err;
+}
+
+int check_ready(fc_engine* e) {
+    if (!e) return fail("null engine");
+    if (!e->finalized) return fail("engine not finalized");
+    return 0;
+}
+
+Ctx make_ctx(int B, void* ws, size_t ws_bytes, void* stream) {
+    Ctx cx;
+    cx.B = B; cx.st = (hipStream_t)stream; cx.base = (char*)ws; cx.cap = ws_bytes;
+    return cx;
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+int fc_abi_version(void) { return FC_ABI_VERSION; }
+const char* fc_last_error(void) { return g_err.c_str(); }
+
+int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
+    if (!arch || !out) return fail("null argument");
+    if (arch->abi_version != FC_ABI_VERSION) return fail("fc_arch.abi_version mismatch");
+    if (arch->n_ratios < 1 || arch->n_ratios > FC_MAX_RATIOS) return fail("n_ratios out of range");
+    if (arch->compress < 1 || arch->n_filters < 2 || (arch->n_filters % arch->compress) != 0) return fail("bad n_filters/compress");
+    if (arch->n_filters % 2) return fail("n_filters must be even");
+    const int D = arch->dimension;
+    if (!(D == 16 || D == 32 || D == 64 || D == 128 || D == 256)) return fail("dimension must be one of 16/32/64/128/256");
+    if (arch->codebook_size % 64) return fail("codebook_size must be a multiple of 64");
+    if (arch->lstm_layers > 0 && ((arch->n_filters << arch->n_ratios) % 16)) return fail("LSTM width must be a multiple of 16");
+    for (int i = 0; i < arch->n_ratios; ++i)
+        if (arch->ratios[i] < 1) return fail("ratios must be >= 1");
+    fc_engine* e = new fc_engine();
+    e->arch = *arch;
+    e->device = device;
+    build_plan(e);
+    *out = e;
+    return 0;
+}
+
+void fc_engine_destroy(fc_engine* e) {
+    if (!e) return;
+    for (void* p : e->dev_allocs) (void)hipFree(p);
+    delete e;
+}
+
+int fc_engine_num_weights(const fc_engine* e) { return e ? (int)e->expected.size() : 0; }
+
+int fc_engine_weight_info(const fc_engine* e, int i, const char** name, int64_t* dims) {
+    if (!e || i < 0 || i >= (int)e->expected.size()) return -1;
+    if (name) *name = e->expected[i].first.c_str();
+    const auto& d = e->expected[i].second;
+    if (dims) for (size_t j = 0; j < d.size(); ++j) dims[j] = d[j];
+    return (int)d.size();
+}
+
+int fc_engine_set_weight(fc_engine* e, const char* name, const float* host, const int64_t* dims, int ndim) {
+    if (!e || !name || !host || !dims) return fail("null argument");
+    if (e->finalized) return fail("engine already finalized");
+    for (auto& ex : e->expected) {
+        if (ex.first != name) continue;
+        if ((int)ex.second.size() != ndim) return fail(std::string("rank mismatch for ") + name);
+        size_t n = 1;
+        for (int j = 0; j < ndim; ++j) {
+            if (ex.second[j] != dims[j]) return fail(std::string("shape mismatch for ") + name);
+            n *= (size_t)dims[j];
+        }
+        HostTensor& t = e->host[name];
+        t.dims.assign(dims, dims + ndim);
+        t.data.assign(host, host + n);
+        t.set = true;
+        return 0;
+    }
+    g_err = std::string("tensor not part of the hot path: ") + name;
+    return 2;
+}
+
+int fc_engine_finalize(fc_engine* e) {
+    if (!e) return fail("null engine");
+    if (e->finalized) return 0;
+    for (auto& ex : e->expected)
+        if (!e->host.count(ex.first) || !e->host[ex.first].set) return fail("checkpoint is missing tensor " + ex.first);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("no HIP device visible: the FunCodec MI355X engine has no CPU fallback");
+    HIP_TRY(hipSetDevice(e->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    std::vector<ConvLayer*> convs = {&e->enc_first, &e->enc_last, &e->dec_first, &e->dec_last};
+    for (auto& S : e->enc_stages) { convs.push_back(&S.shortcut); convs.push_back(&S.block1); convs.push_back(&S.block3); convs.push_back(&S.resample); }
+    for (auto& S : e->dec_stages) { convs.push_back(&S.shortcut); convs.push_back(&S.block1); convs.push_back(&S.block3); convs.push_back(&S.resample); }
+    for (ConvLayer* L : convs)
+        if (pack_conv(e, *L)) return 1;
+    if (pack_lstm(e, e->enc_lstm)) return 1;
+    if (pack_lstm(e, e->dec_lstm)) return 1;
+    // codebooks + |e|^2 (EuclideanCodebook.quantize ddp_core_vq.py:185: embed.pow(2).sum(0)); sequential d, squares rounded
+    const auto& E = e->host["quantizer.rq.model.embed"].data;
+    const int nq = e->arch.num_quantizers, K = e->arch.codebook_size, D = e->arch.dimension;
+    std::vector<float> en((size_t)nq * K);
+    for (size_t r = 0; r < (size_t)nq * K; ++r) {
+        volatile float s = 0.f;
+        for (int d = 0; d < D; ++d) {
+            volatile float sq = E[r * D + d] * E[r * D + d];
+            s = s + sq;
+        }
+        en[r] = s;
+    }
+    if (upload(e, E, &e->cb)) return 1;
+    if (upload(e, en, &e->enorm)) return 1;
+    // opt in to the dynamic LDS the conv kernels ask for is not needed (<= 64 KiB); host copies are dropped
+    e->host.clear();
+    HIP_TRY(hipDeviceSynchronize());
+    e->finalized = true;
+    return 0;
+}
+
+int fc_engine_hop_length(const fc_engine* e) { return e ? total_hop(e) : 0; }
+int fc_engine_frames(const fc_engine* e, int n_samples) { return e ? frames_for(e, n_samples) : 0; }
+
+size_t fc_engine_workspace_bytes(const fc_engine* ce, int B, int T) {
+    fc_engine* e = const_cast<fc_engine*>(ce);
+    if (!e || B <= 0 || T <= 0) return 0;
+    // tiling is only known after finalize(); plan with the same rule here
+    const int Tf = frames_for(e, T), D = e->arch.dimension;
+    Ctx cx; cx.B = B; cx.dry = true;
+    float* q = nullptr;
+    do_encode(e, cx, nullptr, T, e->arch.num_quantizers, nullptr, nullptr, nullptr, nullptr, nullptr, &q);
+    cx.alloc<float>((size_t)B * Tf * D);           // quantized when the caller does not want it
+    cx.alloc<float>((size_t)B * Tf * D);           // emb for decode_codes
+    cx.alloc<float>((size_t)B * Tf * D);           // transposed copy for decode_emb
+    do_decode(e, cx, nullptr, Tf, nullptr, Tf * total_hop(e), nullptr);
+    return cx.off + 4096;
+}
+
+int fc_engine_work(const fc_engine* ce, int B, int T, int n_q, fc_work* out) {
+    fc_engine* e = const_cast<fc_engine*>(ce);
+    if (!e || !out) return fail("null argument");
+    Ctx cx; cx.B = B; cx.dry = true;
+    float* q = nullptr;
+    do_encode(e, cx, nullptr, T, n_q, nullptr, nullptr, nullptr, nullptr, nullptr, &q);
+    do_decode(e, cx, nullptr, frames_for(e, T), nullptr, T, nullptr);
+    out->conv_flops = cx.conv_flops; out->conv_bytes = cx.conv_bytes;
+    out->lstm_flops = cx.lstm_flops; out->rvq_flops = cx.rvq_flops;
+    out->total_flops = cx.conv_flops + cx.lstm_flops + cx.rvq_flops;
+    out->total_bytes = cx.conv_bytes;
+    out->conv_launches = cx.conv_launches; out->total_launches = cx.launches;
+    return 0;
+}
+
+int fc_encode(fc_engine* e, const float* wav, int B, int T, int n_q, int64_t* codes, float* quantized, float* sub_quants,
+              float* scale, float* enc_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    if (!wav || !codes || B <= 0 || T <= 0) return fail("bad argument");
+    if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
+    Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
+    return do_encode(e, cx, wav, T, n_q, codes, quantized, sub_quants, scale, enc_out, nullptr);
+}
+
+int fc_decode_emb(fc_engine* e, const float* emb, const float* scale, int B, int Tf, int out_len, float* wav,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    if (!emb || !wav || B <= 0 || Tf <= 0 || out_len <= 0) return fail("bad argument");
+    Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
+    const int D = e->arch.dimension;
+    float* z = cx.alloc<float>((size_t)B * D * Tf);
+    if (cx.err) return 1;
+    HIP_TRY(fc::launch_transpose_btd(emb, B, Tf, D, z, cx.st));
+    return do_decode(e, cx, z, Tf, scale, out_len, wav);
+}
+
+int fc_decode_codes(fc_engine* e, const int64_t* codes, int B, int Tf, int n_q, int out_len, float* wav, float* emb_out,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    if (!codes || !wav || B <= 0 || Tf <= 0 || out_len <= 0) return fail("bad argument");
+    if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
+    Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
+    const int D = e->arch.dimension;
+    float* z = cx.alloc<float>((size_t)B * D * Tf);
+    if (cx.err) return 1;
+    HIP_TRY(fc::launch_rvq_decode(codes, B, Tf, n_q, D, e->arch.codebook_size, e->cb, emb_out, z, cx.st));
+    return do_decode(e, cx, z, Tf, nullptr, out_len, wav);
+}
+
+int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int use_scale, int64_t* codes, float* quantized,
+                     float* sub_quants, float* scale, float* recon, void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    if (!wav || !codes || !recon || B <= 0 || T <= 0) return fail("bad argument");
+    if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
+    Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
+    float* sc = scale;
+    if (e->arch.audio_normalize && !sc) sc = cx.alloc<float>(B);
+    float* qbdt = nullptr;
+    if (do_encode(e, cx, wav, T, n_q, codes, quantized, sub_quants, sc, nullptr, &qbdt)) return 1;
+    const int Tf = frames_for(e, T);
+    return do_decode(e, cx, qbdt, Tf, (use_scale && e->arch.audio_normalize) ? sc : nullptr, T, recon);
+}
+
+int fc_rvq_encode(fc_engine* e, const float* x, int N, int n_q, int64_t* codes, float* quantized, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    (void)workspace; (void)workspace_bytes;
+    if (!x || !codes || N <= 0) return fail("bad argument");
+    if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
+    HIP_TRY(fc::launch_rvq_encode(x, N, e->arch.dimension, e->arch.codebook_size, n_q, e->cb, e->enorm, codes, quantized,
+                                  nullptr, nullptr, N, (hipStream_t)stream));
+    return 0;
+}
+
+int fc_layer_out_len(const fc_engine* e, const char* prefix, int T) {
+    if (!e || !prefix) return -1;
+    auto it = e->by_prefix.find(prefix);
+    if (it == e->by_prefix.end()) return -1;
+    return conv_geom(*it->second, T).Tout;
+}
+
+int fc_layer_forward(fc_engine* e, const char* prefix, const float* x, int B, int T, int apply_elu, float* y,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    if (!prefix || !x || !y || B <= 0 || T <= 0) return fail("bad argument");
+    auto it = e->by_prefix.find(prefix);
+    if (it == e->by_prefix.end()) return fail(std::string("unknown layer ") + prefix);
+    Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
+    fc::Src s; s.ptr = x; s.used = 1;
+    Act o = run_conv(e, cx, *it->second, s, fc::Src(), apply_elu, T);
+    if (cx.err) return 1;
+    HIP_TRY(fc::launch_combine(src_of(o), fc::Src(), 0, 1.f, nullptr, B, o.C, o.T, o.T, y, (long long)o.C * o.T, o.T, 1, cx.st));
+    return 0;
+}
+
+int fc_lstm_forward(fc_engine* e, const char* prefix, const float* x, int B, int T, float* y, void* workspace,
+                    size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    if (!prefix || !x || !y || B <= 0 || T <= 0) return fail("bad argument");
+    auto it = e->lstm_by_prefix.find(prefix);
+    if (it == e->lstm_by_prefix.end()) return fail(std::string("unknown lstm ") + prefix);
+    Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
+    Act in; in.raw = const_cast<float*>(x); in.C = it->second->H; in.T = T;
+    Act o = run_lstm(e, cx, *it->second, in, T);
+    if (cx.err) return 1;
+    fc::Src s1;
+    if (e->arch.lstm_skip) s1 = src_of(in);
+    HIP_TRY(fc::launch_combine(src_of(o), s1, 0, 1.f, nullptr, B, o.C, T, T, y, (long long)o.C * T, T, 1, cx.st));
+    return 0;
+}
+
+}  // extern "C"

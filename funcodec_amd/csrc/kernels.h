@@ -1,0 +1,68 @@
+// Launch interface between the engine (engine.hip) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fc {
+
+// One input of a fused prologue:  v = src[b][c][t];  optional /div[b];  optional per-(b,c) affine
+// (GroupNorm apply: v*aff[b][c][0] + aff[b][c][1]).
+struct Src {
+    const float* ptr = nullptr;   // [B][C][T]
+    const float* aff = nullptr;   // [B][C][2] or null
+    const float* div = nullptr;   // [B] or null
+    int used = 0;                 // host-side bookkeeping only (dry-run planning has null pointers)
+};
+
+struct ConvLaunch {
+    Src s0, s1;                   // s1.ptr == null -> single source; else v = f0(s0) + f1(s1)
+    int elu = 0; float alpha = 1.f;
+    const float* wt = nullptr;    // packed weights [mtile][chunk][kk][cl][BM]
+    const float* bias = nullptr;  // [Mpad]
+    float* out = nullptr;
+    long long out_sB = 0, out_sM = 0, out_sT = 1;
+    int B = 0, Cin = 0, Tin = 0;
+    int M = 0;                    // real GEMM rows (Cout, or Cout*r for transposed conv)
+    int Tout = 0;                 // GEMM columns per utterance
+    int k = 1, stride = 1, padL = 0, padR = 0;   // padR includes the reference's "extra" padding
+    int pad_zero = 0;             // 0 reflect (pad1d), 1 zeros
+    int up_r = 0, trimL = 0, Tfinal = 0;          // transposed-conv scatter epilogue when up_r > 0
+    double* partials = nullptr;   // [B][nblk][2] (sum, sumsq) or null
+    int BM = 128, BN = 128, CC = 2, nchunk = 1;   // tiling chosen at pack time
+};
+
+int conv_nblk(const ConvLaunch& c);                         // stat partials per utterance
+size_t conv_lds_bytes(const ConvLaunch& c);
+hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
+
+// Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)
+hipError_t launch_gn_finalize(const double* partials, int nblk, double count, const float* gamma,
+                              const float* beta, int C, float eps, int B, float* aff, hipStream_t st);
+
+// out[b][c][t] (strides) = [elu]( f0(s0) + f1(s1) ) * mul[b]     for t < Tcopy
+hipError_t launch_combine(const Src& s0, const Src& s1, int elu, float alpha, const float* mul,
+                          int B, int C, int Tsrc, int Tcopy, float* out,
+                          long long o_sB, long long o_sC, long long o_sT, hipStream_t st);
+
+// scale[b] = 1e-8 + sqrt(mean_t x[b][t]^2)
+hipError_t launch_volume(const float* wav, int B, int T, float* scale, hipStream_t st);
+
+// [B][T][D] -> [B][D][T]
+hipError_t launch_transpose_btd(const float* in, int B, int T, int D, float* out, hipStream_t st);
+
+// Residual vector quantiser, all stages fused.  x [N][D] rows; cb [nq][K][D]; enorm [nq][K].
+hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* enorm,
+                             int64_t* codes /*[nq][N]*/, float* quant /*[N][D] or null*/,
+                             float* quant_bdt /*[B][D][Tf] or null*/, float* subq /*[nq][B][D][Tf] or null*/,
+                             int Tf, hipStream_t st);
+// codes [B][Tf][nq] (i64) -> emb [B][Tf][D] and/or emb_bdt [B][D][Tf]
+hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D, int K, const float* cb,
+                             float* emb, float* emb_bdt, hipStream_t st);
+
+// One LSTM time step for all batch rows.  wperm [4H][H] rows permuted to (blk, unit, gate);
+// xproj [T][B][4H] (permuted the same way, biases folded); h_prev/h_next [B][H]; c [B][H] in place;
+// y[b][u][t] (layout [B][H][T]) receives h_t.
+hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float* h_prev, float* h_next,
+                            float* c, float* y, int B, int H, int T, int t, hipStream_t st);
+
+}  // namespace fc

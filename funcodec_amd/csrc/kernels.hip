@@ -1,0 +1,615 @@
+// gfx950 (MI355X / CDNA4) kernels of the FunCodec encode/decode hot path.
+//
+// Everything here is fp32.  Dense contractions (conv-as-implicit-GEMM, LSTM recurrence, RVQ distance
+// matrix) run on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32): on gfx950
+// those are bit-for-bit an fmaf chain in k order at the fp32 vector peak rate, i.e. no precision is
+// traded.  Wavefront = 64 lanes throughout.
+#include "kernels.h"
+
+namespace fc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline __host__ __device__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// =================================================================================================
+// 1. Implicit-GEMM Conv1d / ConvTranspose1d with fused prologue and GroupNorm-statistics epilogue
+//
+//    out[b][m][n] = bias[m] + sum_{ci,kk} W[m][ci][kk] * f(in[b][ci][n*stride + kk - padL])
+//
+//    f = the pending elementwise work of the PRODUCING layers, applied while the input slab is staged
+//        into LDS: GroupNorm apply (per-(b,c) scale/shift), residual add of a second tensor, ELU,
+//        reflect / zero padding (reference: pad1d conv.py:82-99, SConv1d.forward conv.py:243-261,
+//        GroupNorm conv.py:45-52, ELU activations.py:24-30, SEANetResnetBlock.forward
+//        seanet_encoder.py:60-61).
+//    epilogue: + bias, store the RAW conv output once, and emit deterministic per-workgroup partial
+//        (sum, sum of squares) in fp64 for this layer's own GroupNorm(1,C) statistics.
+//    ConvTranspose1d(k=2r, stride=r) is the same GEMM with M = Cout*r rows (m = co*r + phase), two taps
+//        (x[i-1], x[i]) and a scatter store out[co][i*r + phase - trimL]; its statistics cover the
+//        UNTRIMMED output as in SConvTranspose1d.forward (conv.py:287-303).
+//
+//    LDS:  Ws[Kc][BM]      weight chunk, k-major so the A fragment (lane -> row) is conflict free
+//          Xs[CC][S][PL]   input slab, split by stride phase so the B fragment (lane -> column) is
+//                          conflict free for every stride (tau = n*S + kk -> [kk % S][n + kk / S])
+// =================================================================================================
+struct ConvArgs {
+    const float *src0, *aff0, *div0, *src1, *aff1;
+    const float *wt, *bias;
+    float* out;
+    double* partials;
+    long long out_sB, out_sM, out_sT;
+    int B, Cin, Tin, M, Tout, k, stride, padL, padR, pad_zero, Leff;
+    int up_r, trimL, Tfinal;
+    unsigned magic_r;       // ceil(2^32 / up_r)
+    int elu; float alpha;
+    int CC, nchunk, Kc;
+    int slabW, PL, rowStride;
+    unsigned magic_slabW;   // floor(2^32 / slabW) + 1
+};
+
+__device__ __forceinline__ float elu_f(float v, float alpha) { return v > 0.f ? v : alpha * (expf(v) - 1.f); }
+
+template <int S>
+__device__ __forceinline__ void stage_slab(const ConvArgs& p, float* __restrict__ Xs, int b, int c0, int tbase, int tid) {
+    const int total = p.CC * p.slabW;
+    for (int e = tid; e < total; e += 256) {
+        const int cl = (int)__umulhi((unsigned)e, p.magic_slabW);
+        const int tau = e - cl * p.slabW;
+        const int ci = c0 + cl;
+        const int g = tbase + tau;
+        float v = 0.f;
+        if (ci < p.Cin && g >= -p.padL && g < p.Tin + p.padR) {
+            int src = g;
+            bool zero;
+            if (p.pad_zero) {
+                zero = (g < 0) || (g >= p.Tin);
+            } else {
+                if (src < 0) src = -src;
+                if (src >= p.Leff) src = 2 * (p.Leff - 1) - src;
+                zero = src >= p.Tin;     // zero-extension of inputs shorter than the pad (conv.py:89-93)
+            }
+            if (!zero) {
+                const size_t row = (size_t)b * p.Cin + ci;
+                v = p.src0[row * p.Tin + src];
+                if (p.div0) v = v / p.div0[b];
+                if (p.aff0) { const float2 a = ((const float2*)p.aff0)[row]; v = fmaf(v, a.x, a.y); }
+                if (p.src1) {
+                    float w = p.src1[row * p.Tin + src];
+                    if (p.aff1) { const float2 a = ((const float2*)p.aff1)[row]; w = fmaf(w, a.x, a.y); }
+                    v = v + w;
+                }
+                if (p.elu) v = elu_f(v, p.alpha);
+            }
+        }
+        int ph, q;
+        if (S == 1) { ph = 0; q = tau; }
+        else if (S > 1) { q = tau / S; ph = tau - q * S; }
+        else { q = tau / p.stride; ph = tau - q * p.stride; }
+        Xs[cl * p.rowStride + ph * p.PL + q] = v;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem;
+    float* Xs = smem + p.Kc * BM;
+    __shared__ double red[2][4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int b = blockIdx.z, mt = blockIdx.y, nt = blockIdx.x;
+    const int n0 = nt * BN, m0 = mt * BM;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int tbase = n0 * p.stride - p.padL;
+    const int a_off = wm * (TM * 32) + l31;
+    const int b_off = wn * (TN * 32) + l31 + hi * p.rowStride;
+    const int half_cc = p.CC >> 1;
+
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        {   // weight chunk: contiguous Kc*BM floats
+            const float4* wsrc = (const float4*)(p.wt + ((size_t)(mt * p.nchunk + chunk) * p.Kc) * BM);
+            const int n4 = (p.Kc * BM) >> 2;
+            for (int i = tid; i < n4; i += 256) ((float4*)Ws)[i] = wsrc[i];
+        }
+        const int c0 = chunk * p.CC;
+        switch (p.stride) {
+            case 1: stage_slab<1>(p, Xs, b, c0, tbase, tid); break;
+            case 2: stage_slab<2>(p, Xs, b, c0, tbase, tid); break;
+            case 4: stage_slab<4>(p, Xs, b, c0, tbase, tid); break;
+            case 5: stage_slab<5>(p, Xs, b, c0, tbase, tid); break;
+            case 8: stage_slab<8>(p, Xs, b, c0, tbase, tid); break;
+            default: stage_slab<0>(p, Xs, b, c0, tbase, tid); break;
+        }
+        __syncthreads();
+        int ph = 0, q = 0;
+        for (int kk = 0; kk < p.k; ++kk) {
+            const int tapoff = ph * p.PL + q;
+            const float* wrow = Ws + (kk * p.CC + hi) * BM + a_off;
+            const float* xrow = Xs + tapoff + b_off;
+            for (int c2 = 0; c2 < half_cc; ++c2) {
+                float a[TM], bb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wrow[c2 * 2 * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bb[j] = xrow[c2 * 2 * p.rowStride + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+            }
+            if (++ph == p.stride) { ph = 0; ++q; }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, store, GroupNorm partial statistics --------------------------------------
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m >= p.M) continue;
+            const float bias = p.bias[m];
+            int co = m, phs = 0;
+            if (p.up_r) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (n >= p.Tout) continue;
+                const float v = acc[i][j][r] + bias;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+                if (p.up_r) {
+                    const int t = n * p.up_r + phs - p.trimL;
+                    if (t >= 0 && t < p.Tfinal) p.out[(size_t)b * p.out_sB + (size_t)co * p.out_sM + t] = v;
+                } else {
+                    p.out[(size_t)b * p.out_sB + (size_t)m * p.out_sM + (size_t)n * p.out_sT] = v;
+                }
+            }
+        }
+    }
+    if (p.partials) {
+        double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            d1 += __shfl_xor(d1, o, 64);
+            d2 += __shfl_xor(d2, o, 64);
+        }
+        if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+            const int nblk = gridDim.x * gridDim.y;
+            const size_t slot = ((size_t)b * nblk + (size_t)mt * gridDim.x + nt) * 2;
+            p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+    }
+}
+
+static ConvArgs make_args(const ConvLaunch& c) {
+    ConvArgs a;
+    a.src0 = c.s0.ptr; a.aff0 = c.s0.aff; a.div0 = c.s0.div;
+    a.src1 = c.s1.ptr; a.aff1 = c.s1.aff;
+    a.wt = c.wt; a.bias = c.bias; a.out = c.out; a.partials = c.partials;
+    a.out_sB = c.out_sB; a.out_sM = c.out_sM; a.out_sT = c.out_sT;
+    a.B = c.B; a.Cin = c.Cin; a.Tin = c.Tin; a.M = c.M; a.Tout = c.Tout;
+    a.k = c.k; a.stride = c.stride; a.padL = c.padL; a.padR = c.padR; a.pad_zero = c.pad_zero;
+    const int maxpad = c.padL > c.padR ? c.padL : c.padR;
+    a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
+    a.up_r = c.up_r; a.trimL = c.trimL; a.Tfinal = c.Tfinal;
+    a.magic_r = c.up_r ? (unsigned)((0x100000000ull + c.up_r - 1) / (unsigned long long)c.up_r) : 0u;
+    a.elu = c.elu; a.alpha = c.alpha;
+    a.CC = c.CC; a.nchunk = c.nchunk; a.Kc = c.k * c.CC;
+    a.slabW = (c.BN - 1) * c.stride + c.k;
+    a.PL = ceil_div(a.slabW, c.stride);
+    a.rowStride = a.PL * c.stride;
+    a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
+    return a;
+}
+
+int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM); }
+
+size_t conv_lds_bytes(const ConvLaunch& c) {
+    const ConvArgs a = make_args(c);
+    return (size_t)(a.Kc * c.BM + c.CC * a.rowStride) * sizeof(float);
+}
+
+hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
+    const ConvArgs a = make_args(c);
+    const size_t lds = conv_lds_bytes(c);
+    dim3 grid(ceil_div(c.Tout, c.BN), ceil_div(c.M, c.BM), c.B), block(256);
+    if (c.BM == 128 && c.BN == 128)
+        hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2>), grid, block, lds, st, a);
+    else if (c.BM == 64 && c.BN == 256)
+        hipLaunchKernelGGL((conv_mfma_kernel<64, 256, 1, 4>), grid, block, lds, st, a);
+    else if (c.BM == 32 && c.BN == 256)
+        hipLaunchKernelGGL((conv_mfma_kernel<32, 256, 1, 4>), grid, block, lds, st, a);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// 2. GroupNorm(1, C) statistics finalisation (nn.GroupNorm(num_groups=1), conv.py:45-52)
+//    Fixed-order fp64 reduction of the per-workgroup partials -> mean / rstd -> per-(b,c) affine table
+//    consumed by the next layer's prologue:  y = x*a + s,  a = rstd*gamma_c,  s = beta_c - mean*a.
+// =================================================================================================
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partials, int nblk, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int C, float eps, float* __restrict__ aff) {
+    __shared__ double sh[2][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < nblk; i += 256) {
+        s1 += partials[((size_t)b * nblk + i) * 2];
+        s2 += partials[((size_t)b * nblk + i) * 2 + 1];
+    }
+    sh[0][tid] = s1; sh[1][tid] = s2;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) { sh[0][tid] += sh[0][tid + o]; sh[1][tid] += sh[1][tid + o]; }
+        __syncthreads();
+    }
+    const double mean = sh[0][0] / count;
+    double var = sh[1][0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    for (int c = tid; c < C; c += 256) {
+        const float a = rstd * gamma[c];
+        const float s = fmaf(-a, meanf, beta[c]);
+        ((float2*)aff)[(size_t)b * C + c] = make_float2(a, s);
+    }
+}
+
+hipError_t launch_gn_finalize(const double* partials, int nblk, double count, const float* gamma, const float* beta,
+                              int C, float eps, int B, float* aff, hipStream_t st) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partials, nblk, count, gamma, beta, C, eps, aff);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// 3. Elementwise materialisation (only where a tensor leaves the engine or changes layout)
+// =================================================================================================
+__global__ __launch_bounds__(256) void combine_kernel(Src s0, Src s1, int elu, float alpha, const float* __restrict__ mul,
+                                                      int C, int Tsrc, int Tcopy, float* __restrict__ out,
+                                                      long long o_sB, long long o_sC, long long o_sT) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const size_t row = (size_t)b * C + c;
+    float2 a0 = make_float2(1.f, 0.f), a1 = make_float2(1.f, 0.f);
+    if (s0.aff) a0 = ((const float2*)s0.aff)[row];
+    if (s1.ptr && s1.aff) a1 = ((const float2*)s1.aff)[row];
+    const float m = mul ? mul[b] : 1.f;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < Tcopy; t += gridDim.x * 256) {
+        float v = s0.ptr[row * Tsrc + t];
+        if (s0.div) v = v / s0.div[b];
+        if (s0.aff) v = fmaf(v, a0.x, a0.y);
+        if (s1.ptr) {
+            float w = s1.ptr[row * Tsrc + t];
+            if (s1.aff) w = fmaf(w, a1.x, a1.y);
+            v = v + w;
+        }
+        if (elu) v = elu_f(v, alpha);
+        if (mul) v = v * m;
+        out[(size_t)b * o_sB + (size_t)c * o_sC + (size_t)t * o_sT] = v;
+    }
+}
+
+hipError_t launch_combine(const Src& s0, const Src& s1, int elu, float alpha, const float* mul, int B, int C, int Tsrc,
+                          int Tcopy, float* out, long long o_sB, long long o_sC, long long o_sT, hipStream_t st) {
+    if (Tcopy <= 0 || B <= 0) return hipSuccess;
+    int gx = ceil_div(Tcopy, 256 * 4);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(combine_kernel, dim3(gx, C, B), dim3(256), 0, st, s0, s1, elu, alpha, mul, C, Tsrc, Tcopy, out,
+                       o_sB, o_sC, o_sT);
+    return hipGetLastError();
+}
+
+// volume = sqrt(mean(x^2)); scale = 1e-8 + volume        (Encodec._encode_frame codec_basic.py:366-371)
+__global__ __launch_bounds__(1024) void volume_kernel(const float* __restrict__ wav, int T, float* __restrict__ scale) {
+    __shared__ double sh[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* x = wav + (size_t)b * T;
+    double s = 0.0;
+    for (int t = tid; t < T; t += 1024) { const float v = x[t]; s += (double)(v * v); }
+    sh[tid] = s;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) scale[b] = 1e-8f + sqrtf((float)(sh[0] / (double)T));
+}
+
+hipError_t launch_volume(const float* wav, int B, int T, float* scale, hipStream_t st) {
+    hipLaunchKernelGGL(volume_kernel, dim3(B), dim3(1024), 0, st, wav, T, scale);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void transpose_btd_kernel(const float* __restrict__ in, int T, int D, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int t = t0 + i, d = d0 + tx;
+        tile[i][tx] = (t < T && d < D) ? in[((size_t)b * T + t) * D + d] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int d = d0 + i, t = t0 + tx;
+        if (t < T && d < D) out[((size_t)b * D + d) * T + t] = tile[tx][i];
+    }
+}
+
+hipError_t launch_transpose_btd(const float* in, int B, int T, int D, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_btd_kernel, dim3(ceil_div(T, 32), ceil_div(D, 32), B), dim3(256), 0, st, in, T, D, out);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// 4. Residual vector quantiser: all n_q stages fused, 16 rows per workgroup
+//    (DistributedResidualVectorQuantization.forward ddp_core_vq.py:367-418, eval branch;
+//     EuclideanCodebook.quantize :180-188; dequantize :190-192)
+//
+//    stage i:  dist[row][k] = -(( |x|^2 - (2x).e_k ) + |e_k|^2)     idx = argmax_k, FIRST max wins
+//              q = E_i[idx];  residual -= q;  out += q
+//
+//    Arithmetic order (restated bit-for-bit by oracle/c/rvq_oracle.c):
+//      |x|^2   : 4 partial chains over d in [j*D/4,(j+1)*D/4), s = s + x*x with the square rounded
+//                separately (torch: x.pow(2).sum(1)), combined (p0+p1)+(p2+p3);
+//      (2x).e  : one MFMA accumulator per (row, code): fmaf chain from 0 over d in the order
+//                d = 16q + 4g + j  for q = 0..D/16-1, j = 0..3, g = 0..3 (innermost);
+//      |e|^2   : precomputed at load time (engine.hip), sequential d = 0..D-1, squares rounded separately.
+// =================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ x, int N, int K, int nq,
+                                                         const float* __restrict__ cb, const float* __restrict__ enorm,
+                                                         int64_t* __restrict__ codes, float* __restrict__ quant,
+                                                         float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf) {
+    constexpr int NQ4 = D / 16;
+    __shared__ __attribute__((aligned(16))) float R[16][D];
+    __shared__ __attribute__((aligned(16))) float Q[16][D];
+    __shared__ float xn[16];
+    __shared__ float bestv[4][16];
+    __shared__ int besti[4][16];
+    __shared__ int sel[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int row0 = blockIdx.x * 16;
+
+    for (int e = tid; e < 16 * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        const int n = row0 + r;
+        R[r][d] = n < N ? x[(size_t)n * D + d] : 0.f;
+        Q[r][d] = 0.f;
+    }
+    const int codes_per_wave = K >> 2;
+
+    for (int i = 0; i < nq; ++i) {
+        __syncthreads();
+        if (tid < 64) {   // |x|^2
+            const int r = tid >> 2, j = tid & 3;
+            float s = 0.f;
+            for (int d = j * (D / 4); d < (j + 1) * (D / 4); ++d) {
+                const float v = R[r][d];
+                s = __fadd_rn(s, __fmul_rn(v, v));
+            }
+            const float s_pair = __fadd_rn(s, __shfl_xor(s, 1, 64));          // p0+p1 | p2+p3
+            const float s_all = __fadd_rn(s_pair, __shfl_xor(s_pair, 2, 64));  // (p0+p1)+(p2+p3)
+            if (j == 0) xn[r] = s_all;
+        }
+        f32x4 a4[NQ4];
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) {
+            const f32x4 v = *(const f32x4*)&R[r16][16 * q + 4 * g];
+            a4[q] = v + v;   // 2*x, exact
+        }
+        __syncthreads();
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+        float xr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xr[r] = xn[4 * g + r];
+        const float* cbi = cb + (size_t)i * K * D;
+        for (int nt = 0; nt < codes_per_wave; nt += 16) {
+            const int code = wid * codes_per_wave + nt + r16;
+            const float* erow = cbi + (size_t)code * D + 4 * g;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NQ4; ++q) {
+                const f32x4 b4 = *(const f32x4*)(erow + 16 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[j], acc, 0, 0, 0);
+            }
+            const float en = enorm[(size_t)i * K + code];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dist = -__fadd_rn(__fsub_rn(xr[r], acc[r]), en);
+                if (dist > best[r]) { best[r] = dist; bidx[r] = code; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const float ov = __shfl_xor(best[r], o, 64);
+                const int oi = __shfl_xor(bidx[r], o, 64);
+                if (ov > best[r] || (ov == best[r] && oi < bidx[r])) { best[r] = ov; bidx[r] = oi; }
+            }
+            if (r16 == 0) { bestv[wid][4 * g + r] = best[r]; besti[wid][4 * g + r] = bidx[r]; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float bv = bestv[0][tid];
+            int bi = besti[0][tid];
+            for (int w = 1; w < 4; ++w) {
+                const float ov = bestv[w][tid];
+                const int oi = besti[w][tid];
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (bi < 0 || bi >= K) bi = 0;   // all-NaN row: torch would return an index too; stay in range
+            sel[tid] = bi;
+            if (row0 + tid < N) codes[(size_t)i * N + row0 + tid] = (int64_t)bi;
+        }
+        __syncthreads();
+        for (int e = tid; e < 16 * D; e += 256) {
+            const int r = e / D, d = e - r * D;
+            const float qv = cbi[(size_t)sel[r] * D + d];
+            R[r][d] = R[r][d] - qv;
+            Q[r][d] = Q[r][d] + qv;
+            const int n = row0 + r;
+            if (subq && n < N) {
+                const int bb = n / Tf, t = n - bb * Tf;
+                const int Bn = N / Tf;
+                subq[(((size_t)i * Bn + bb) * D + d) * Tf + t] = qv;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        const int n = row0 + r;
+        if (n >= N) continue;
+        const float v = Q[r][d];
+        if (quant) quant[(size_t)n * D + d] = v;
+        if (quant_bdt) {
+            const int bb = n / Tf, t = n - bb * Tf;
+            quant_bdt[((size_t)bb * D + d) * Tf + t] = v;
+        }
+    }
+}
+
+hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* enorm,
+                             int64_t* codes, float* quant, float* quant_bdt, float* subq, int Tf, hipStream_t st) {
+    if (N <= 0) return hipSuccess;
+    if (K % 64 != 0) return hipErrorInvalidValue;
+    dim3 grid(ceil_div(N, 16)), block(256);
+#define FC_RVQ_CASE(DD)                                                                                            \
+    case DD:                                                                                                       \
+        hipLaunchKernelGGL(rvq_encode_kernel<DD>, grid, block, 0, st, x, N, K, nq, cb, enorm, codes, quant, quant_bdt, \
+                           subq, Tf);                                                                              \
+        break;
+    switch (D) {
+        FC_RVQ_CASE(16)
+        FC_RVQ_CASE(32)
+        FC_RVQ_CASE(64)
+        FC_RVQ_CASE(128)
+        FC_RVQ_CASE(256)
+        default: return hipErrorInvalidValue;
+    }
+#undef FC_RVQ_CASE
+    return hipGetLastError();
+}
+
+// DRVQ.decode (ddp_core_vq.py:442-453): out = ((0 + E_0[i0]) + E_1[i1]) + ...
+__global__ __launch_bounds__(256) void rvq_decode_kernel(const int64_t* __restrict__ codes, int Tf, int nq, int D, int K,
+                                                         const float* __restrict__ cb, float* __restrict__ emb,
+                                                         float* __restrict__ emb_bdt) {
+    const int n = blockIdx.x;   // row = b*Tf + t
+    const int b = n / Tf, t = n - b * Tf;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < nq; ++i) {
+            long long idx = codes[(size_t)n * nq + i];
+            if (idx < 0) idx = 0;
+            if (idx >= K) idx = K - 1;
+            s = s + cb[((size_t)i * K + idx) * D + d];
+        }
+        if (emb) emb[(size_t)n * D + d] = s;
+        if (emb_bdt) emb_bdt[((size_t)b * D + d) * Tf + t] = s;
+    }
+}
+
+hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D, int K, const float* cb, float* emb,
+                             float* emb_bdt, hipStream_t st) {
+    if (B * Tf <= 0) return hipSuccess;
+    const int threads = D >= 256 ? 256 : (D >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(rvq_decode_kernel, dim3(B * Tf), dim3(threads), 0, st, codes, Tf, nq, D, K, cb, emb, emb_bdt);
+    return hipGetLastError();
+}
+
+// =================================================================================================
+// 5. LSTM time step (nn.LSTM inside SLSTM, lstm.py:12-28).  One launch per t; workgroup j owns the
+//    16 gate rows {i,f,g,o} x 4 hidden units (rows permuted at load time), split-K over its waves,
+//    gates + state update fused.  gates = (W_hh h_{t-1}) + xproj_t,  xproj = W_ih x_t + b_ih + b_hh
+//    computed for all t at once by the conv kernel (k = 1).
+// =================================================================================================
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
+
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ wperm, const float* __restrict__ xproj,
+                                                        const float* __restrict__ h_prev, float* __restrict__ h_next,
+                                                        float* __restrict__ c, float* __restrict__ y, int B, int H, int T,
+                                                        int t) {
+    __shared__ f32x4 red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int blk = blockIdx.x;
+    const int KS = (H >> 4) < 4 ? (H >> 4) : 4;
+    const int kslice = H / KS;
+    const int nsteps = kslice >> 4;
+    const float* wrow = wperm + ((size_t)blk * 16 + r16) * H + wid * kslice + 4 * g;
+    const int nbt = (B + 15) >> 4;
+    for (int nb = 0; nb < nbt; ++nb) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (wid < KS) {
+            const int brow = nb * 16 + r16;
+            const bool bvalid = brow < B;
+            const float* hrow = h_prev + (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
+            for (int q = 0; q < nsteps; ++q) {
+                const f32x4 a4 = *(const f32x4*)(wrow + 16 * q);
+                f32x4 b4 = *(const f32x4*)(hrow + 16 * q);
+                if (!bvalid) b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b4[j], acc, 0, 0, 0);
+            }
+        }
+        red[wid][lane] = acc;
+        __syncthreads();
+        if (wid == 0) {
+            f32x4 s = red[0][lane];
+            for (int w = 1; w < KS; ++w) s = s + red[w][lane];
+            const int bb = nb * 16 + r16;
+            if (bb < B) {
+                const f32x4 xp = *(const f32x4*)(xproj + ((size_t)t * B + bb) * 4 * H + (size_t)blk * 16 + 4 * g);
+                const int unit = blk * 4 + g;
+                const float gi = sigmoid_f(s[0] + xp[0]);
+                const float gf = sigmoid_f(s[1] + xp[1]);
+                const float gg = tanhf(s[2] + xp[2]);
+                const float go = sigmoid_f(s[3] + xp[3]);
+                const size_t ci = (size_t)bb * H + unit;
+                const float cn = gf * c[ci] + gi * gg;
+                const float hn = go * tanhf(cn);
+                c[ci] = cn;
+                h_next[ci] = hn;
+                y[ci * T + t] = hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float* h_prev, float* h_next, float* c,
+                            float* y, int B, int H, int T, int t, hipStream_t st) {
+    if (H % 16 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 4), dim3(256), 0, st, wperm, xproj, h_prev, h_next, c, y, B, H, T, t);
+    return hipGetLastError();
+}
+
+}  // namespace fc

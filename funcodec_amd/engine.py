@@ -1,0 +1,243 @@
+"""Host side of the MI355X engine: owns the engine handle, checkpoint ingestion and the device
+workspace.  PyTorch is used only for device memory, streams and checkpoint I/O; every arithmetic
+operation of the hot path happens inside libfuncodec_amd.so (HIP, gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ArchSpec
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class CodecEngine:
+    """One engine per (device, checkpoint).  Calls on one engine are serialised by the caller,
+    like a torch module's forward."""
+
+    def __init__(self, arch: ArchSpec, device: "torch.device | str | int" = "cuda:0"):
+        self.lib = _lib.load()
+        self.arch = arch
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if dev.type != "cuda":
+            raise EngineError(
+                f"funcodec_amd runs on MI355X (gfx950) only; device={device!r} has no implementation "
+                "(there is deliberately no CPU fallback)")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else 0)
+        a = _lib.FcArch()
+        a.abi_version = _lib.FC_ABI_VERSION
+        a.sample_rate = arch.sample_rate
+        a.audio_normalize = int(arch.audio_normalize)
+        a.n_filters = arch.n_filters
+        a.dimension = arch.dimension
+        a.n_ratios = len(arch.ratios)
+        for i, r in enumerate(arch.ratios):
+            a.ratios[i] = int(r)
+        a.kernel_size = arch.kernel_size
+        a.last_kernel_size = arch.last_kernel_size
+        a.residual_kernel_size = arch.residual_kernel_size
+        a.compress = arch.compress
+        a.lstm_layers = arch.lstm_layers
+        a.lstm_skip = int(arch.lstm_skip)
+        a.elu_alpha = arch.elu_alpha
+        a.gn_eps = arch.gn_eps
+        a.codebook_size = arch.codebook_size
+        a.num_quantizers = arch.num_quantizers
+        h = C.c_void_p()
+        self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
+        self._h = h
+        self._ws: Optional[torch.Tensor] = None
+        self._finalized = False
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(self.lib.fc_last_error().decode("utf-8", "replace"))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.fc_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def expected_tensors(self) -> Dict[str, tuple]:
+        out = {}
+        name = C.c_char_p()
+        dims = (C.c_int64 * 4)()
+        for i in range(self.lib.fc_engine_num_weights(self._h)):
+            nd = self.lib.fc_engine_weight_info(self._h, i, C.byref(name), dims)
+            out[name.value.decode()] = tuple(int(dims[j]) for j in range(nd))
+        return out
+
+    # -- checkpoint ----------------------------------------------------------------------------
+    def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"]) -> None:
+        """Tolerant load, like the reference's filter_state_dict
+        (funcodec/torch_utils/load_pretrained_model.py:12-43): unknown keys (discriminator.*,
+        mel_spec_transforms.*, EMA buffers) are skipped; a MISSING hot-path tensor is an error
+        because, unlike the reference, we cannot run on random init silently."""
+        want = self.expected_tensors()
+        state = dict(state)
+        # `use_ddp: false` checkpoints store one codebook per layer (core_vq.py:147-150)
+        if "quantizer.rq.model.embed" not in state:
+            per = []
+            i = 0
+            while f"quantizer.rq.model.layers.{i}._codebook.embed" in state:
+                per.append(torch.as_tensor(state[f"quantizer.rq.model.layers.{i}._codebook.embed"]))
+                i += 1
+            if per:
+                state["quantizer.rq.model.embed"] = torch.stack(per)
+        inited = state.get("quantizer.rq.model.inited", None)
+        if inited is not None and not bool(torch.as_tensor(inited).bool().all()):
+            raise EngineError("checkpoint has un-initialised codebooks (quantizer.rq.model.inited == 0); the reference "
+                              "would run k-means on the first batch (ddp_core_vq.py:149-159), which is training behaviour")
+        for key, shape in want.items():
+            if key not in state:
+                raise EngineError(f"checkpoint is missing tensor {key} {shape}")
+            t = torch.as_tensor(state[key]).detach().to("cpu", torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise EngineError(f"shape mismatch for {key}: checkpoint {tuple(t.shape)} vs architecture {shape}")
+            dims = (C.c_int64 * 4)(*t.shape)
+            self._check(self.lib.fc_engine_set_weight(self._h, key.encode(), C.c_void_p(t.data_ptr()), dims, t.dim()))
+        skipped = [k for k in state if k not in want]
+        if skipped:
+            logging.info("funcodec_amd: skipped %d checkpoint tensors outside the hot path (e.g. %s)", len(skipped), skipped[0])
+        self._check(self.lib.fc_engine_finalize(self._h))
+        self._finalized = True
+
+    # -- sizes ---------------------------------------------------------------------------------
+    @property
+    def hop_length(self) -> int:
+        return self.lib.fc_engine_hop_length(self._h)
+
+    def frames(self, n_samples: int) -> int:
+        return self.lib.fc_engine_frames(self._h, n_samples)
+
+    def _workspace(self, B: int, T: int) -> torch.Tensor:
+        need = int(self.lib.fc_engine_workspace_bytes(self._h, B, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def work(self, B: int, T: int, n_q: int) -> Dict[str, float]:
+        w = _lib.FcWork()
+        self._check(self.lib.fc_engine_work(self._h, B, T, n_q, C.byref(w)))
+        return {f: getattr(w, f) for f, _ in _lib.FcWork._fields_}
+
+    def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    # -- hot path ------------------------------------------------------------------------------
+    def encode(self, wav: torch.Tensor, n_q: int, want_sub_quants: bool = True, want_enc_out: bool = False):
+        """wav [B,T] -> dict(codes [n_q,B,Tf] i64, quantized [B,Tf,D], sub_quants [n_q,B,D,Tf], scale [B,1]|None)."""
+        wav = self._dev(wav, torch.float32)
+        B, T = wav.shape
+        Tf, D = self.frames(T), self.arch.dimension
+        dev = self.device
+        codes = torch.empty((n_q, B, Tf), dtype=torch.int64, device=dev)
+        quant = torch.empty((B, Tf, D), dtype=torch.float32, device=dev)
+        subq = torch.empty((n_q, B, D, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
+        scale = torch.empty((B,), dtype=torch.float32, device=dev) if self.arch.audio_normalize else None
+        enc = torch.empty((B, Tf, D), dtype=torch.float32, device=dev) if want_enc_out else None
+        ws = self._workspace(B, T)
+        self._check(self.lib.fc_encode(self._h, _ptr(wav), B, T, n_q, _ptr(codes), _ptr(quant), _ptr(subq), _ptr(scale),
+                                       _ptr(enc), _ptr(ws), ws.numel(), self._stream()))
+        return dict(codes=codes, quantized=quant, sub_quants=subq,
+                    scale=None if scale is None else scale.view(B, 1), enc_out=enc)
+
+    def encode_decode(self, wav: torch.Tensor, n_q: int, use_scale: bool = True, want_sub_quants: bool = True):
+        wav = self._dev(wav, torch.float32)
+        B, T = wav.shape
+        Tf, D = self.frames(T), self.arch.dimension
+        dev = self.device
+        codes = torch.empty((n_q, B, Tf), dtype=torch.int64, device=dev)
+        quant = torch.empty((B, Tf, D), dtype=torch.float32, device=dev)
+        subq = torch.empty((n_q, B, D, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
+        scale = torch.empty((B,), dtype=torch.float32, device=dev) if self.arch.audio_normalize else None
+        recon = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
+        ws = self._workspace(B, T)
+        self._check(self.lib.fc_encode_decode(self._h, _ptr(wav), B, T, n_q, int(use_scale), _ptr(codes), _ptr(quant),
+                                              _ptr(subq), _ptr(scale), _ptr(recon), _ptr(ws), ws.numel(), self._stream()))
+        return dict(codes=codes, quantized=quant, sub_quants=subq,
+                    scale=None if scale is None else scale.view(B, 1), recon=recon)
+
+    def decode_codes(self, tokens: torch.Tensor):
+        """tokens [B,Tf,n_q] i64 -> (wav [B,1,Tf*hop], emb [B,Tf,D])."""
+        tokens = self._dev(tokens, torch.int64)
+        B, Tf, n_q = tokens.shape
+        L = Tf * self.hop_length
+        wav = torch.empty((B, 1, L), dtype=torch.float32, device=self.device)
+        emb = torch.empty((B, Tf, self.arch.dimension), dtype=torch.float32, device=self.device)
+        ws = self._workspace(B, L)
+        self._check(self.lib.fc_decode_codes(self._h, _ptr(tokens), B, Tf, n_q, L, _ptr(wav), _ptr(emb), _ptr(ws), ws.numel(),
+                                             self._stream()))
+        return wav, emb
+
+    def decode_emb(self, emb: torch.Tensor, scale: Optional[torch.Tensor] = None, out_len: Optional[int] = None):
+        """emb [B,Tf,D] -> wav [B,1,out_len or Tf*hop]."""
+        emb = self._dev(emb, torch.float32)
+        B, Tf, D = emb.shape
+        if D != self.arch.dimension:
+            raise EngineError(f"embedding dim {D} != {self.arch.dimension}")
+        L = Tf * self.hop_length
+        out_len = L if out_len is None else int(out_len)
+        sc = None if scale is None else self._dev(scale.reshape(-1), torch.float32)
+        wav = torch.empty((B, 1, out_len), dtype=torch.float32, device=self.device)
+        ws = self._workspace(B, L)
+        self._check(self.lib.fc_decode_emb(self._h, _ptr(emb), _ptr(sc), B, Tf, out_len, _ptr(wav), _ptr(ws), ws.numel(),
+                                           self._stream()))
+        return wav
+
+    # -- per-op entry points (tests) -----------------------------------------------------------
+    def rvq_encode(self, x: torch.Tensor, n_q: int):
+        x = self._dev(x, torch.float32)
+        N, D = x.shape
+        codes = torch.empty((n_q, N), dtype=torch.int64, device=self.device)
+        quant = torch.empty((N, D), dtype=torch.float32, device=self.device)
+        self._check(self.lib.fc_rvq_encode(self._h, _ptr(x), N, n_q, _ptr(codes), _ptr(quant), None, 0, self._stream()))
+        return codes, quant
+
+    def layer_forward(self, prefix: str, x: torch.Tensor, apply_elu: bool = False) -> torch.Tensor:
+        x = self._dev(x, torch.float32)
+        B, Cin, T = x.shape
+        Tout = self.lib.fc_layer_out_len(self._h, prefix.encode(), T)
+        if Tout < 0:
+            raise EngineError(f"unknown layer {prefix}")
+        cout = self.expected_tensors()[prefix + ".norm.weight"][0]
+        y = torch.empty((B, cout, Tout), dtype=torch.float32, device=self.device)
+        ws = self._workspace(B, max(T, Tout) * 4 + 4096)
+        need = (B * cout * (Tout + 64) * 4) * 2 + (1 << 20)
+        if ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws = self._ws
+        self._check(self.lib.fc_layer_forward(self._h, prefix.encode(), _ptr(x), B, T, int(apply_elu), _ptr(y), _ptr(ws),
+                                              ws.numel(), self._stream()))
+        return y
+
+    def lstm_forward(self, prefix: str, x: torch.Tensor) -> torch.Tensor:
+        x = self._dev(x, torch.float32)
+        B, H, T = x.shape
+        y = torch.empty_like(x)
+        need = (T * B * 4 * H + 3 * B * H + B * H * T) * 4 * self.arch.lstm_layers + (1 << 20)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws
+        self._check(self.lib.fc_lstm_forward(self._h, prefix.encode(), _ptr(x), B, T, _ptr(y), _ptr(ws), ws.numel(), self._stream()))
+        return y

@@ -1,0 +1,149 @@
+/*
+ * funcodec_amd.h -- C ABI of the MI355X (gfx950) FunCodec encode/decode engine.
+ *
+ * The reference (modelscope/FunCodec, /root/reference) is 100 % Python on top of torch.nn; it has no
+ * FFI layer.  Its operator boundary for this path is the set of Python callables listed next to each
+ * entry point below; a maintainer binds this library with ctypes from
+ * `funcodec/bin/codec_inference.py` (Speech2Token.__call__, :86-134).
+ *
+ * Conventions
+ *   - plain C types only; every pointer argument marked "dev" is a DEVICE pointer (HBM) owned by the
+ *     caller (e.g. `tensor.data_ptr()`), "host" pointers are ordinary host memory;
+ *   - all tensors are dense, row-major, fp32 unless stated; code indices are int64 like the reference;
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no host sync);
+ *   - return value: 0 = ok, non-zero = error, message via fc_last_error() (thread-local);
+ *   - one engine per (device, checkpoint); calls on one engine must be serialised by the caller;
+ *   - the engine never falls back to a CPU path: without a gfx950 device every compute call fails.
+ */
+#ifndef FUNCODEC_AMD_H
+#define FUNCODEC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC_MAX_RATIOS 8
+#define FC_ABI_VERSION 1
+
+typedef struct fc_engine fc_engine;
+
+/* Architecture, i.e. the subset of config.yaml the hot path depends on.
+ * Replaces: GANSpeechCodecTask.build_model (funcodec/tasks/gan_speech_codec.py:300-343) +
+ * SEANetEncoder.__init__ (funcodec/models/encoder/seanet_encoder.py:88-160) +
+ * SEANetDecoder.__init__ (funcodec/models/decoder/seanet_decoder.py:88-164) +
+ * CostumeQuantizer.__init__ (funcodec/models/quantizer/costume_quantizer.py:7-55). */
+typedef struct fc_arch {
+    int32_t abi_version;            /* FC_ABI_VERSION */
+    int32_t sample_rate;
+    int32_t audio_normalize;        /* model_conf.audio_normalize */
+    int32_t n_filters;              /* 32 */
+    int32_t dimension;              /* 128: encoder output / codebook dim */
+    int32_t n_ratios;
+    int32_t ratios[FC_MAX_RATIOS];  /* decoder order, e.g. {8,5,4,2,2}; encoder walks it reversed */
+    int32_t kernel_size;            /* 7 */
+    int32_t last_kernel_size;       /* 7 */
+    int32_t residual_kernel_size;   /* 3 */
+    int32_t compress;               /* 2 */
+    int32_t lstm_layers;            /* 2 (0 = no sequence model) */
+    int32_t lstm_skip;              /* res_seq */
+    float   elu_alpha;              /* 1.0 */
+    float   gn_eps;                 /* 1e-5 */
+    int32_t codebook_size;          /* 1024 */
+    int32_t num_quantizers;         /* 32 */
+} fc_arch;
+
+/* ---- lifetime ------------------------------------------------------------------------------------ */
+int  fc_abi_version(void);
+const char* fc_last_error(void);
+
+/* Replaces build_model(): builds the layer plan; allocates nothing on the device yet. */
+int  fc_engine_create(const fc_arch* arch, int device, fc_engine** out);
+void fc_engine_destroy(fc_engine* e);
+
+/* Checkpoint contract.  Replaces build_model_from_file / filter_state_dict
+ * (funcodec/tasks/abs_task.py:1895-1947, funcodec/torch_utils/load_pretrained_model.py:12-43):
+ * the host enumerates the state_dict keys the engine wants and hands each tensor over by name. */
+int  fc_engine_num_weights(const fc_engine* e);
+/* name/dims of expected tensor i (dims has room for 4 entries); returns ndim or <0. */
+int  fc_engine_weight_info(const fc_engine* e, int i, const char** name, int64_t* dims);
+/* host fp32 tensor in the reference's own layout (e.g. Conv1d [Cout,Cin,k], ConvTranspose1d [Cin,Cout,k],
+ * LSTM weight_ih_l0 [4H,H], quantizer.rq.model.embed [n_q,K,D]).  Unknown names -> error code 2
+ * (the host skips discriminator.* etc. itself).  Shape mismatch -> error. */
+int  fc_engine_set_weight(fc_engine* e, const char* name, const float* host, const int64_t* dims, int ndim);
+/* Folds / re-lays-out the weights into HBM.  Fails if a tensor is missing. */
+int  fc_engine_finalize(fc_engine* e);
+
+/* ---- sizes --------------------------------------------------------------------------------------- */
+int    fc_engine_hop_length(const fc_engine* e);
+/* frames emitted for n_samples: ceil at every encoder stride (SConv1d extra padding, conv.py:57-64). */
+int    fc_engine_frames(const fc_engine* e, int n_samples);
+/* bytes of caller-provided device scratch needed by any call with batch B and T samples (or Tf*hop). */
+size_t fc_engine_workspace_bytes(const fc_engine* e, int B, int T);
+
+/* ---- the hot path -------------------------------------------------------------------------------- */
+/* Encodec.inference_encoding (funcodec/models/codec_basic.py:720-764) = _encode_frame (:361-380) +
+ * SEANetEncoder.forward + CostumeQuantizer.inference -> DRVQ.forward (ddp_core_vq.py:367-418).
+ *   wav        dev f32 [B,T]
+ *   n_q        number of quantizers to run (1..num_quantizers)
+ *   codes      dev i64 [n_q,B,Tf]                         (code_indices[0])
+ *   quantized  dev f32 [B,Tf,D]   or NULL                 (code_embeddings[0][0])
+ *   sub_quants dev f32 [n_q,B,D,Tf] or NULL               (sub_quants[0])
+ *   scale      dev f32 [B]        or NULL (1e-8+rms; written only if audio_normalize)
+ *   enc_out    dev f32 [B,Tf,D]   or NULL (encoder output before quantisation) */
+int fc_encode(fc_engine* e, const float* wav, int B, int T, int n_q,
+              int64_t* codes, float* quantized, float* sub_quants, float* scale, float* enc_out,
+              void* workspace, size_t workspace_bytes, void* stream);
+
+/* Encodec.inference_decoding_emb (codec_basic.py:804-836) = _decode_frame (:398-408) + SEANetDecoder.forward.
+ *   emb   dev f32 [B,Tf,D];  scale dev f32 [B] or NULL (multiplied in when non-NULL, :406-407)
+ *   wav   dev f32 [B,out_len], out_len <= Tf*hop (the first out_len samples are written) */
+int fc_decode_emb(fc_engine* e, const float* emb, const float* scale, int B, int Tf, int out_len,
+                  float* wav, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Encodec.inference_decoding (codec_basic.py:766-802): DRVQ.decode (ddp_core_vq.py:442-453) + decoder.
+ *   codes dev i64 [B,Tf,n_q] (the reference's token layout);  emb_out dev f32 [B,Tf,D] or NULL */
+int fc_decode_codes(fc_engine* e, const int64_t* codes, int B, int Tf, int n_q, int out_len,
+                    float* wav, float* emb_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Encodec.inference (codec_basic.py:670-718): encode + decode in one enqueue; recon [B,T]. */
+int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int use_scale,
+                     int64_t* codes, float* quantized, float* sub_quants, float* scale, float* recon,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-op entry points (so tests can pin each kernel against torch.nn.functional) -------------- */
+/* DRVQ.forward on rows: x dev f32 [N,D], codebooks as loaded; codes dev i64 [n_q,N];
+ * quantized dev f32 [N,D] or NULL. */
+int fc_rvq_encode(fc_engine* e, const float* x, int N, int n_q, int64_t* codes, float* quantized,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* One SConv1d / SConvTranspose1d of the plan, addressed by its checkpoint prefix (e.g.
+ * "encoder.model.3.conv", "decoder.model.3.convtr"): y = GroupNorm(conv(pad(act(x)))) as the reference
+ * module computes it (conv.py:243-305), x dev f32 [B,Cin,T], y dev f32 [B,Cout,Tout] (trimmed for convtr).
+ * apply_elu: apply ELU to x first (the nn.ELU that precedes the module in the Sequential). */
+int fc_layer_forward(fc_engine* e, const char* prefix, const float* x, int B, int T, int apply_elu,
+                     float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* output length of that layer for input length T */
+int fc_layer_out_len(const fc_engine* e, const char* prefix, int T);
+
+/* SLSTM.forward (lstm.py:22-28) addressed by prefix ("encoder.model.16.lstm"): x,y dev f32 [B,C,T]. */
+int fc_lstm_forward(fc_engine* e, const char* prefix, const float* x, int B, int T,
+                    float* y, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- profiling aid ------------------------------------------------------------------------------- */
+/* Algorithmic work of one fc_encode_decode call: flops and bytes, total and for the
+ * implicit-GEMM conv kernel family only. */
+typedef struct fc_work {
+    double total_flops, total_bytes;
+    double conv_flops, conv_bytes;
+    double lstm_flops, rvq_flops;
+    int32_t conv_launches, total_launches;
+} fc_work;
+int fc_engine_work(const fc_engine* e, int B, int T, int n_q, fc_work* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUNCODEC_AMD_H */
