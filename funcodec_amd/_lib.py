@@ -28,6 +28,13 @@ class FcWork(C.Structure):
                 ("conv_launches", C.c_int32), ("total_launches", C.c_int32)]
 
 
+class FcProf(C.Structure):
+    _fields_ = [("kernel", C.c_char * 64), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double),
+                ("launches", C.c_int32), ("reserved", C.c_int32)]
+
+
+FC_PROF_CLASSES = 6
+
 # every symbol include/funcodec_amd.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -51,6 +58,8 @@ SYMBOLS = {
     "fc_layer_out_len": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "fc_lstm_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "fc_engine_work": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(FcWork)]),
+    "fc_engine_profile": (C.c_int, [_P, C.c_int]),
+    "fc_engine_profile_read": (C.c_int, [_P, C.POINTER(FcProf)]),
 }
 
 _lib = None
@@ -66,6 +75,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so); it must be in the process BEFORE this
+    # library is loaded so that both share ONE runtime -- two HIP runtimes in one process cannot both
+    # see the device ("no HIP device visible").
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(

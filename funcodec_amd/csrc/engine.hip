@@ -42,6 +42,8 @@ struct ConvLayer {
     bool transposed = false;
     int cin = 0, cout = 0, k = 1, stride = 1;
     bool has_norm = true;
+    bool dual = false;      // the plan feeds it two summed sources (residual sum / LSTM skip)
+    bool small_n = false;   // runs at the bottleneck frame rate: few columns per utterance
     // GEMM view
     int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
     int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
@@ -86,6 +88,11 @@ struct Ctx {
 
 int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
+enum ProfClass { PC_CONV128 = 0, PC_CONV64 = 1, PC_CONV32 = 2, PC_LSTM = 3, PC_RVQ = 4, PC_OTHER = 5 };
+const char* kProfNames[FC_PROF_CLASSES] = {"conv_mfma_kernel<128,128,2,2>", "conv_mfma_kernel<64,256,1,4>",
+                                           "conv_mfma_kernel<32,256,1,4>", "lstm_step_kernel (whole recurrence, incl. gaps)",
+                                           "rvq_encode_kernel", "other"};
+
 }  // namespace
 
 struct fc_engine {
@@ -104,9 +111,37 @@ struct fc_engine {
     // quantiser
     float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
     std::vector<void*> dev_allocs;
+    // optional event timing
+    bool profiling = false;
+    struct Span { hipEvent_t a, b; int cls; double flops, bytes; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
 };
 
 namespace {
+
+hipEvent_t prof_event(fc_engine* e) {
+    if (e->events_used == e->event_pool.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        e->event_pool.push_back(ev);
+    }
+    return e->event_pool[e->events_used++];
+}
+
+struct ProfSpan {   // RAII: records start now, stop at scope exit
+    fc_engine* e; hipStream_t st; int idx = -1;
+    ProfSpan(fc_engine* e_, Ctx& cx, int cls, double flops, double bytes) : e(e_), st(cx.st) {
+        if (!e->profiling || cx.dry || cx.err) return;
+        fc_engine::Span s; s.a = prof_event(e); s.b = prof_event(e); s.cls = cls; s.flops = flops; s.bytes = bytes;
+        if (!s.a || !s.b) return;
+        (void)hipEventRecord(s.a, st);
+        e->spans.push_back(s);
+        idx = (int)e->spans.size() - 1;
+    }
+    ~ProfSpan() { if (idx >= 0) (void)hipEventRecord(e->spans[idx].b, st); }
+};
 
 // ---- plan construction (mirrors nn.Sequential indices: seanet_encoder.py:109-160, seanet_decoder.py:111-164)
 void add_conv_expect(fc_engine* e, ConvLayer& L) {
@@ -123,9 +158,11 @@ void add_conv_expect(fc_engine* e, ConvLayer& L) {
 
 void choose_tiling(ConvLayer& L);
 
-ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed = false) {
+ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed = false,
+                  bool dual = false, bool small_n = false) {
     ConvLayer L;
     L.prefix = prefix; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.transposed = transposed;
+    L.dual = dual; L.small_n = small_n;
     if (!transposed) { L.M = cout; L.gk = k; L.gstride = stride; }
     else { L.M = cout * stride; L.gk = 2; L.gstride = 1; }   // 2-tap GEMM over the r output phases
     choose_tiling(L);
@@ -151,7 +188,7 @@ void build_plan(fc_engine* e) {
         S.block1 = mk_conv(name("encoder", idx, ".block.1.conv"), c, hid, a.residual_kernel_size, 1);
         S.block3 = mk_conv(name("encoder", idx, ".block.3.conv"), hid, c, 1, 1);
         idx += 2;
-        S.resample = mk_conv(name("encoder", idx, ".conv"), c, 2 * c, 2 * ratio, ratio);
+        S.resample = mk_conv(name("encoder", idx, ".conv"), c, 2 * c, 2 * ratio, ratio, false, true);
         idx++;
         mult *= 2;
     }
@@ -162,10 +199,11 @@ void build_plan(fc_engine* e) {
         idx++;
     }
     idx++;
-    e->enc_last = mk_conv(name("encoder", idx, ".conv"), cb, a.dimension, a.last_kernel_size, 1);
+    const bool skip_dual = a.lstm_layers > 0 && a.lstm_skip;
+    e->enc_last = mk_conv(name("encoder", idx, ".conv"), cb, a.dimension, a.last_kernel_size, 1, false, skip_dual, true);
     // ---- decoder
     idx = 0;
-    e->dec_first = mk_conv(name("decoder", idx, ".conv"), a.dimension, cb, a.kernel_size, 1);
+    e->dec_first = mk_conv(name("decoder", idx, ".conv"), a.dimension, cb, a.kernel_size, 1, false, false, true);
     idx++;
     if (a.lstm_layers > 0) {
         e->dec_lstm.prefix = name("decoder", idx, ".lstm");
@@ -179,7 +217,7 @@ void build_plan(fc_engine* e) {
         const int c = mult * nf, c2 = c / 2, hid = c2 / a.compress;
         auto& S = e->dec_stages[s];
         idx++;
-        S.resample = mk_conv(name("decoder", idx, ".convtr"), c, c2, 2 * ratio, ratio, true);
+        S.resample = mk_conv(name("decoder", idx, ".convtr"), c, c2, 2 * ratio, ratio, true, s > 0 || skip_dual, s == 0);
         idx++;
         S.shortcut = mk_conv(name("decoder", idx, ".shortcut.conv"), c2, c2, 1, 1);
         S.block1 = mk_conv(name("decoder", idx, ".block.1.conv"), c2, hid, a.residual_kernel_size, 1);
@@ -188,7 +226,7 @@ void build_plan(fc_engine* e) {
         mult /= 2;
     }
     idx++;
-    e->dec_last = mk_conv(name("decoder", idx, ".conv"), nf, 1, a.last_kernel_size, 1);
+    e->dec_last = mk_conv(name("decoder", idx, ".conv"), nf, 1, a.last_kernel_size, 1, false, true);
 
     // ---- checkpoint contract, in execution order
     add_conv_expect(e, e->enc_first);
@@ -201,7 +239,7 @@ void build_plan(fc_engine* e) {
         lb.layers.resize(a.lstm_layers);
         for (int l = 0; l < a.lstm_layers; ++l) {
             const std::string sfx = "_l" + std::to_string(l);
-            lb.layers[l].inproj = mk_conv(lb.prefix + ".inproj" + sfx, lb.H, 4 * lb.H, 1, 1);
+            lb.layers[l].inproj = mk_conv(lb.prefix + ".inproj" + sfx, lb.H, 4 * lb.H, 1, 1, false, false, true);
             lb.layers[l].inproj.has_norm = false;
             e->expected.push_back({lb.prefix + ".weight_ih" + sfx, {4 * lb.H, lb.H}});
             e->expected.push_back({lb.prefix + ".weight_hh" + sfx, {4 * lb.H, lb.H}});
@@ -224,14 +262,23 @@ void build_plan(fc_engine* e) {
 
 // ---- weight packing -------------------------------------------------------------------------------
 void choose_tiling(ConvLayer& L) {  // NOLINT
-    if (L.M > 64) { L.BM = 128; L.BN = 128; }
-    else if (L.M > 32) { L.BM = 64; L.BN = 256; }
+    if (L.M > 64) {
+        L.BM = 128; L.BN = 128;
+        if (L.small_n && L.M <= 256) { L.BM = 32; L.BN = 128; }   // too few 128x128 tiles at the bottleneck rate
+    } else if (L.M > 32) { L.BM = 64; L.BN = 256; }
     else { L.BM = 32; L.BN = 256; }
-    int cc = 2;
-    while (cc * 2 * L.gk <= 64 && cc * 2 <= 32) cc *= 2;
+    // channels per K-chunk: as many as fit (a) the register-staged slab, (b) K-chunk <= 64, (c) 80 KiB of LDS
+    // (two workgroups per CU: one stages while the other feeds the matrix cores)
     int cin_p2 = 2;
     while (cin_p2 < L.cin) cin_p2 *= 2;
-    if (cc > cin_p2) cc = cin_p2;
+    int cc = 2;
+    for (;;) {
+        const int n = cc * 2;
+        if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
+        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN)) break;
+        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, L.dual) > 80 * 1024) break;
+        cc = n;
+    }
     L.CC = cc;
     L.nchunk = ceil_div_i(L.cin, cc);
     L.Mpad = ceil_div_i(L.M, L.BM) * L.BM;
@@ -249,15 +296,16 @@ int upload(fc_engine* e, const std::vector<T>& h, T** out) {
 
 // gemm weight accessor: w(m, ci, tap) and bias(m)
 int pack_gemm(fc_engine* e, ConvLayer& L, const std::vector<float>& wg /*[M][cin][gk]*/, const std::vector<float>& bg) {
-    const int Kc = L.gk * L.CC, mtiles = L.Mpad / L.BM;
-    std::vector<float> packed((size_t)mtiles * L.nchunk * Kc * L.BM, 0.f);
+    const int mtiles = L.Mpad / L.BM;
+    const int wbuf = fc::conv_wbuf_floats(L.gk, L.CC, L.BM);   // chunk image exactly as it sits in LDS
+    std::vector<float> packed((size_t)mtiles * L.nchunk * wbuf, 0.f);
     for (int mt = 0; mt < mtiles; ++mt)
         for (int ch = 0; ch < L.nchunk; ++ch)
             for (int kk = 0; kk < L.gk; ++kk)
                 for (int cl = 0; cl < L.CC; ++cl) {
                     const int ci = ch * L.CC + cl;
                     if (ci >= L.cin) continue;
-                    float* dst = &packed[(((size_t)(mt * L.nchunk + ch) * L.gk + kk) * L.CC + cl) * L.BM];
+                    float* dst = &packed[(size_t)(mt * L.nchunk + ch) * wbuf + ((size_t)kk * L.CC + cl) * L.BM];
                     for (int mm = 0; mm < L.BM; ++mm) {
                         const int m = mt * L.BM + mm;
                         if (m < L.M) dst[mm] = wg[((size_t)m * L.cin + ci) * L.gk + kk];
@@ -384,7 +432,13 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     cx.launches += L.has_norm ? 2 : 1;
     cx.conv_launches += 1;
     if (cx.dry || cx.err) return out;
-    hipError_t er = fc::launch_conv(c, cx.st);
+    const double fl = 2.0 * cx.B * (double)L.M * L.cin * L.gk * c.Tout;
+    const double by = 4.0 * cx.B * ((double)L.cin * Tin * (s1.used ? 2 : 1) + (double)L.cout * g.Tout);
+    hipError_t er;
+    {
+        ProfSpan sp(e, cx, L.BM == 128 ? PC_CONV128 : (L.BM == 64 ? PC_CONV64 : PC_CONV32), fl, by);
+        er = fc::launch_conv(c, cx.st);
+    }
     if (er != hipSuccess) { cx.err = 1; g_err = "conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); return out; }
     if (L.has_norm) {
         er = fc::launch_gn_finalize(c.partials, nblk, (double)L.cout * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps,
@@ -411,6 +465,7 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
         cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H;
         cx.launches += T + 1;
         if (!cx.dry && !cx.err) {
+            ProfSpan sp(e, cx, PC_LSTM, 2.0 * B * (double)T * 4 * H * H, 4.0 * T * 4.0 * H * H);
             hipError_t er = hipMemsetAsync(state, 0, (size_t)3 * B * H * sizeof(float), cx.st);
             float *h0 = state, *h1 = state + (size_t)B * H, *c = state + (size_t)2 * B * H;
             for (int t = 0; t < T && er == hipSuccess; ++t) {
@@ -501,6 +556,7 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
         // encoder output permuted to [B,Tf,D] (seanet_encoder.py:175) with the last GroupNorm applied
         if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, emb, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
             return fail("combine launch failed");
+        ProfSpan sp(e, cx, PC_RVQ, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D, 0.0);
         if (fc::launch_rvq_encode(emb, B * Tf, D, e->arch.codebook_size, n_q, e->cb, e->enorm, codes, quantized, qbdt,
                                   sub_quants, Tf, cx.st) != hipSuccess)
             return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256})");
@@ -561,8 +617,32 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     return 0;
 }
 
+int fc_engine_profile(fc_engine* e, int enable) {
+    if (!e) return fail("null engine");
+    e->profiling = enable != 0;
+    return 0;
+}
+
+int fc_engine_profile_read(fc_engine* e, fc_prof* out) {
+    if (!e || !out) return fail("null argument");
+    for (int i = 0; i < FC_PROF_CLASSES; ++i) {
+        memset(&out[i], 0, sizeof(fc_prof));
+        strncpy(out[i].kernel, kProfNames[i], sizeof(out[i].kernel) - 1);
+    }
+    if (!e->spans.empty()) HIP_TRY(hipEventSynchronize(e->spans.back().b));
+    for (auto& s : e->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) continue;
+        out[s.cls].total_ms += ms; out[s.cls].flops += s.flops; out[s.cls].bytes += s.bytes; out[s.cls].launches += 1;
+    }
+    e->spans.clear();
+    e->events_used = 0;
+    return 0;
+}
+
 void fc_engine_destroy(fc_engine* e) {
     if (!e) return;
+    for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     for (void* p : e->dev_allocs) (void)hipFree(p);
     delete e;
 }

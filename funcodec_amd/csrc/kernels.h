@@ -17,7 +17,7 @@ struct Src {
 struct ConvLaunch {
     Src s0, s1;                   // s1.ptr == null -> single source; else v = f0(s0) + f1(s1)
     int elu = 0; float alpha = 1.f;
-    const float* wt = nullptr;    // packed weights [mtile][chunk][kk][cl][BM]
+    const float* wt = nullptr;    // packed weights [mtile][chunk][Wbuf]: [kk][cl][BM] + zero pad to 4 KiB
     const float* bias = nullptr;  // [Mpad]
     float* out = nullptr;
     long long out_sB = 0, out_sM = 0, out_sT = 1;
@@ -33,6 +33,9 @@ struct ConvLaunch {
 
 int conv_nblk(const ConvLaunch& c);                         // stat partials per utterance
 size_t conv_lds_bytes(const ConvLaunch& c);
+int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
+size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, bool dual);
+bool conv_slab_fits(int k, int stride, int CC, int BN);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
 
 // Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)

@@ -29,9 +29,12 @@ static inline __host__ __device__ int ceil_div(int a, int b) { return (a + b - 1
 //        (x[i-1], x[i]) and a scatter store out[co][i*r + phase - trimL]; its statistics cover the
 //        UNTRIMMED output as in SConvTranspose1d.forward (conv.py:287-303).
 //
-//    LDS:  Ws[Kc][BM]      weight chunk, k-major so the A fragment (lane -> row) is conflict free
+//    LDS:  Ws[2][Kc][BM]   weight chunk, k-major so the A fragment (lane -> row) is conflict free; filled by
+//                          global_load_lds DMA, double buffered (chunk c+1 streams in while chunk c computes)
 //          Xs[CC][S][PL]   input slab, split by stride phase so the B fragment (lane -> column) is
-//                          conflict free for every stride (tau = n*S + kk -> [kk % S][n + kk / S])
+//                          conflict free for every stride (tau = n*S + kk -> [kk % S][n + kk / S]); the raw
+//                          values of chunk c+1 are prefetched into registers during the MFMA loop of chunk c
+//          tab[Cin]        the producers' GroupNorm affine for this utterance
 // =================================================================================================
 struct ConvArgs {
     const float *src0, *aff0, *div0, *src1, *aff1;
@@ -44,60 +47,52 @@ struct ConvArgs {
     unsigned magic_r;       // ceil(2^32 / up_r)
     int elu; float alpha;
     int CC, nchunk, Kc;
-    int slabW, PL, rowStride;
+    int Wbuf;               // floats per packed weight chunk (multiple of 1024)
+    int slabW, PL, rowStride, xs_floats;
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
 __device__ __forceinline__ float elu_f(float v, float alpha) { return v > 0.f ? v : alpha * (expf(v) - 1.f); }
 
-template <int S>
-__device__ __forceinline__ void stage_slab(const ConvArgs& p, float* __restrict__ Xs, int b, int c0, int tbase, int tid) {
-    const int total = p.CC * p.slabW;
-    for (int e = tid; e < total; e += 256) {
-        const int cl = (int)__umulhi((unsigned)e, p.magic_slabW);
-        const int tau = e - cl * p.slabW;
-        const int ci = c0 + cl;
-        const int g = tbase + tau;
-        float v = 0.f;
-        if (ci < p.Cin && g >= -p.padL && g < p.Tin + p.padR) {
-            int src = g;
-            bool zero;
-            if (p.pad_zero) {
-                zero = (g < 0) || (g >= p.Tin);
-            } else {
-                if (src < 0) src = -src;
-                if (src >= p.Leff) src = 2 * (p.Leff - 1) - src;
-                zero = src >= p.Tin;     // zero-extension of inputs shorter than the pad (conv.py:89-93)
-            }
-            if (!zero) {
-                const size_t row = (size_t)b * p.Cin + ci;
-                v = p.src0[row * p.Tin + src];
-                if (p.div0) v = v / p.div0[b];
-                if (p.aff0) { const float2 a = ((const float2*)p.aff0)[row]; v = fmaf(v, a.x, a.y); }
-                if (p.src1) {
-                    float w = p.src1[row * p.Tin + src];
-                    if (p.aff1) { const float2 a = ((const float2*)p.aff1)[row]; w = fmaf(w, a.x, a.y); }
-                    v = v + w;
-                }
-                if (p.elu) v = elu_f(v, p.alpha);
-            }
-        }
-        int ph, q;
-        if (S == 1) { ph = 0; q = tau; }
-        else if (S > 1) { q = tau / S; ph = tau - q * S; }
-        else { q = tau / p.stride; ph = tau - q * p.stride; }
-        Xs[cl * p.rowStride + ph * p.PL + q] = v;
+constexpr int SLAB_PER_THREAD = 17;          // register-staged slab elements per thread per chunk
+constexpr int SLAB_MAX = SLAB_PER_THREAD * 256;
+
+// Direct global -> LDS copy of one packed weight chunk (contiguous, multiple of 4 KiB): each wave
+// instruction moves 1 KiB (64 lanes x 16 B) with no VGPR round trip.
+__device__ __forceinline__ void dma_weights(const float* __restrict__ gsrc, float* lds_dst, int nfloats, int tid) {
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int off = 0; off < nfloats; off += 1024) {
+        const float* g = gsrc + off + tid * 4;
+        float* l = lds_dst + off + wid * 256;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
+// Resolve slab element e of the chunk starting at channel c0 to its source index; returns false when the
+// element is padding that evaluates to literal zero.
+__device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int tbase, int& cl, int& tau, int& src) {
+    cl = (int)__umulhi((unsigned)e, p.magic_slabW);
+    tau = e - cl * p.slabW;
+    const int g = tbase + tau;
+    src = g;
+    if (c0 + cl >= p.Cin || g < -p.padL || g >= p.Tin + p.padR) return false;
+    if (p.pad_zero) return g >= 0 && g < p.Tin;
+    if (src < 0) src = -src;
+    if (src >= p.Leff) src = 2 * (p.Leff - 1) - src;
+    return src < p.Tin;      // zero-extension of inputs shorter than the pad (conv.py:89-93)
+}
+
+template <int BM, int BN, int WM, int WN, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ws = smem;
-    float* Xs = smem + p.Kc * BM;
-    __shared__ double red[2][4];
+    float* Xs = smem + 2 * p.Wbuf;
+    float2* tab0 = (float2*)(Xs + p.xs_floats);
+    float2* tab1 = tab0 + p.Cin;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -114,46 +109,137 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int tbase = n0 * p.stride - p.padL;
-    const int a_off = wm * (TM * 32) + l31;
-    const int b_off = wn * (TN * 32) + l31 + hi * p.rowStride;
+    const int total = p.CC * p.slabW;
+    const int nu = (total + 255) >> 8;                // slab elements per thread (<= SLAB_PER_THREAD)
+    const float divv = p.div0 ? p.div0[b] : 1.f;
+    const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
+    const size_t rowbase = (size_t)b * p.Cin;
+
+    // per-(b, channel) GroupNorm affine of the producers, staged once
+    for (int c = tid; c < p.Cin; c += 256) {
+        tab0[c] = p.aff0 ? ((const float2*)p.aff0)[rowbase + c] : make_float2(1.f, 0.f);
+        if (DUAL) tab1[c] = p.aff1 ? ((const float2*)p.aff1)[rowbase + c] : make_float2(1.f, 0.f);
+    }
+
+    // utterance base pointers are wave-uniform (SGPR base + 32-bit lane offset addressing)
+    const float* __restrict__ s0b = p.src0 + rowbase * p.Tin;
+    const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
+
+    // Register-staged slab: element e = tid + 256*u of every chunk maps to the same (local channel, tau), so
+    // its source offset (relative to the chunk's first channel) and its LDS slot are computed ONCE:
+    //   soff[u] = cl*Tin + reflect(tau)      meta[u] = lds_slot | cl << 16 | in_slab << 30 | nonzero << 31
+    unsigned soff[SLAB_PER_THREAD], meta[SLAB_PER_THREAD];
+    float v0[SLAB_PER_THREAD], v1[DUAL ? SLAB_PER_THREAD : 1];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int u = 0; u < SLAB_PER_THREAD; ++u) {
+        const int e = tid + 256 * u;
+        soff[u] = 0u; meta[u] = 0u;
+        if (u < nu && e < total) {
+            int cl, tau, src;
+            const bool ok = slab_src(p, e, 0, tbase, cl, tau, src);
+            int ph, q;
+            switch (p.stride) {
+                case 1: ph = 0; q = tau; break;
+                case 2: q = tau >> 1; ph = tau & 1; break;
+                case 4: q = tau >> 2; ph = tau & 3; break;
+                case 8: q = tau >> 3; ph = tau & 7; break;
+                default: q = tau / p.stride; ph = tau - q * p.stride; break;
+            }
+            soff[u] = ok ? (unsigned)(cl * p.Tin + src) : 0u;     // < 2^31 elements per utterance
+            meta[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | ((unsigned)cl << 16) | (1u << 30) | (ok ? 1u << 31 : 0u);
+        }
+    }
+    // All loads of a chunk are unconditional (masked elements read offset 0) and issued back to back so that
+    // they stay in flight during the MFMA loop of the previous chunk.
+    auto load_slab = [&](int c0) {
+        vmask = 0;
+        const unsigned cbase = (unsigned)(c0 * p.Tin);
+#pragma unroll
+        for (int u = 0; u < SLAB_PER_THREAD; ++u) {
+            if (u < nu) {                             // wave-uniform
+                const bool ok = (meta[u] >> 31) && (c0 + (int)((meta[u] >> 16) & 0x3fu) < p.Cin);
+                const unsigned off = ok ? soff[u] + cbase : 0u;
+                v0[u] = s0b[off];
+                if (DUAL) v1[u] = s1b[off];
+                vmask |= (ok ? 1u : 0u) << u;
+            }
+        }
+    };
+    auto write_slab = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < SLAB_PER_THREAD; ++u) {
+            if (u < nu && ((meta[u] >> 30) & 1u)) {
+                float v = 0.f;
+                if ((vmask >> u) & 1u) {
+                    const int ci = c0 + (int)((meta[u] >> 16) & 0x3fu);
+                    v = v0[u];
+                    if (p.div0) v = v / divv;
+                    const float2 a = tab0[ci];
+                    v = fmaf(v, a.x, a.y);
+                    if (DUAL) {
+                        const float2 a1 = tab1[ci];
+                        v = v + fmaf(v1[u], a1.x, a1.y);
+                    }
+                    if (p.elu) v = elu_f(v, p.alpha);
+                }
+                Xs[meta[u] & 0xffffu] = v;
+            }
+        }
+    };
+
+    dma_weights(wt_tile, smem, p.Wbuf, tid);
+    load_slab(0);
+    __syncthreads();          // affine tables visible; weight chunk 0 landed (the barrier drains vmcnt)
+    write_slab(0);
+    __syncthreads();
+
+    const int a_off = hi * BM + wm * (TM * 32) + l31;
+    const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
     const int half_cc = p.CC >> 1;
+    const int nks = p.Kc >> 1;
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-        {   // weight chunk: contiguous Kc*BM floats
-            const float4* wsrc = (const float4*)(p.wt + ((size_t)(mt * p.nchunk + chunk) * p.Kc) * BM);
-            const int n4 = (p.Kc * BM) >> 2;
-            for (int i = tid; i < n4; i += 256) ((float4*)Ws)[i] = wsrc[i];
+        const float* Ws = smem + (chunk & 1) * p.Wbuf;
+        const bool more = chunk + 1 < p.nchunk;
+        if (more) {
+            dma_weights(wt_tile + (size_t)(chunk + 1) * p.Wbuf, smem + ((chunk + 1) & 1) * p.Wbuf, p.Wbuf, tid);
+            load_slab((chunk + 1) * p.CC);
         }
-        const int c0 = chunk * p.CC;
-        switch (p.stride) {
-            case 1: stage_slab<1>(p, Xs, b, c0, tbase, tid); break;
-            case 2: stage_slab<2>(p, Xs, b, c0, tbase, tid); break;
-            case 4: stage_slab<4>(p, Xs, b, c0, tbase, tid); break;
-            case 5: stage_slab<5>(p, Xs, b, c0, tbase, tid); break;
-            case 8: stage_slab<8>(p, Xs, b, c0, tbase, tid); break;
-            default: stage_slab<0>(p, Xs, b, c0, tbase, tid); break;
-        }
-        __syncthreads();
-        int ph = 0, q = 0;
-        for (int kk = 0; kk < p.k; ++kk) {
-            const int tapoff = ph * p.PL + q;
-            const float* wrow = Ws + (kk * p.CC + hi) * BM + a_off;
-            const float* xrow = Xs + tapoff + b_off;
-            for (int c2 = 0; c2 < half_cc; ++c2) {
-                float a[TM], bb[TN];
+        {   // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi
+            float a_cur[TM], b_cur[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = wrow[c2 * 2 * BM + i * 32];
+            for (int i = 0; i < TM; ++i) a_cur[i] = Ws[a_off + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bb[j] = xrow[c2 * 2 * p.rowStride + j * 32];
+            for (int j = 0; j < TN; ++j) b_cur[j] = Xs[b_off + j * 32];
+            int ph = 0, q = 0, c2 = 0;
+            for (int ks = 0; ks < nks; ++ks) {
+                if (++c2 == half_cc) { c2 = 0; if (++ph == p.stride) { ph = 0; ++q; } }
+                float a_n[TM], b_n[TN];
+                if (ks + 1 < nks) {
+                    const float* wrow = Ws + (ks + 1) * 2 * BM + a_off;
+                    const float* xrow = Xs + c2 * 2 * p.rowStride + ph * p.PL + q + b_off;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a_n[i] = wrow[i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b_n[j] = xrow[j * 32];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a_cur[i] = a_n[i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b_cur[j] = b_n[j];
             }
-            if (++ph == p.stride) { ph = 0; ++q; }
         }
-        __syncthreads();
+        __syncthreads();      // every wave is done with Xs and Ws[cur]; next weights + slab registers landed
+        if (more) {
+            write_slab((chunk + 1) * p.CC);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias, store, GroupNorm partial statistics --------------------------------------
@@ -184,19 +270,20 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs p) {
         }
     }
     if (p.partials) {
+        double* red = (double*)smem;     // all waves are past the last barrier: the weight buffers are free
         double d1 = (double)s1, d2 = (double)s2;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) {
             d1 += __shfl_xor(d1, o, 64);
             d2 += __shfl_xor(d2, o, 64);
         }
-        if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+        if (lane == 0) { red[wid] = d1; red[4 + wid] = d2; }
         __syncthreads();
         if (tid == 0) {
             const int nblk = gridDim.x * gridDim.y;
             const size_t slot = ((size_t)b * nblk + (size_t)mt * gridDim.x + nt) * 2;
-            p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-            p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+            p.partials[slot] = ((red[0] + red[1]) + red[2]) + red[3];
+            p.partials[slot + 1] = ((red[4] + red[5]) + red[6]) + red[7];
         }
     }
 }
@@ -215,33 +302,64 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.magic_r = c.up_r ? (unsigned)((0x100000000ull + c.up_r - 1) / (unsigned long long)c.up_r) : 0u;
     a.elu = c.elu; a.alpha = c.alpha;
     a.CC = c.CC; a.nchunk = c.nchunk; a.Kc = c.k * c.CC;
+    a.Wbuf = conv_wbuf_floats(c.k, c.CC, c.BM);
     a.slabW = (c.BN - 1) * c.stride + c.k;
     a.PL = ceil_div(a.slabW, c.stride);
     a.rowStride = a.PL * c.stride;
+    a.xs_floats = (c.CC * a.rowStride + 3) & ~3;
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     return a;
 }
 
+int conv_wbuf_floats(int k, int CC, int BM) { return ((k * CC * BM + 1023) / 1024) * 1024; }
+
 int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM); }
 
+size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, bool dual) {
+    const int slabW = (BN - 1) * stride + k;
+    const int rowStride = ceil_div(slabW, stride) * stride;
+    const int xs = (CC * rowStride + 3) & ~3;
+    return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + xs) * sizeof(float) + (size_t)Cin * 8 * (dual ? 2 : 1);
+}
+
+bool conv_slab_fits(int k, int stride, int CC, int BN) { return CC * ((BN - 1) * stride + k) <= SLAB_MAX; }
+
 size_t conv_lds_bytes(const ConvLaunch& c) {
-    const ConvArgs a = make_args(c);
-    return (size_t)(a.Kc * c.BM + c.CC * a.rowStride) * sizeof(float);
+    return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr);
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_done[2] = {false, false};
+    const bool dual = c.s1.ptr != nullptr;
+    if (dual) {
+        auto kfn = conv_mfma_kernel<BM, BN, WM, WN, true>;
+        if (!attr_done[1]) {
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done[1] = true;
+        }
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    } else {
+        auto kfn = conv_mfma_kernel<BM, BN, WM, WN, false>;
+        if (!attr_done[0]) {
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done[0] = true;
+        }
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
-    dim3 grid(ceil_div(c.Tout, c.BN), ceil_div(c.M, c.BM), c.B), block(256);
-    if (c.BM == 128 && c.BN == 128)
-        hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2>), grid, block, lds, st, a);
-    else if (c.BM == 64 && c.BN == 256)
-        hipLaunchKernelGGL((conv_mfma_kernel<64, 256, 1, 4>), grid, block, lds, st, a);
-    else if (c.BM == 32 && c.BN == 256)
-        hipLaunchKernelGGL((conv_mfma_kernel<32, 256, 1, 4>), grid, block, lds, st, a);
-    else
-        return hipErrorInvalidValue;
-    return hipGetLastError();
+    if (!conv_slab_fits(c.k, c.stride, c.CC, c.BN) || lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
+    dim3 grid(ceil_div(c.Tout, c.BN), ceil_div(c.M, c.BM), c.B);
+    if (c.BM == 128 && c.BN == 128) return launch_conv_t<128, 128, 2, 2>(c, a, grid, lds, st);
+    if (c.BM == 64 && c.BN == 256) return launch_conv_t<64, 256, 1, 4>(c, a, grid, lds, st);
+    if (c.BM == 32 && c.BN == 256) return launch_conv_t<32, 256, 1, 4>(c, a, grid, lds, st);
+    if (c.BM == 32 && c.BN == 128) return launch_conv_t<32, 128, 1, 4>(c, a, grid, lds, st);
+    return hipErrorInvalidValue;
 }
 
 // =================================================================================================
@@ -428,21 +546,43 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
 #pragma unroll
         for (int r = 0; r < 4; ++r) xr[r] = xn[4 * g + r];
         const float* cbi = cb + (size_t)i * K * D;
-        for (int nt = 0; nt < codes_per_wave; nt += 16) {
-            const int code = wid * codes_per_wave + nt + r16;
-            const float* erow = cbi + (size_t)code * D + 4 * g;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // two code tiles per iteration: independent accumulators hide the 40-cycle dependent-MFMA latency and
+        // keep 2*NQ4 16-byte codebook loads in flight; each (row, code) chain keeps its own d order.
+        constexpr bool TWO = (D <= 128);
+        for (int nt = 0; nt < codes_per_wave; nt += (TWO ? 32 : 16)) {
+            const int codeA = wid * codes_per_wave + nt + r16;
+            const bool hasB = TWO && (nt + 16 < codes_per_wave);
+            const int codeB = hasB ? codeA + 16 : codeA;
+            const float* erowA = cbi + (size_t)codeA * D + 4 * g;
+            const float* erowB = cbi + (size_t)codeB * D + 4 * g;
+            f32x4 bA[NQ4], bB[TWO ? NQ4 : 1];
 #pragma unroll
             for (int q = 0; q < NQ4; ++q) {
-                const f32x4 b4 = *(const f32x4*)(erow + 16 * q);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[j], acc, 0, 0, 0);
+                bA[q] = *(const f32x4*)(erowA + 16 * q);
+                if (TWO) bB[q] = *(const f32x4*)(erowB + 16 * q);
             }
-            const float en = enorm[(size_t)i * K + code];
+            f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NQ4; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], bA[q][j], accA, 0, 0, 0);
+                    if (TWO) accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], bB[q][j], accB, 0, 0, 0);
+                }
+            }
+            const float enA = enorm[(size_t)i * K + codeA];
+            const float enB = enorm[(size_t)i * K + codeB];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float dist = -__fadd_rn(__fsub_rn(xr[r], acc[r]), en);
-                if (dist > best[r]) { best[r] = dist; bidx[r] = code; }
+                const float dist = -__fadd_rn(__fsub_rn(xr[r], accA[r]), enA);
+                if (dist > best[r]) { best[r] = dist; bidx[r] = codeA; }
+            }
+            if (hasB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dist = -__fadd_rn(__fsub_rn(xr[r], accB[r]), enB);
+                    if (dist > best[r]) { best[r] = dist; bidx[r] = codeB; }
+                }
             }
         }
 #pragma unroll
@@ -553,33 +693,60 @@ hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D,
 // =================================================================================================
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.f / (1.f + expf(-v)); }
 
+// NS = 16-wide k super-steps per wave (compile time, so that all W / h fragments are loaded up front and stay
+// in flight together); NS == 0 selects the generic runtime loop.
+template <int NS>
 __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ wperm, const float* __restrict__ xproj,
                                                         const float* __restrict__ h_prev, float* __restrict__ h_next,
                                                         float* __restrict__ c, float* __restrict__ y, int B, int H, int T,
-                                                        int t) {
+                                                        int t, int KS) {
     __shared__ f32x4 red[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
     const int blk = blockIdx.x;
-    const int KS = (H >> 4) < 4 ? (H >> 4) : 4;
     const int kslice = H / KS;
     const int nsteps = kslice >> 4;
-    const float* wrow = wperm + ((size_t)blk * 16 + r16) * H + wid * kslice + 4 * g;
+    const bool active = wid < KS;
+    const float* wrow = wperm + ((size_t)blk * 16 + r16) * H + (active ? wid : 0) * kslice + 4 * g;
+    constexpr int NA = NS > 0 ? NS : 1;
+    f32x4 a4[NA];
+    if (NS > 0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) a4[q] = *(const f32x4*)(wrow + 16 * q);
+    }
     const int nbt = (B + 15) >> 4;
     for (int nb = 0; nb < nbt; ++nb) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (wid < KS) {
-            const int brow = nb * 16 + r16;
-            const bool bvalid = brow < B;
-            const float* hrow = h_prev + (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
-            for (int q = 0; q < nsteps; ++q) {
-                const f32x4 a4 = *(const f32x4*)(wrow + 16 * q);
-                f32x4 b4 = *(const f32x4*)(hrow + 16 * q);
-                if (!bvalid) b4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int brow = nb * 16 + r16;
+        const bool bvalid = brow < B;
+        const float* hrow = h_prev + (size_t)(bvalid ? brow : 0) * H + (active ? wid : 0) * kslice + 4 * g;
+        if (NS > 0) {
+            f32x4 b4[NA];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b4[j], acc, 0, 0, 0);
+            for (int q = 0; q < NA; ++q) {
+                b4[q] = *(const f32x4*)(hrow + 16 * q);
+                if (!bvalid) b4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (q & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[q][j], acc1, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[q][j], acc, 0, 0, 0);
+                }
+            }
+            acc = acc + acc1;
+        } else if (active) {
+            for (int q = 0; q < nsteps; ++q) {
+                const f32x4 av = *(const f32x4*)(wrow + 16 * q);
+                f32x4 bv = *(const f32x4*)(hrow + 16 * q);
+                if (!bvalid) bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
             }
         }
+        if (!active) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         red[wid][lane] = acc;
         __syncthreads();
         if (wid == 0) {
@@ -608,7 +775,21 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
 hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float* h_prev, float* h_next, float* c,
                             float* y, int B, int H, int T, int t, hipStream_t st) {
     if (H % 16 != 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lstm_step_kernel, dim3(H / 4), dim3(256), 0, st, wperm, xproj, h_prev, h_next, c, y, B, H, T, t);
+    int KS = 4;
+    while (KS > 1 && (H % (16 * KS)) != 0) KS >>= 1;
+    const int ns = H / (16 * KS);
+    dim3 grid(H / 4), block(256);
+#define FC_LSTM_CASE(NS) \
+    hipLaunchKernelGGL(lstm_step_kernel<NS>, grid, block, 0, st, wperm, xproj, h_prev, h_next, c, y, B, H, T, t, KS)
+    switch (ns) {
+        case 1: FC_LSTM_CASE(1); break;
+        case 2: FC_LSTM_CASE(2); break;
+        case 4: FC_LSTM_CASE(4); break;
+        case 8: FC_LSTM_CASE(8); break;
+        case 16: FC_LSTM_CASE(16); break;
+        default: FC_LSTM_CASE(0); break;
+    }
+#undef FC_LSTM_CASE
     return hipGetLastError();
 }
 

@@ -141,6 +141,16 @@ class CodecEngine:
         self._check(self.lib.fc_engine_work(self._h, B, T, n_q, C.byref(w)))
         return {f: getattr(w, f) for f, _ in _lib.FcWork._fields_}
 
+    def set_profiling(self, on: bool) -> None:
+        self._check(self.lib.fc_engine_profile(self._h, int(on)))
+
+    def read_profile(self):
+        """Per-kernel-class totals since the last read (synchronises on the last recorded event)."""
+        arr = (_lib.FcProf * _lib.FC_PROF_CLASSES)()
+        self._check(self.lib.fc_engine_profile_read(self._h, arr))
+        return [dict(kernel=p.kernel.decode(), total_ms=p.total_ms, flops=p.flops, bytes=p.bytes, launches=p.launches)
+                for p in arr]
+
     def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
         return t.to(device=self.device, dtype=dtype).contiguous()
 
