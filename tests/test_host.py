@@ -1,0 +1,151 @@
+"""CPU tests of the host logic and of the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from funcodec_amd import _lib
+from funcodec_amd.config import ArchSpec, arch_from_config, recipe_config
+from funcodec_amd.engine import CodecEngine, EngineError
+from funcodec_amd.parallel import shard_range
+from funcodec_amd.plan import expected_tensors
+from funcodec_amd.synth import make_state_dict, synthetic_audio
+from helpers import GOLD
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "funcodec_amd.h")).read()
+    declared = set(re.findall(r"\b(fc_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"fc_engine", "fc_arch", "fc_work", "fc_prof"}
+    lib = ctypes.CDLL(_lib.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/funcodec_amd.h but not exported"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert _lib.load().fc_abi_version() == _lib.FC_ABI_VERSION
+
+
+@pytest.mark.parametrize("name", ["ds320", "ds640"])
+def test_checkpoint_contract_matches_reference_keys(name):
+    """Key names/shapes the engine asks for == the real reference's state_dict (fixture from make_golden.py)."""
+    arch = arch_from_config(recipe_config(name))
+    ref = json.load(open(os.path.join(GOLD, f"state_dict_keys_{name}.json")))
+    want = expected_tensors(arch)
+    eng = CodecEngine(arch)
+    assert eng.expected_tensors() == want
+    for k, shape in want.items():
+        assert k in ref, k
+        assert tuple(ref[k]) == tuple(shape), (k, ref[k], shape)
+    unused = {k for k in ref if k not in want}
+    # everything of encoder./decoder. is consumed; only EMA bookkeeping of the quantiser is not
+    assert unused == {"quantizer.rq.model.inited", "quantizer.rq.model.cluster_size", "quantizer.rq.model.embed_avg"}
+
+
+def test_arch_from_recipe_configs():
+    a = arch_from_config(recipe_config("ds640"))
+    assert a.ratios == (8, 5, 4, 2, 2) and a.hop_length == 640 and a.bottleneck_channels == 1024
+    assert a.num_quantizers_for_bandwidth(None) == 32
+    assert a.num_quantizers_for_bandwidth(4000) == 16       # 250 bps per quantiser (vq.py:114-117)
+    assert a.num_quantizers_for_bandwidth(100) == 1
+    assert a.num_quantizers_for_bandwidth(10 ** 9) == 32
+    b = arch_from_config(recipe_config("ds320"))
+    assert b.hop_length == 320 and b.num_quantizers_for_bandwidth(8000) == 16
+    assert a.frames_for(160000) == 250 and a.frames_for(160001) == 251 and a.frames_for(1) == 1
+
+
+@pytest.mark.parametrize("mut", [
+    lambda c: c["encoder_conf"].update(norm="weight_norm"),
+    lambda c: c["encoder_conf"].update(causal=True),
+    lambda c: c.update(model="freqcodec"),
+    lambda c: c["model_conf"].update(segment_dur=1.0),
+    lambda c: c["quantizer_conf"].update(codec_dim=64),
+    lambda c: c["decoder_conf"].update(ratios=[8, 5, 4]),
+])
+def test_out_of_scope_configs_are_refused(mut):
+    cfg = recipe_config("ds320")
+    mut(cfg)
+    with pytest.raises(NotImplementedError):
+        arch_from_config(cfg)
+
+
+def test_engine_sizes_and_work_accounting():
+    arch = arch_from_config(recipe_config("ds640"))
+    eng = CodecEngine(arch)
+    assert eng.hop_length == 640
+    for T in (1, 639, 640, 641, 16000, 160000, 160001):
+        assert eng.frames(T) == arch.frames_for(T)
+    w1 = eng.lib.fc_engine_workspace_bytes(eng._h, 1, 16000)
+    w2 = eng.lib.fc_engine_workspace_bytes(eng._h, 2, 16000)
+    w3 = eng.lib.fc_engine_workspace_bytes(eng._h, 2, 32000)
+    assert 0 < w1 < w2 < w3
+    work = eng.work(16, 160000, 32)
+    # 8.51 GFLOP per audio-second for ds640 -> 1.36 TFLOP for the 160 audio-second batch
+    assert abs(work["total_flops"] / 1.36e12 - 1.0) < 0.01
+
+
+def test_engine_fails_loudly_without_gpu_and_on_bad_checkpoints():
+    arch = arch_from_config(recipe_config("tiny"))
+    sd = make_state_dict(arch, 1)
+    eng = CodecEngine(arch)
+    bad = dict(sd)
+    del bad["encoder.model.3.conv.conv.weight"]
+    with pytest.raises(EngineError, match="missing tensor"):
+        eng.load_state_dict(bad)
+    bad = dict(sd)
+    bad["encoder.model.3.conv.conv.weight"] = bad["encoder.model.3.conv.conv.weight"][:, :, :-1]
+    with pytest.raises(EngineError, match="shape mismatch"):
+        CodecEngine(arch).load_state_dict(bad)
+    bad = dict(sd)
+    bad["quantizer.rq.model.inited"] = np.zeros_like(bad["quantizer.rq.model.inited"])
+    with pytest.raises(EngineError, match="un-initialised"):
+        CodecEngine(arch).load_state_dict(bad)
+    if not torch.cuda.is_available():
+        with pytest.raises(EngineError, match="no CPU fallback"):
+            CodecEngine(arch).load_state_dict(sd)      # finalize() needs a gfx950 device
+    with pytest.raises(EngineError, match="no CPU fallback|gfx950"):
+        CodecEngine(arch, "cpu")
+
+
+def test_use_ddp_false_checkpoint_layout_is_accepted_up_to_finalize():
+    """core_vq.py:147-150 stores one codebook per layer; the loader stacks them."""
+    arch = arch_from_config(recipe_config("tiny"))
+    sd = make_state_dict(arch, 2)
+    emb = sd.pop("quantizer.rq.model.embed")
+    for i in range(emb.shape[0]):
+        sd[f"quantizer.rq.model.layers.{i}._codebook.embed"] = emb[i]
+    sd.pop("quantizer.rq.model.inited")
+    eng = CodecEngine(arch)
+    try:
+        eng.load_state_dict(sd)
+    except EngineError as e:           # only the device step may fail on a GPU-less box
+        assert "no CPU fallback" in str(e)
+
+
+def test_speech2token_refuses_cpu(tmp_path):
+    from funcodec_amd.bin.codec_inference import Speech2Token
+    from funcodec_amd.synth import make_checkpoint
+    cfg, pth = make_checkpoint(str(tmp_path), "tiny", 3)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        Speech2Token(cfg, pth, device="cpu")
+
+
+def test_synth_is_deterministic():
+    arch = arch_from_config(recipe_config("tiny"))
+    a, b = make_state_dict(arch, 7), make_state_dict(arch, 7)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert np.array_equal(synthetic_audio(2, 100, 5, "tones"), synthetic_audio(2, 100, 5, "tones"))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 16, 1024, 1027):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

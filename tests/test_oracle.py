@@ -1,0 +1,71 @@
+"""CPU tests: the oracle itself against the golden vectors produced by the REAL reference
+(oracle/make_golden.py), and the plain-C RVQ restatement against the same."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import audio, golden, index_report, manifest, oracle_for, rms
+
+MAN = manifest()
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") != "rvq"]
+SAME_BUILD = torch.__version__ == MAN["torch"]
+
+
+@pytest.mark.parametrize("name", E2E)
+def test_torch_oracle_matches_reference_golden(name):
+    c = MAN["cases"][name]
+    if c["config"] == "ds640" and c["samples"] > 12000 and not SAME_BUILD:
+        pytest.skip("different torch build")
+    orc = oracle_for(c["config"], c["weight_seed"], c["codebook_decay"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    g = golden(name)
+    o = orc.inference(wav, bit_width=c["bit_width"], use_scale=True)
+    rep = index_report(o["code_indices"][0], g["indices"].astype(np.int64))
+    # bit-exact on the torch build / thread count that generated the fixtures; ~1e-6 noise otherwise
+    assert rms(o["encoder_out"], g["encoder_out"]) < 1e-5
+    assert rms(o["recon_speech"], g["recon"]) < 1e-4
+    if SAME_BUILD and torch.get_num_threads() == MAN["threads"]:
+        assert rep["mismatched_indices"] == 0
+        assert np.array_equal(o["recon_speech"].numpy(), g["recon"])
+    else:
+        assert rep["frames_bad"] <= max(1, rep["frames"] // 100)
+    tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
+    wav2, _ = orc.decode_codes(tok)
+    assert rms(wav2, g["recon_from_codes"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["rvq_flat", "rvq_decay08"])
+def test_c_oracle_rvq_matches_reference_golden(name):
+    import c_oracle
+    c = MAN["cases"][name]
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    sig = (c["codebook_decay"] ** np.arange(32, dtype=np.float64)).astype(np.float32)[:, None, None]
+    embed = rng.standard_normal((32, 1024, 128)).astype(np.float32) * sig
+    z = rng.standard_normal((8, 250, 128)).astype(np.float32) * 1.5
+    rows = slice(700, 900)     # 200 rows of the 2000 keep the scalar C loop to ~2 s
+    codes, quant = c_oracle.rvq_encode(z.reshape(-1, 128)[rows], embed, 32)
+    g = golden(name)
+    ref = g["indices"].astype(np.int64).reshape(32, -1)[:, rows]
+    assert np.array_equal(codes, ref), f"{int((codes != ref).sum())} of {codes.size} indices differ"
+    assert np.array_equal(quant, g["quantized"].reshape(-1, 128)[rows])
+    # decode: sum of code vectors in stage order
+    emb = c_oracle.rvq_decode(codes.T.copy(), embed)
+    assert np.array_equal(emb, quant)
+
+
+def test_c_oracle_small_dims_and_ties():
+    """D=16/K=64 (the tiny config) and a planted exact tie: the first index must win."""
+    import c_oracle
+    rng = np.random.Generator(np.random.PCG64(5))
+    cb = rng.standard_normal((3, 64, 16)).astype(np.float32)
+    cb[0, 40] = cb[0, 7]           # duplicate code vector -> exact tie whenever 7 is the nearest
+    x = cb[0, 7][None, :] + 0.01 * rng.standard_normal((5, 16)).astype(np.float32)
+    codes, quant = c_oracle.rvq_encode(x, cb, 3)
+    assert (codes[0] == 7).all()
+    orc_t = torch.from_numpy(cb)
+    # torch restatement agrees on this easy case
+    from torch_oracle import Oracle
+    from funcodec_amd.config import recipe_config
+    o = Oracle(recipe_config("tiny"), {"quantizer.rq.model.embed": orc_t})
+    _, idx, _ = o.rvq_forward(torch.from_numpy(x)[None], 3)
+    assert np.array_equal(idx[:, 0].numpy(), codes)
