@@ -48,6 +48,7 @@ struct ConvLayer {
     int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
     int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
     float *wt = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;   // device
+    int* koff = nullptr;                                                        // device
 };
 
 struct LstmLayer {
@@ -315,6 +316,7 @@ int pack_gemm(fc_engine* e, ConvLayer& L, const std::vector<float>& wg /*[M][cin
     for (int m = 0; m < L.M; ++m) bpad[m] = bg[m];
     if (upload(e, packed, &L.wt)) return 1;
     if (upload(e, bpad, &L.bias)) return 1;
+    if (upload(e, fc::conv_koff_table(L.gk, L.gstride, L.CC, L.BN), &L.koff)) return 1;
     return 0;
 }
 
@@ -399,9 +401,24 @@ ConvGeom conv_geom(const ConvLayer& L, int T) {
 Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, int elu, int Tin,
              float* out_override = nullptr, long long sB = 0, long long sM = 0, long long sT = 0) {
     const ConvGeom g = conv_geom(L, Tin);
+    // Layers with several M tiles would re-apply the fused prologue (GroupNorm affine, residual add, ELU) once per
+    // M tile; for those (deep, short tensors) it is cheaper to materialise the activated input once and stream it.
+    const bool has_prologue = s0.aff || s0.div || s1.used || elu;
+    if (L.Mpad / L.BM >= 3 && has_prologue) {
+        float* tmp = cx.alloc<float>((size_t)cx.B * L.cin * Tin);
+        cx.launches++;
+        if (!cx.dry && !cx.err) {
+            hipError_t er0 = fc::launch_combine(s0, s1, elu, e->arch.elu_alpha, nullptr, cx.B, L.cin, Tin, Tin, tmp,
+                                                (long long)L.cin * Tin, Tin, 1, cx.st);
+            if (er0 != hipSuccess) { cx.err = 1; g_err = std::string("combine launch failed: ") + hipGetErrorString(er0); }
+        }
+        s0 = fc::Src(); s0.ptr = tmp; s0.used = 1;
+        s1 = fc::Src();
+        elu = 0;
+    }
     fc::ConvLaunch c;
     c.s0 = s0; c.s1 = s1; c.elu = elu; c.alpha = e->arch.elu_alpha;
-    c.wt = L.wt; c.bias = L.bias;
+    c.wt = L.wt; c.bias = L.bias; c.koff = L.koff;
     c.B = cx.B; c.Cin = L.cin; c.Tin = Tin; c.M = L.M;
     c.k = L.gk; c.stride = L.gstride; c.padL = g.padL; c.padR = g.padR;
     c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk;

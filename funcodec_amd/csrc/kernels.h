@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace fc {
 
 // One input of a fused prologue:  v = src[b][c][t];  optional /div[b];  optional per-(b,c) affine
@@ -19,6 +21,7 @@ struct ConvLaunch {
     int elu = 0; float alpha = 1.f;
     const float* wt = nullptr;    // packed weights [mtile][chunk][Wbuf]: [kk][cl][BM] + zero pad to 4 KiB
     const float* bias = nullptr;  // [Mpad]
+    const int* koff = nullptr;    // device table from conv_koff_table()
     float* out = nullptr;
     long long out_sB = 0, out_sM = 0, out_sT = 1;
     int B = 0, Cin = 0, Tin = 0;
@@ -36,6 +39,7 @@ size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
 size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, bool dual);
 bool conv_slab_fits(int k, int stride, int CC, int BN);
+std::vector<int> conv_koff_table(int k, int stride, int CC, int BN);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
 
 // Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)

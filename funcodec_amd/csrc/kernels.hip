@@ -6,6 +6,8 @@
 // traded.  Wavefront = 64 lanes throughout.
 #include "kernels.h"
 
+#include <vector>
+
 namespace fc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,12 +52,24 @@ struct ConvArgs {
     int Wbuf;               // floats per packed weight chunk (multiple of 1024)
     int slabW, PL, rowStride, xs_floats;
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
+    const int* koff;        // [Kc/2 (+pad)] B-operand LDS float offset per k-step
+    int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-__device__ __forceinline__ float elu_f(float v, float alpha) { return v > 0.f ? v : alpha * (expf(v) - 1.f); }
+// exp(x) for x <= 0 via the hardware exp2 with a two-term product x*log2(e) (hi + lo), ~1-2 ulp, no
+// range/denormal handling needed on this half line (results in (0, 1], underflow to 0 is the right answer).
+__device__ __forceinline__ float exp_neg(float x) {
+    const float L2E_HI = 1.44269502162933349609375f;      // fl(log2 e)
+    const float L2E_LO = 1.925963033500011e-08f;           // log2 e - L2E_HI
+    const float r = x * L2E_HI;
+    const float err = fmaf(x, L2E_HI, -r) + x * L2E_LO;    // exact rounding error of r + low-order term
+    const float p = __builtin_amdgcn_exp2f(r);
+    return fmaf(p, err * 0.693147182464599609375f, p);    // 2^(r+err) ~= 2^r * (1 + err ln 2)
+}
+__device__ __forceinline__ float elu_f(float v, float alpha) { return v > 0.f ? v : alpha * (exp_neg(v) - 1.f); }
 
 constexpr int SLAB_PER_THREAD = 17;          // register-staged slab elements per thread per chunk
 constexpr int SLAB_MAX = SLAB_PER_THREAD * 256;
@@ -85,10 +99,15 @@ __device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int t
     return src < p.Tin;      // zero-extension of inputs shorter than the pad (conv.py:89-93)
 }
 
-template <int BM, int BN, int WM, int WN, bool DUAL>
+// MODE 0: plain single source (already activated input, no prologue math)
+// MODE 1: single source with prologue (optional /div, GroupNorm affine, ELU)
+// MODE 2: two summed sources with prologue
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr bool DUAL = MODE == 2;
+    constexpr bool PLAIN = MODE == 0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem + 2 * p.Wbuf;
     float2* tab0 = (float2*)(Xs + p.xs_floats);
@@ -111,14 +130,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     const int tbase = n0 * p.stride - p.padL;
     const int total = p.CC * p.slabW;
     const int nu = (total + 255) >> 8;                // slab elements per thread (<= SLAB_PER_THREAD)
-    const float divv = p.div0 ? p.div0[b] : 1.f;
+    const float divv = (!PLAIN && p.div0) ? p.div0[b] : 1.f;
     const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
     const size_t rowbase = (size_t)b * p.Cin;
 
-    // per-(b, channel) GroupNorm affine of the producers, staged once
-    for (int c = tid; c < p.Cin; c += 256) {
-        tab0[c] = p.aff0 ? ((const float2*)p.aff0)[rowbase + c] : make_float2(1.f, 0.f);
-        if (DUAL) tab1[c] = p.aff1 ? ((const float2*)p.aff1)[rowbase + c] : make_float2(1.f, 0.f);
+    if (!PLAIN) {   // per-(b, channel) GroupNorm affine of the producers, staged once
+        for (int c = tid; c < p.Cin; c += 256) {
+            tab0[c] = p.aff0 ? ((const float2*)p.aff0)[rowbase + c] : make_float2(1.f, 0.f);
+            if (DUAL) tab1[c] = p.aff1 ? ((const float2*)p.aff1)[rowbase + c] : make_float2(1.f, 0.f);
+        }
     }
 
     // utterance base pointers are wave-uniform (SGPR base + 32-bit lane offset addressing)
@@ -126,15 +146,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
 
     // Register-staged slab: element e = tid + 256*u of every chunk maps to the same (local channel, tau), so
-    // its source offset (relative to the chunk's first channel) and its LDS slot are computed ONCE:
-    //   soff[u] = cl*Tin + reflect(tau)      meta[u] = lds_slot | cl << 16 | in_slab << 30 | nonzero << 31
-    unsigned soff[SLAB_PER_THREAD], meta[SLAB_PER_THREAD];
+    // its source offset (relative to the chunk's first channel), its LDS slot and whether it is literal-zero
+    // padding are computed ONCE per kernel:
+    //   soff[u] = cl*Tin + reflect(tau)      slot[u] = LDS float index | cl << 16      okmask bit u
+    unsigned soff[SLAB_PER_THREAD], slot[SLAB_PER_THREAD];
     float v0[SLAB_PER_THREAD], v1[DUAL ? SLAB_PER_THREAD : 1];
-    unsigned vmask = 0;
+    unsigned okmask = 0, inmask = 0;
 #pragma unroll
     for (int u = 0; u < SLAB_PER_THREAD; ++u) {
         const int e = tid + 256 * u;
-        soff[u] = 0u; meta[u] = 0u;
+        soff[u] = 0u; slot[u] = 0u;
         if (u < nu && e < total) {
             int cl, tau, src;
             const bool ok = slab_src(p, e, 0, tbase, cl, tau, src);
@@ -147,43 +168,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 default: q = tau / p.stride; ph = tau - q * p.stride; break;
             }
             soff[u] = ok ? (unsigned)(cl * p.Tin + src) : 0u;     // < 2^31 elements per utterance
-            meta[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | ((unsigned)cl << 16) | (1u << 30) | (ok ? 1u << 31 : 0u);
+            slot[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | (PLAIN ? 0u : ((unsigned)cl << 16));
+            inmask |= 1u << u;
+            okmask |= (ok ? 1u : 0u) << u;
         }
     }
     // All loads of a chunk are unconditional (masked elements read offset 0) and issued back to back so that
     // they stay in flight during the MFMA loop of the previous chunk.
+    unsigned vmask = 0;
     auto load_slab = [&](int c0) {
-        vmask = 0;
         const unsigned cbase = (unsigned)(c0 * p.Tin);
+        vmask = okmask;
 #pragma unroll
         for (int u = 0; u < SLAB_PER_THREAD; ++u) {
             if (u < nu) {                             // wave-uniform
-                const bool ok = (meta[u] >> 31) && (c0 + (int)((meta[u] >> 16) & 0x3fu) < p.Cin);
-                const unsigned off = ok ? soff[u] + cbase : 0u;
+                unsigned off = ((okmask >> u) & 1u) ? soff[u] + cbase : 0u;
+                if (p.cin_tail) {                     // last chunk may run past Cin (uniform flag, rare)
+                    const int cl = PLAIN ? (int)__umulhi((unsigned)(tid + 256 * u), p.magic_slabW) : (int)(slot[u] >> 16);
+                    if (c0 + cl >= p.Cin) { off = 0u; vmask &= ~(1u << u); }
+                }
                 v0[u] = s0b[off];
                 if (DUAL) v1[u] = s1b[off];
-                vmask |= (ok ? 1u : 0u) << u;
             }
         }
     };
     auto write_slab = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < SLAB_PER_THREAD; ++u) {
-            if (u < nu && ((meta[u] >> 30) & 1u)) {
-                float v = 0.f;
-                if ((vmask >> u) & 1u) {
-                    const int ci = c0 + (int)((meta[u] >> 16) & 0x3fu);
-                    v = v0[u];
-                    if (p.div0) v = v / divv;
-                    const float2 a = tab0[ci];
-                    v = fmaf(v, a.x, a.y);
-                    if (DUAL) {
-                        const float2 a1 = tab1[ci];
-                        v = v + fmaf(v1[u], a1.x, a1.y);
+            if (u < nu && ((inmask >> u) & 1u)) {
+                float v = ((vmask >> u) & 1u) ? v0[u] : 0.f;
+                if (!PLAIN) {
+                    if ((vmask >> u) & 1u) {
+                        const int ci = c0 + (int)(slot[u] >> 16);
+                        if (p.div0) v = v / divv;
+                        const float2 a = tab0[ci];
+                        v = fmaf(v, a.x, a.y);
+                        if (DUAL) {
+                            const float2 a1 = tab1[ci];
+                            v = v + fmaf(v1[u], a1.x, a1.y);
+                        }
+                        if (p.elu) v = elu_f(v, p.alpha);
                     }
-                    if (p.elu) v = elu_f(v, p.alpha);
+                    Xs[slot[u] & 0xffffu] = v;
+                } else {
+                    Xs[slot[u]] = v;
                 }
-                Xs[meta[u] & 0xffffu] = v;
             }
         }
     };
@@ -196,44 +225,51 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 
     const int a_off = hi * BM + wm * (TM * 32) + l31;
     const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
-    const int half_cc = p.CC >> 1;
     const int nks = p.Kc >> 1;
+    const int* __restrict__ koff = p.koff;        // B-operand float offset of k-step ks (same for every chunk)
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-        const float* Ws = smem + (chunk & 1) * p.Wbuf;
+        const float* Ws = smem + (chunk & 1) * p.Wbuf + a_off;
+        const float* Xb = Xs + b_off;
         const bool more = chunk + 1 < p.nchunk;
         if (more) {
             dma_weights(wt_tile + (size_t)(chunk + 1) * p.Wbuf, smem + ((chunk + 1) & 1) * p.Wbuf, p.Wbuf, tid);
             load_slab((chunk + 1) * p.CC);
         }
-        {   // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi
-            float a_cur[TM], b_cur[TN];
+        // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16
+        // LDS fragment reads are issued ahead of 16 MFMAs, B offsets come from a scalar-loaded table.
+        int ks = 0;
+        for (; ks + 4 <= nks; ks += 4) {
+            const int4 ko = *(const int4*)(koff + ks);
+            const int kos[4] = {ko.x, ko.y, ko.z, ko.w};
+            float a[4][TM], bb[4][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a_cur[i] = Ws[a_off + i * 32];
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b_cur[j] = Xs[b_off + j * 32];
-            int ph = 0, q = 0, c2 = 0;
-            for (int ks = 0; ks < nks; ++ks) {
-                if (++c2 == half_cc) { c2 = 0; if (++ph == p.stride) { ph = 0; ++q; } }
-                float a_n[TM], b_n[TN];
-                if (ks + 1 < nks) {
-                    const float* wrow = Ws + (ks + 1) * 2 * BM + a_off;
-                    const float* xrow = Xs + c2 * 2 * p.rowStride + ph * p.PL + q + b_off;
+                for (int i = 0; i < TM; ++i) a[u][i] = Ws[(ks + u) * 2 * BM + i * 32];
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a_n[i] = wrow[i * 32];
+                for (int j = 0; j < TN; ++j) bb[u][j] = Xb[kos[u] + j * 32];
+            }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) b_n[j] = xrow[j * 32];
-                }
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
+        }
+        for (; ks < nks; ++ks) {
+            const int ko = koff[ks];
+            float a[TM], bb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a_cur[i] = a_n[i];
+            for (int i = 0; i < TM; ++i) a[i] = Ws[ks * 2 * BM + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b_cur[j] = b_n[j];
-            }
+            for (int j = 0; j < TN; ++j) bb[j] = Xb[ko + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();      // every wave is done with Xs and Ws[cur]; next weights + slab registers landed
         if (more) {
@@ -308,7 +344,23 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.rowStride = a.PL * c.stride;
     a.xs_floats = (c.CC * a.rowStride + 3) & ~3;
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
+    a.koff = c.koff;
+    a.cin_tail = (c.Cin % c.CC) != 0;
     return a;
+}
+
+// B-operand LDS offset (floats) of every k-step of a chunk: k-step ks covers kidx = 2*ks + {0,1} = kk*CC + 2*c2 + {0,1}
+// -> offset = 2*c2*rowStride + (kk % stride)*PL + kk / stride.  Padded to a multiple of 4 entries.
+std::vector<int> conv_koff_table(int k, int stride, int CC, int BN) {
+    const int slabW = (BN - 1) * stride + k;
+    const int PL = ceil_div(slabW, stride), rowStride = PL * stride;
+    const int nks = k * CC / 2, half_cc = CC / 2;
+    std::vector<int> t((nks + 7) & ~3, 0);
+    for (int ks = 0; ks < nks; ++ks) {
+        const int kk = ks / half_cc, c2 = ks % half_cc;
+        t[ks] = 2 * c2 * rowStride + (kk % stride) * PL + kk / stride;
+    }
+    return t;
 }
 
 int conv_wbuf_floats(int k, int CC, int BM) { return ((k * CC * BM + 1023) / 1024) * 1024; }
@@ -328,26 +380,23 @@ size_t conv_lds_bytes(const ConvLaunch& c) {
     return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr);
 }
 
+template <int BM, int BN, int WM, int WN, int MODE>
+static hipError_t launch_conv_m(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static bool attr_done = false;
+    auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_done[2] = {false, false};
-    const bool dual = c.s1.ptr != nullptr;
-    if (dual) {
-        auto kfn = conv_mfma_kernel<BM, BN, WM, WN, true>;
-        if (!attr_done[1]) {
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done[1] = true;
-        }
-        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
-    } else {
-        auto kfn = conv_mfma_kernel<BM, BN, WM, WN, false>;
-        if (!attr_done[0]) {
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done[0] = true;
-        }
-        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
-    }
-    return hipGetLastError();
+    if (c.s1.ptr) return launch_conv_m<BM, BN, WM, WN, 2>(a, grid, lds, st);
+    if (c.s0.aff || c.s0.div || c.elu) return launch_conv_m<BM, BN, WM, WN, 1>(a, grid, lds, st);
+    return launch_conv_m<BM, BN, WM, WN, 0>(a, grid, lds, st);
 }
 
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
@@ -720,6 +769,14 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
         const int brow = nb * 16 + r16;
         const bool bvalid = brow < B;
         const float* hrow = h_prev + (size_t)(bvalid ? brow : 0) * H + (active ? wid : 0) * kslice + 4 * g;
+        // wave 0 finishes the step: fetch its x-projection and cell state now so the latency hides under the MFMAs
+        const size_t ci = (size_t)(bvalid ? brow : 0) * H + (size_t)blk * 4 + g;
+        f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+        float cprev = 0.f;
+        if (wid == 0) {
+            xp = *(const f32x4*)(xproj + ((size_t)t * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
+            cprev = c[ci];
+        }
         if (NS > 0) {
             f32x4 b4[NA];
 #pragma unroll
@@ -752,16 +809,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict_
         if (wid == 0) {
             f32x4 s = red[0][lane];
             for (int w = 1; w < KS; ++w) s = s + red[w][lane];
-            const int bb = nb * 16 + r16;
-            if (bb < B) {
-                const f32x4 xp = *(const f32x4*)(xproj + ((size_t)t * B + bb) * 4 * H + (size_t)blk * 16 + 4 * g);
-                const int unit = blk * 4 + g;
+            if (bvalid) {
                 const float gi = sigmoid_f(s[0] + xp[0]);
                 const float gf = sigmoid_f(s[1] + xp[1]);
                 const float gg = tanhf(s[2] + xp[2]);
                 const float go = sigmoid_f(s[3] + xp[3]);
-                const size_t ci = (size_t)bb * H + unit;
-                const float cn = gf * c[ci] + gi * gg;
+                const float cn = gf * cprev + gi * gg;
                 const float hn = go * tanhf(cn);
                 c[ci] = cn;
                 h_next[ci] = hn;
