@@ -277,7 +277,7 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
         const int n = cc * 2;
         if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
         if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN)) break;
-        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, L.dual) > 80 * 1024) break;
+        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, L.dual ? 2 : 1) > 80 * 1024) break;
         cc = n;
     }
     L.CC = cc;

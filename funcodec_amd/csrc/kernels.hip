@@ -52,7 +52,8 @@ struct ConvArgs {
     int Wbuf;               // floats per packed weight chunk (multiple of 1024)
     int slabW, PL, rowStride, xs_floats;
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
-    const int* koff;        // [Kc/2 (+pad)] B-operand LDS float offset per k-step
+    const int* koff;        // [koff_n] B-operand LDS float offset per k-step (padded, multiple of 4)
+    int koff_n;
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
 };
 
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem + 2 * p.Wbuf;
     float2* tab0 = (float2*)(Xs + p.xs_floats);
-    float2* tab1 = tab0 + p.Cin;
+    const int cin_pad = (p.Cin + 1) & ~1;             // keeps everything behind the tables 16-byte aligned
+    float2* tab1 = tab0 + cin_pad;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
@@ -141,6 +143,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         }
     }
 
+    {   // B-operand offset of every k-step (same for all chunks), kept in LDS behind the affine tables
+        int* kdst = (int*)(DUAL ? (float2*)(tab1 + cin_pad) : (PLAIN ? (float2*)tab0 : (float2*)tab1));
+        for (int i = tid; i < p.koff_n; i += 256) kdst[i] = p.koff[i];
+    }
     // utterance base pointers are wave-uniform (SGPR base + 32-bit lane offset addressing)
     const float* __restrict__ s0b = p.src0 + rowbase * p.Tin;
     const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     const int a_off = hi * BM + wm * (TM * 32) + l31;
     const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
     const int nks = p.Kc >> 1;
-    const int* __restrict__ koff = p.koff;        // B-operand float offset of k-step ks (same for every chunk)
+    const int4* kofs = (const int4*)(DUAL ? (float2*)(tab1 + cin_pad) : (PLAIN ? (float2*)tab0 : (float2*)tab1));
 
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         const float* Ws = smem + (chunk & 1) * p.Wbuf + a_off;
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16
         // LDS fragment reads are issued ahead of 16 MFMAs, B offsets come from a scalar-loaded table.
         int ks = 0;
+        int4 ko = kofs[0];                            // LDS broadcast read; prefetched one iteration ahead
         for (; ks + 4 <= nks; ks += 4) {
-            const int4 ko = *(const int4*)(koff + ks);
             const int kos[4] = {ko.x, ko.y, ko.z, ko.w};
             float a[4][TM], bb[4][TN];
 #pragma unroll
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bb[u][j] = Xb[kos[u] + j * 32];
             }
+            ko = kofs[(ks >> 2) + 1];                 // table is padded: always in bounds
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -258,18 +265,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
         }
-        for (; ks < nks; ++ks) {
-            const int ko = koff[ks];
-            float a[TM], bb[TN];
+        if (ks < nks) {
+            const int kos[4] = {ko.x, ko.y, ko.z, ko.w};
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Ws[ks * 2 * BM + i * 32];
+            for (int u = 0; u < 3; ++u) {
+                if (ks + u < nks) {
+                    float a[TM], bb[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bb[j] = Xb[ko + j * 32];
+                    for (int i = 0; i < TM; ++i) a[i] = Ws[(ks + u) * 2 * BM + i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int j = 0; j < TN; ++j) bb[j] = Xb[kos[u] + j * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+                }
+            }
         }
         __syncthreads();      // every wave is done with Xs and Ws[cur]; next weights + slab registers landed
         if (more) {
@@ -345,6 +357,7 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.xs_floats = (c.CC * a.rowStride + 3) & ~3;
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.koff = c.koff;
+    a.koff_n = (int)(((c.k * c.CC / 2) + 7) & ~3) + 4;
     a.cin_tail = (c.Cin % c.CC) != 0;
     return a;
 }
@@ -355,7 +368,7 @@ std::vector<int> conv_koff_table(int k, int stride, int CC, int BN) {
     const int slabW = (BN - 1) * stride + k;
     const int PL = ceil_div(slabW, stride), rowStride = PL * stride;
     const int nks = k * CC / 2, half_cc = CC / 2;
-    std::vector<int> t((nks + 7) & ~3, 0);
+    std::vector<int> t(((nks + 7) & ~3) + 4, 0);
     for (int ks = 0; ks < nks; ++ks) {
         const int kk = ks / half_cc, c2 = ks % half_cc;
         t[ks] = 2 * c2 * rowStride + (kk % stride) * PL + kk / stride;
@@ -367,17 +380,19 @@ int conv_wbuf_floats(int k, int CC, int BM) { return ((k * CC * BM + 1023) / 102
 
 int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM); }
 
-size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, bool dual) {
+size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab) {
     const int slabW = (BN - 1) * stride + k;
     const int rowStride = ceil_div(slabW, stride) * stride;
     const int xs = (CC * rowStride + 3) & ~3;
-    return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + xs) * sizeof(float) + (size_t)Cin * 8 * (dual ? 2 : 1);
+    const size_t koff_bytes = (size_t)((((k * CC / 2) + 7) & ~3) + 4) * sizeof(int);
+    return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes;
 }
 
 bool conv_slab_fits(int k, int stride, int CC, int BN) { return CC * ((BN - 1) * stride + k) <= SLAB_MAX; }
 
 size_t conv_lds_bytes(const ConvLaunch& c) {
-    return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr);
+    const int ntab = c.s1.ptr ? 2 : ((c.s0.aff || c.s0.div || c.elu) ? 1 : 0);
+    return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, ntab);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
