@@ -6,6 +6,8 @@
 // traded.  Wavefront = 64 lanes throughout.
 #include "kernels.h"
 
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace fc {
@@ -55,6 +57,9 @@ struct ConvArgs {
     const int* koff;        // [koff_n] B-operand LDS float offset per k-step (padded, multiple of 4)
     int koff_n;
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
+    int skew, skew_div;     // phase skew between co-resident workgroups (units of 64*64 cycles), see kernel
+    int ablate;             // profiling aid (FC_ABLATE env): 1 no MFMA, 2 no stores, 4 no slab loads, 8 no slab transform,
+                            // 16 no weight DMA.  0 in production.
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -72,12 +77,13 @@ __device__ __forceinline__ float exp_neg(float x) {
 }
 __device__ __forceinline__ float elu_f(float v, float alpha) { return v > 0.f ? v : alpha * (exp_neg(v) - 1.f); }
 
-constexpr int SLAB_PER_THREAD = 17;          // register-staged slab elements per thread per chunk
+constexpr int SLAB_PER_THREAD = 16;          // register-staged slab elements per thread per chunk (NU = 8 or 16)
 constexpr int SLAB_MAX = SLAB_PER_THREAD * 256;
 
 // Direct global -> LDS copy of one packed weight chunk (contiguous, multiple of 4 KiB): each wave
 // instruction moves 1 KiB (64 lanes x 16 B) with no VGPR round trip.
-__device__ __forceinline__ void dma_weights(const float* __restrict__ gsrc, float* lds_dst, int nfloats, int tid) {
+__device__ __forceinline__ void dma_weights(const float* __restrict__ gsrc, float* lds_dst, int nfloats, int tid, int ablate = 0) {
+    if (ablate & 16) return;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int off = 0; off < nfloats; off += 1024) {
         const float* g = gsrc + off + tid * 4;
@@ -101,70 +107,70 @@ __device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int t
 }
 
 // MODE 0: plain single source (already activated input, no prologue math)
-// MODE 1: single source with prologue (optional /div, GroupNorm affine, ELU)
-// MODE 2: two summed sources with prologue
-template <int BM, int BN, int WM, int WN, int MODE>
+// MODE 1/2: single source with GroupNorm affine (optional /div), without / with ELU
+// MODE 3/4: two summed sources with GroupNorm affines, without / with ELU
+// NU: slab elements staged per thread per chunk (compile time: every staging phase is one straight-line block)
+//
+// Each workgroup owns one (utterance b, M tile mt) and a CONTIGUOUS RANGE of N tiles; the load pipeline
+// (weight DMA + register-prefetched slab) runs across chunk AND tile boundaries, so per-workgroup fixed costs
+// (affine tables, slab descriptors, first-load latency) are paid once per range instead of once per tile.
+template <int BM, int BN, int WM, int WN, int MODE, int NU>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr bool DUAL = MODE == 2;
-    constexpr bool PLAIN = MODE == 0;
+    constexpr bool PLAIN = MODE == 0;                 // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU
+    constexpr bool DUAL = MODE >= 3;
+    constexpr bool ELU = MODE == 2 || MODE == 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem + 2 * p.Wbuf;
-    float2* tab0 = (float2*)(Xs + p.xs_floats);
     const int cin_pad = (p.Cin + 1) & ~1;             // keeps everything behind the tables 16-byte aligned
-    float2* tab1 = tab0 + cin_pad;
+    float2* tab0 = (float2*)(Xs + p.xs_floats);
+    float2* tab1 = tab0 + (PLAIN ? 0 : cin_pad);
+    int* kofs_i = (int*)(tab1 + (DUAL ? cin_pad : 0));
+    float* bias_s = (float*)(kofs_i + p.koff_n);
+    double* red = (double*)(bias_s + BM);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int b = blockIdx.z, mt = blockIdx.y, nt = blockIdx.x;
-    const int n0 = nt * BN, m0 = mt * BM;
+    const int b = blockIdx.z, mt = blockIdx.y;
+    const int m0 = mt * BM;
     const int hi = lane >> 5, l31 = lane & 31;
+    const int ntiles = (p.Tout + BN - 1) / BN;
+    const int t_begin = (int)(((long long)ntiles * blockIdx.x) / gridDim.x);
+    const int t_end = (int)(((long long)ntiles * (blockIdx.x + 1)) / gridDim.x);
+    if (t_begin >= t_end) return;
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int tbase = n0 * p.stride - p.padL;
-    const int total = p.CC * p.slabW;
-    const int nu = (total + 255) >> 8;                // slab elements per thread (<= SLAB_PER_THREAD)
+    const int total = p.CC * p.slabW;                 // <= 256 * NU
     const float divv = (!PLAIN && p.div0) ? p.div0[b] : 1.f;
     const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
     const size_t rowbase = (size_t)b * p.Cin;
 
-    if (!PLAIN) {   // per-(b, channel) GroupNorm affine of the producers, staged once
+    if (!PLAIN) {   // per-(b, channel) GroupNorm affine of the producers, staged once per workgroup
         for (int c = tid; c < p.Cin; c += 256) {
             tab0[c] = p.aff0 ? ((const float2*)p.aff0)[rowbase + c] : make_float2(1.f, 0.f);
             if (DUAL) tab1[c] = p.aff1 ? ((const float2*)p.aff1)[rowbase + c] : make_float2(1.f, 0.f);
         }
     }
+    for (int i = tid; i < p.koff_n; i += 256) kofs_i[i] = p.koff[i];
+    for (int i = tid; i < BM; i += 256) bias_s[i] = p.bias[m0 + i];
+    const int4* kofs = (const int4*)kofs_i;
 
-    {   // B-operand offset of every k-step (same for all chunks), kept in LDS behind the affine tables
-        int* kdst = (int*)(DUAL ? (float2*)(tab1 + cin_pad) : (PLAIN ? (float2*)tab0 : (float2*)tab1));
-        for (int i = tid; i < p.koff_n; i += 256) kdst[i] = p.koff[i];
-    }
     // utterance base pointers are wave-uniform (SGPR base + 32-bit lane offset addressing)
     const float* __restrict__ s0b = p.src0 + rowbase * p.Tin;
     const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
 
-    // Register-staged slab: element e = tid + 256*u of every chunk maps to the same (local channel, tau), so
-    // its source offset (relative to the chunk's first channel), its LDS slot and whether it is literal-zero
-    // padding are computed ONCE per kernel:
-    //   soff[u] = cl*Tin + reflect(tau)      slot[u] = LDS float index | cl << 16      okmask bit u
-    unsigned soff[SLAB_PER_THREAD], slot[SLAB_PER_THREAD];
-    float v0[SLAB_PER_THREAD], v1[DUAL ? SLAB_PER_THREAD : 1];
-    unsigned okmask = 0, inmask = 0;
+    // Register-staged slab.  Element e = tid + 256*u of every chunk of every tile maps to the same (local channel
+    // cl, slab column tau); computed once:  base0[u] = cl*Tin + tau,  slot[u] = LDS float index | cl << 16.
+    unsigned base0[NU], slot[NU];
+    float v0[NU], v1[DUAL ? NU : 1];
+    unsigned inmask = 0;
 #pragma unroll
-    for (int u = 0; u < SLAB_PER_THREAD; ++u) {
+    for (int u = 0; u < NU; ++u) {
         const int e = tid + 256 * u;
-        soff[u] = 0u; slot[u] = 0u;
-        if (u < nu && e < total) {
-            int cl, tau, src;
-            const bool ok = slab_src(p, e, 0, tbase, cl, tau, src);
+        base0[u] = 0u; slot[u] = (unsigned)p.xs_floats - 1u;   // dummy LDS slot (never read by the MFMA loop)
+        if (e < total) {
+            const int cl = (int)__umulhi((unsigned)e, p.magic_slabW);
+            const int tau = e - cl * p.slabW;
             int ph, q;
             switch (p.stride) {
                 case 1: ph = 0; q = tau; break;
@@ -173,79 +179,198 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 case 8: q = tau >> 3; ph = tau & 7; break;
                 default: q = tau / p.stride; ph = tau - q * p.stride; break;
             }
-            soff[u] = ok ? (unsigned)(cl * p.Tin + src) : 0u;     // < 2^31 elements per utterance
-            slot[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | (PLAIN ? 0u : ((unsigned)cl << 16));
+            base0[u] = (unsigned)(cl * p.Tin + tau);
+            slot[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | ((unsigned)cl << 16);
             inmask |= 1u << u;
-            okmask |= (ok ? 1u : 0u) << u;
         }
     }
-    // All loads of a chunk are unconditional (masked elements read offset 0) and issued back to back so that
-    // they stay in flight during the MFMA loop of the previous chunk.
+    // All loads of a chunk are unconditional (masked elements read offset 0) and issued back to back so that they
+    // stay in flight during the MFMA loop of the previous chunk.  Interior tiles (no padding, no channel tail)
+    // take the fast path: one uniform add per element.
     unsigned vmask = 0;
-    auto load_slab = [&](int c0) {
-        const unsigned cbase = (unsigned)(c0 * p.Tin);
-        vmask = okmask;
+    auto load_slab = [&](int tile, int c0) {
+        const int tbase = tile * BN * p.stride - p.padL;
+        vmask = inmask;
+        if (p.ablate & 4) return;
+        const bool interior = tbase >= 0 && tbase + p.slabW <= p.Tin && c0 + p.CC <= p.Cin;
+        if (interior) {
+            const unsigned ubase = (unsigned)(c0 * p.Tin + tbase);
 #pragma unroll
-        for (int u = 0; u < SLAB_PER_THREAD; ++u) {
-            if (u < nu) {                             // wave-uniform
-                unsigned off = ((okmask >> u) & 1u) ? soff[u] + cbase : 0u;
-                if (p.cin_tail) {                     // last chunk may run past Cin (uniform flag, rare)
-                    const int cl = PLAIN ? (int)__umulhi((unsigned)(tid + 256 * u), p.magic_slabW) : (int)(slot[u] >> 16);
-                    if (c0 + cl >= p.Cin) { off = 0u; vmask &= ~(1u << u); }
-                }
+            for (int u = 0; u < NU; ++u) {
+                const unsigned off = ((inmask >> u) & 1u) ? base0[u] + ubase : 0u;
                 v0[u] = s0b[off];
                 if (DUAL) v1[u] = s1b[off];
             }
-        }
-    };
-    auto write_slab = [&](int c0) {
+        } else {
+            const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
 #pragma unroll
-        for (int u = 0; u < SLAB_PER_THREAD; ++u) {
-            if (u < nu && ((inmask >> u) & 1u)) {
-                float v = ((vmask >> u) & 1u) ? v0[u] : 0.f;
-                if (!PLAIN) {
-                    if ((vmask >> u) & 1u) {
-                        const int ci = c0 + (int)(slot[u] >> 16);
-                        if (p.div0) v = v / divv;
-                        const float2 a = tab0[ci];
-                        v = fmaf(v, a.x, a.y);
-                        if (DUAL) {
-                            const float2 a1 = tab1[ci];
-                            v = v + fmaf(v1[u], a1.x, a1.y);
-                        }
-                        if (p.elu) v = elu_f(v, p.alpha);
-                    }
-                    Xs[slot[u] & 0xffffu] = v;
-                } else {
-                    Xs[slot[u]] = v;
-                }
+            for (int u = 0; u < NU; ++u) {
+                unsigned sl = slot[u];
+                asm volatile("" : "+v"(sl));            // keep the edge-tile index math out of the persistent registers
+                const int cl = (int)(sl >> 16);
+                const int tau = (tid + 256 * u) - cl * p.slabW;
+                const int g = tbase + tau;
+                bool ok = ((inmask >> u) & 1u) && c0 + cl < p.Cin && g >= -p.padL && g < hi_lim;
+                int src = g < 0 ? -g : g;
+                src = src >= p.Leff ? refl - src : src;
+                if (p.pad_zero) { src = g; ok = ok && g >= 0; }
+                ok = ok && src < p.Tin;              // zero padding / zero-extension of short inputs (conv.py:89-93)
+                const unsigned off = ok ? (unsigned)((c0 + cl) * p.Tin + src) : 0u;
+                v0[u] = s0b[off];
+                if (DUAL) v1[u] = s1b[off];
+                vmask &= ~((ok ? 0u : 1u) << u);
             }
         }
     };
+    // Branch-free per element: lanes without an element write a dummy slot, padding lanes select 0.
+    auto write_slab_t = [&](int c0, auto use_div) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float v = v0[u];
+            if (!PLAIN) {
+                const int ci = c0 + (int)(slot[u] >> 16);            // a missing element has cl = 0
+                if (decltype(use_div)::value) v = v / divv;
+                const float2 a = tab0[ci];
+                v = fmaf(v, a.x, a.y);
+                if (DUAL) {
+                    const float2 a1 = tab1[ci];
+                    v = v + fmaf(v1[u], a1.x, a1.y);
+                }
+                if (ELU) v = elu_f(v, p.alpha);
+            }
+            v = ((vmask >> u) & 1u) ? v : 0.f;
+            Xs[slot[u] & 0xffffu] = v;
+        }
+    };
+    auto write_slab = [&](int c0) {
+        if (p.ablate & 64) return;
+        if (MODE == 1 && p.div0) write_slab_t(c0, std::true_type());
+        else write_slab_t(c0, std::false_type());
+    };
 
-    dma_weights(wt_tile, smem, p.Wbuf, tid);
-    load_slab(0);
-    __syncthreads();          // affine tables visible; weight chunk 0 landed (the barrier drains vmcnt)
+    f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+
+    // ---- epilogue of one tile: bias, store, GroupNorm partial statistics ---------------------------
+    auto epilogue = [&](int tile) {
+        const int n0 = tile * BN;
+        // opaque copies: keep the row-pointer arithmetic INSIDE the tile loop (hoisting it costs ~64 VGPRs)
+        int m0_l = m0, b_l = b;
+        asm volatile("" : "+s"(m0_l), "+s"(b_l));
+        float s1 = 0.f, s2 = 0.f;
+        const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2);
+        if (full) {
+            // interior tile, unit time stride: no bounds checks, one row pointer per accumulator row
+            float* __restrict__ base = p.out + (size_t)b_l * p.out_sB + (size_t)(n0 + wn * (TN * 32) + l31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float bias = bias_s[ml];
+                    float* __restrict__ rowp = base + (size_t)(m0_l + ml) * p.out_sM;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float v = acc[i][j][r] + bias;
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                        rowp[j * 32] = v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int m = m0_l + ml;
+                if (m >= p.M) continue;
+                const float bias = bias_s[ml];
+                int co = m, phs = 0;
+                if (p.up_r) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }
+                float* __restrict__ rowp = p.out + (size_t)b_l * p.out_sB + (size_t)co * p.out_sM;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                    if (n >= p.Tout) continue;
+                    const float v = acc[i][j][r] + bias;
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
+                    if (p.ablate & 2) continue;
+                    if (p.up_r) {
+                        const int t = n * p.up_r + phs - p.trimL;
+                        if (t >= 0 && t < p.Tfinal) rowp[t] = v;
+                    } else {
+                        rowp[(size_t)n * p.out_sT] = v;
+                    }
+                }
+            }
+        }
+        }
+        if (p.partials && !(p.ablate & 32)) {
+            double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                d1 += __shfl_xor(d1, o, 64);
+                d2 += __shfl_xor(d2, o, 64);
+            }
+            if (lane == 0) { red[wid] = d1; red[4 + wid] = d2; }
+            __syncthreads();
+            if (tid == 0) {
+                const int nblk = ntiles * gridDim.y;
+                const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
+                p.partials[slot_p] = ((red[0] + red[1]) + red[2]) + red[3];
+                p.partials[slot_p + 1] = ((red[4] + red[5]) + red[6]) + red[7];
+            }
+            // red is rewritten only after the next tile's barriers
+        }
+    };
+
+    // ---- pipeline over (tile, chunk) ---------------------------------------------------------------
+    const bool resident = p.nchunk <= 2;              // the whole K extent of this M tile stays in LDS
+    dma_weights(wt_tile, smem, p.Wbuf, tid, p.ablate);
+    if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, tid, p.ablate);
+    load_slab(t_begin, 0);
+    __syncthreads();          // tables visible; weights landed (the barrier drains vmcnt)
     write_slab(0);
     __syncthreads();
 
     const int a_off = hi * BM + wm * (TM * 32) + l31;
     const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
     const int nks = p.Kc >> 1;
-    const int4* kofs = (const int4*)(DUAL ? (float2*)(tab1 + cin_pad) : (PLAIN ? (float2*)tab0 : (float2*)tab1));
+    const float* Xb = Xs + b_off;
 
-    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
-        const float* Ws = smem + (chunk & 1) * p.Wbuf + a_off;
-        const float* Xb = Xs + b_off;
-        const bool more = chunk + 1 < p.nchunk;
+    // Two workgroups share a CU; started together they run their load / MFMA / store phases in lock step and
+    // contend instead of overlapping.  Skew the second resident set by about half a chunk period.
+    if (p.skew) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if ((lin / p.skew_div) & 1u)
+            for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(64);
+    }
+    int tile = t_begin, chunk = 0, step = 0;
+    for (;;) {
+        int ntile = tile, nchunk_i = chunk + 1;
+        if (nchunk_i == p.nchunk) { nchunk_i = 0; ntile = tile + 1; }
+        const bool more = ntile < t_end;
         if (more) {
-            dma_weights(wt_tile + (size_t)(chunk + 1) * p.Wbuf, smem + ((chunk + 1) & 1) * p.Wbuf, p.Wbuf, tid);
-            load_slab((chunk + 1) * p.CC);
+            if (!resident)
+                dma_weights(wt_tile + (size_t)nchunk_i * p.Wbuf, smem + ((step + 1) & 1) * p.Wbuf, p.Wbuf, tid, p.ablate);
+            load_slab(ntile, nchunk_i * p.CC);
         }
-        // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16
-        // LDS fragment reads are issued ahead of 16 MFMAs, B offsets come from a scalar-loaded table.
-        int ks = 0;
-        int4 ko = kofs[0];                            // LDS broadcast read; prefetched one iteration ahead
+        const float* Ws = smem + (resident ? chunk : (step & 1)) * p.Wbuf + a_off;
+        // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16 LDS
+        // fragment reads are issued ahead of 16 MFMAs; B offsets come from the LDS table, prefetched one ahead.
+        int ks = (p.ablate & 1) ? nks : 0;
+        int4 ko = kofs[0];
         for (; ks + 4 <= nks; ks += 4) {
             const int kos[4] = {ko.x, ko.y, ko.z, ko.w};
             float a[4][TM], bb[4][TN];
@@ -283,56 +408,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
                 }
             }
         }
-        __syncthreads();      // every wave is done with Xs and Ws[cur]; next weights + slab registers landed
-        if (more) {
-            write_slab((chunk + 1) * p.CC);
-            __syncthreads();
+        __syncthreads();      // every wave is done with Xs and this weight buffer; next weights + slab registers landed
+        if (chunk == p.nchunk - 1) {
+            if (!(p.ablate & 128)) epilogue(tile);
+            zero_acc();
         }
-    }
-
-    // ---- epilogue: bias, store, GroupNorm partial statistics --------------------------------------
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (m >= p.M) continue;
-            const float bias = p.bias[m];
-            int co = m, phs = 0;
-            if (p.up_r) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-                if (n >= p.Tout) continue;
-                const float v = acc[i][j][r] + bias;
-                s1 += v;
-                s2 = fmaf(v, v, s2);
-                if (p.up_r) {
-                    const int t = n * p.up_r + phs - p.trimL;
-                    if (t >= 0 && t < p.Tfinal) p.out[(size_t)b * p.out_sB + (size_t)co * p.out_sM + t] = v;
-                } else {
-                    p.out[(size_t)b * p.out_sB + (size_t)m * p.out_sM + (size_t)n * p.out_sT] = v;
-                }
-            }
-        }
-    }
-    if (p.partials) {
-        double* red = (double*)smem;     // all waves are past the last barrier: the weight buffers are free
-        double d1 = (double)s1, d2 = (double)s2;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            d1 += __shfl_xor(d1, o, 64);
-            d2 += __shfl_xor(d2, o, 64);
-        }
-        if (lane == 0) { red[wid] = d1; red[4 + wid] = d2; }
+        if (!more) break;
+        write_slab(nchunk_i * p.CC);
         __syncthreads();
-        if (tid == 0) {
-            const int nblk = gridDim.x * gridDim.y;
-            const size_t slot = ((size_t)b * nblk + (size_t)mt * gridDim.x + nt) * 2;
-            p.partials[slot] = ((red[0] + red[1]) + red[2]) + red[3];
-            p.partials[slot + 1] = ((red[4] + red[5]) + red[6]) + red[7];
-        }
+        tile = ntile; chunk = nchunk_i; ++step;
     }
 }
 
@@ -354,11 +438,16 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.slabW = (c.BN - 1) * c.stride + c.k;
     a.PL = ceil_div(a.slabW, c.stride);
     a.rowStride = a.PL * c.stride;
-    a.xs_floats = (c.CC * a.rowStride + 3) & ~3;
+    a.xs_floats = ((c.CC * a.rowStride + 3) & ~3) + 4;   // + a dummy slot for lanes without a slab element
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.koff = c.koff;
     a.koff_n = (int)(((c.k * c.CC / 2) + 7) & ~3) + 4;
     a.cin_tail = (c.Cin % c.CC) != 0;
+    static const int ablate = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
+    static const int skew = getenv("FC_SKEW") ? atoi(getenv("FC_SKEW")) : 0;
+    static const int skew_div = getenv("FC_SKEW_DIV") ? atoi(getenv("FC_SKEW_DIV")) : 256;
+    a.skew = skew; a.skew_div = skew_div;
+    a.ablate = ablate;
     return a;
 }
 
@@ -383,9 +472,10 @@ int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.
 size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab) {
     const int slabW = (BN - 1) * stride + k;
     const int rowStride = ceil_div(slabW, stride) * stride;
-    const int xs = (CC * rowStride + 3) & ~3;
+    const int xs = ((CC * rowStride + 3) & ~3) + 4;
     const size_t koff_bytes = (size_t)((((k * CC / 2) + 7) & ~3) + 4) * sizeof(int);
-    return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes;
+    return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
+           (size_t)BM * sizeof(float) + 64;
 }
 
 bool conv_slab_fits(int k, int stride, int CC, int BN) { return CC * ((BN - 1) * stride + k) <= SLAB_MAX; }
@@ -395,10 +485,10 @@ size_t conv_lds_bytes(const ConvLaunch& c) {
     return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, ntab);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
-static hipError_t launch_conv_m(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int MODE, int NU>
+static hipError_t launch_conv_k(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
-    auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE>;
+    auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE, NU>;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
@@ -407,18 +497,33 @@ static hipError_t launch_conv_m(const ConvArgs& a, dim3 grid, size_t lds, hipStr
     return hipGetLastError();
 }
 
+template <int BM, int BN, int WM, int WN, int MODE>
+static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t lds, hipStream_t st) {
+    if (total <= 256 * 8) return launch_conv_k<BM, BN, WM, WN, MODE, 8>(a, grid, lds, st);
+    return launch_conv_k<BM, BN, WM, WN, MODE, 16>(a, grid, lds, st);
+}
+
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    if (c.s1.ptr) return launch_conv_m<BM, BN, WM, WN, 2>(a, grid, lds, st);
-    if (c.s0.aff || c.s0.div || c.elu) return launch_conv_m<BM, BN, WM, WN, 1>(a, grid, lds, st);
-    return launch_conv_m<BM, BN, WM, WN, 0>(a, grid, lds, st);
+    const int total = a.CC * a.slabW;
+    if (c.s1.ptr) return c.elu ? launch_conv_m<BM, BN, WM, WN, 4>(a, total, grid, lds, st)
+                               : launch_conv_m<BM, BN, WM, WN, 3>(a, total, grid, lds, st);
+    if (c.s0.aff || c.s0.div || c.elu) return c.elu ? launch_conv_m<BM, BN, WM, WN, 2>(a, total, grid, lds, st)
+                                                    : launch_conv_m<BM, BN, WM, WN, 1>(a, total, grid, lds, st);
+    return launch_conv_m<BM, BN, WM, WN, 0>(a, total, grid, lds, st);
 }
 
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
     if (!conv_slab_fits(c.k, c.stride, c.CC, c.BN) || lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
-    dim3 grid(ceil_div(c.Tout, c.BN), ceil_div(c.M, c.BM), c.B);
+    // one resident wave of workgroups (2 per CU): each takes a contiguous range of N tiles
+    const int ntiles = ceil_div(c.Tout, c.BN), mtiles = ceil_div(c.M, c.BM);
+    static const int target_wgs = getenv("FC_TARGET_WGS") ? atoi(getenv("FC_TARGET_WGS")) : 512;
+    int G = target_wgs / (mtiles * c.B);
+    if (G < 1) G = 1;
+    if (G > ntiles) G = ntiles;
+    dim3 grid(G, mtiles, c.B);
     if (c.BM == 128 && c.BN == 128) return launch_conv_t<128, 128, 2, 2>(c, a, grid, lds, st);
     if (c.BM == 64 && c.BN == 256) return launch_conv_t<64, 256, 1, 4>(c, a, grid, lds, st);
     if (c.BM == 32 && c.BN == 256) return launch_conv_t<32, 256, 1, 4>(c, a, grid, lds, st);

@@ -59,6 +59,7 @@ class CodecEngine:
         self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
         self._h = h
         self._ws: Optional[torch.Tensor] = None
+        self._ws_need: Dict[tuple, int] = {}
         self._finalized = False
 
     # -- plumbing ------------------------------------------------------------------------------
@@ -127,7 +128,10 @@ class CodecEngine:
         return self.lib.fc_engine_frames(self._h, n_samples)
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
-        need = int(self.lib.fc_engine_workspace_bytes(self._h, B, T))
+        key = (B, T)
+        need = self._ws_need.get(key)
+        if need is None:
+            need = self._ws_need[key] = int(self.lib.fc_engine_workspace_bytes(self._h, B, T))
         if self._ws is None or self._ws.numel() < need:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
