@@ -54,6 +54,8 @@ struct ConvLayer {
 struct LstmLayer {
     ConvLayer inproj;       // W_ih as a k=1 GEMM with permuted rows, bias = b_ih + b_hh
     float* whh = nullptr;   // [4H][H] rows permuted to (blk, unit, gate)
+    float* wcat = nullptr;  // layers >= 1: [4H][2H] = [W_ih | W_hh], same row permutation (wavefront kernel)
+    float* bperm = nullptr; // layers >= 1: permuted b_ih + b_hh
 };
 
 struct LstmBlock {
@@ -66,6 +68,7 @@ struct Act {               // raw tensor [B][C][T] + pending GroupNorm affine (n
     float* raw = nullptr;
     float* aff = nullptr;
     int C = 0, T = 0;
+    bool normed = false;   // has a pending affine (valid in dry-run planning too, where pointers are null)
 };
 
 struct Ctx {
@@ -111,6 +114,7 @@ struct fc_engine {
     std::map<std::string, LstmBlock*> lstm_by_prefix;
     // quantiser
     float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
+    float* zeros = nullptr;                  // 64 zero floats
     std::vector<void*> dev_allocs;
     // optional event timing
     bool profiling = false;
@@ -276,8 +280,8 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     for (;;) {
         const int n = cc * 2;
         if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
-        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN)) break;
-        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, L.dual ? 2 : 1) > 80 * 1024) break;
+        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN, L.BM)) break;
+        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, L.dual ? 2 : 1) > (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) break;
         cc = n;
     }
     L.CC = cc;
@@ -370,6 +374,15 @@ int pack_lstm(fc_engine* e, LstmBlock& lb) {
         LstmLayer& L = lb.layers[l];
         if (pack_gemm(e, L.inproj, wih_p, b_p)) return 1;
         if (upload(e, whh_p, &L.whh)) return 1;
+        if (l >= 1) {
+            std::vector<float> cat((size_t)4 * H * 2 * H);
+            for (int mp = 0; mp < 4 * H; ++mp) {
+                memcpy(&cat[(size_t)mp * 2 * H], &wih_p[(size_t)mp * H], H * sizeof(float));
+                memcpy(&cat[(size_t)mp * 2 * H + H], &whh_p[(size_t)mp * H], H * sizeof(float));
+            }
+            if (upload(e, cat, &L.wcat)) return 1;
+            if (upload(e, b_p, &L.bperm)) return 1;
+        }
     }
     return 0;
 }
@@ -403,7 +416,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     const ConvGeom g = conv_geom(L, Tin);
     // Layers with several M tiles would re-apply the fused prologue (GroupNorm affine, residual add, ELU) once per
     // M tile; for those (deep, short tensors) it is cheaper to materialise the activated input once and stream it.
-    const bool has_prologue = s0.aff || s0.div || s1.used || elu;
+    const bool has_prologue = (s0.used & 2) || s1.used || elu;
     if (L.Mpad / L.BM >= 3 && has_prologue) {
         float* tmp = cx.alloc<float>((size_t)cx.B * L.cin * Tin);
         cx.launches++;
@@ -418,7 +431,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     }
     fc::ConvLaunch c;
     c.s0 = s0; c.s1 = s1; c.elu = elu; c.alpha = e->arch.elu_alpha;
-    c.wt = L.wt; c.bias = L.bias; c.koff = L.koff;
+    c.wt = L.wt; c.bias = L.bias; c.koff = L.koff; c.zeros = e->zeros;
     c.B = cx.B; c.Cin = L.cin; c.Tin = Tin; c.M = L.M;
     c.k = L.gk; c.stride = L.gstride; c.padL = g.padL; c.padR = g.padR;
     c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk;
@@ -442,6 +455,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     if (L.has_norm) {
         c.partials = cx.alloc<double>((size_t)cx.B * nblk * 2);
         out.aff = cx.alloc<float>((size_t)cx.B * L.cout * 2);
+        out.normed = true;
     }
     // accounting (algorithmic: real channel counts, every operand touched once)
     cx.conv_flops += 2.0 * cx.B * (double)L.M * L.cin * L.gk * c.Tout;
@@ -465,34 +479,33 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     return out;
 }
 
-inline fc::Src src_of(const Act& a) { fc::Src s; s.ptr = a.raw; s.aff = a.aff; s.used = 1; return s; }
+// Src.used: bit 0 = present, bit 1 = carries an affine / divisor (planning flags, valid when pointers are null)
+inline fc::Src src_of(const Act& a) { fc::Src s; s.ptr = a.raw; s.aff = a.aff; s.used = a.normed ? 3 : 1; return s; }
 
-// SLSTM.forward (lstm.py:22-28) without the skip; returns plain y [B][H][T]
+// SLSTM.forward (lstm.py:22-28) without the skip; returns plain y [B][H][T].
+// Layer wavefront: one launch per "diagonal" s advances every layer l by its timestep s - l.
 Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
-    const int H = lb.H, B = cx.B;
-    Act cur = in;
-    for (size_t l = 0; l < lb.layers.size(); ++l) {
-        const LstmLayer& L = lb.layers[l];
-        float* xproj = cx.alloc<float>((size_t)T * B * 4 * H);
-        run_conv(e, cx, L.inproj, src_of(cur), fc::Src(), 0, T, xproj, (long long)4 * H, 1, (long long)B * 4 * H);
-        float* state = cx.alloc<float>((size_t)3 * B * H);   // h ping, h pong, c
-        Act y;
-        y.C = H; y.T = T;
-        y.raw = cx.alloc<float>((size_t)B * H * T);
-        cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H;
-        cx.launches += T + 1;
-        if (!cx.dry && !cx.err) {
-            ProfSpan sp(e, cx, PC_LSTM, 2.0 * B * (double)T * 4 * H * H, 4.0 * T * 4.0 * H * H);
-            hipError_t er = hipMemsetAsync(state, 0, (size_t)3 * B * H * sizeof(float), cx.st);
-            float *h0 = state, *h1 = state + (size_t)B * H, *c = state + (size_t)2 * B * H;
-            for (int t = 0; t < T && er == hipSuccess; ++t) {
-                er = fc::launch_lstm_step(L.whh, xproj, (t & 1) ? h1 : h0, (t & 1) ? h0 : h1, c, y.raw, B, H, T, t, cx.st);
-            }
-            if (er != hipSuccess) { cx.err = 1; g_err = std::string("lstm step failed: ") + hipGetErrorString(er); }
-        }
-        cur = y;
+    const int H = lb.H, B = cx.B, L = (int)lb.layers.size();
+    float* xproj = cx.alloc<float>((size_t)T * B * 4 * H);
+    run_conv(e, cx, lb.layers[0].inproj, src_of(in), fc::Src(), 0, T, xproj, (long long)4 * H, 1, (long long)B * 4 * H);
+    float* state = cx.alloc<float>((size_t)3 * L * B * H);   // h [L][2][B][H], c [L][B][H]
+    Act y;
+    y.C = H; y.T = T;
+    y.raw = cx.alloc<float>((size_t)B * H * T);
+    cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H * (2 * L - 1);
+    cx.launches += T + L;
+    if (!cx.dry && !cx.err) {
+        ProfSpan sp(e, cx, PC_LSTM, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
+        hipError_t er = hipMemsetAsync(state, 0, (size_t)3 * L * B * H * sizeof(float), cx.st);
+        const float* w[FC_LSTM_MAX_LAYERS] = {nullptr};
+        const float* bias[FC_LSTM_MAX_LAYERS] = {nullptr};
+        for (int l = 0; l < L; ++l) { w[l] = l == 0 ? lb.layers[0].whh : lb.layers[l].wcat; bias[l] = lb.layers[l].bperm; }
+        float *h = state, *c = state + (size_t)2 * L * B * H;
+        for (int s = 0; s < T + L - 1 && er == hipSuccess; ++s)
+            er = fc::launch_lstm_wave(w, bias, xproj, h, c, y.raw, B, H, T, L, s, cx.st);
+        if (er != hipSuccess) { cx.err = 1; g_err = std::string("lstm step failed: ") + hipGetErrorString(er); }
     }
-    return cur;
+    return y;
 }
 
 // SEANetResnetBlock (seanet_encoder.py:16-61): returns the two raw branches whose GroupNorm'd sum is the output
@@ -504,7 +517,7 @@ void run_resblock(fc_engine* e, Ctx& cx, const fc_engine::Stage& S, const Act& x
 
 // SEANetEncoder.forward: wav [B][T] (optionally divided by scale[b]) -> last conv (raw + affine), T -> Tf
 Act run_encoder(fc_engine* e, Ctx& cx, const float* wav, int T, const float* scale) {
-    fc::Src s; s.ptr = wav; s.div = scale; s.used = 1;
+    fc::Src s; s.ptr = wav; s.div = scale; s.used = e->arch.audio_normalize ? 3 : 1;
     Act x = run_conv(e, cx, e->enc_first, s, fc::Src(), 0, T);
     for (auto& S : e->enc_stages) {
         Act sc, b3;
@@ -624,6 +637,7 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (!(D == 16 || D == 32 || D == 64 || D == 128 || D == 256)) return fail("dimension must be one of 16/32/64/128/256");
     if (arch->codebook_size % 64) return fail("codebook_size must be a multiple of 64");
     if (arch->lstm_layers > 0 && ((arch->n_filters << arch->n_ratios) % 16)) return fail("LSTM width must be a multiple of 16");
+    if (arch->lstm_layers > FC_LSTM_MAX_LAYERS) return fail("too many LSTM layers");
     for (int i = 0; i < arch->n_ratios; ++i)
         if (arch->ratios[i] < 1) return fail("ratios must be >= 1");
     fc_engine* e = new fc_engine();
@@ -727,6 +741,7 @@ int fc_engine_finalize(fc_engine* e) {
         }
         en[r] = s;
     }
+    if (upload(e, std::vector<float>(64, 0.f), &e->zeros)) return 1;
     if (upload(e, E, &e->cb)) return 1;
     if (upload(e, en, &e->enorm)) return 1;
     // opt in to the dynamic LDS the conv kernels ask for is not needed (<= 64 KiB); host copies are dropped

@@ -22,6 +22,7 @@ struct ConvLaunch {
     const float* wt = nullptr;    // packed weights [mtile][chunk][Wbuf]: [kk][cl][BM] + zero pad to 4 KiB
     const float* bias = nullptr;  // [Mpad]
     const int* koff = nullptr;    // device table from conv_koff_table()
+    const float* zeros = nullptr; // device buffer of zeros (DMA source for padding)
     float* out = nullptr;
     long long out_sB = 0, out_sM = 0, out_sT = 1;
     int B = 0, Cin = 0, Tin = 0;
@@ -38,7 +39,8 @@ int conv_nblk(const ConvLaunch& c);                         // stat partials per
 size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
 size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab);
-bool conv_slab_fits(int k, int stride, int CC, int BN);
+bool conv_slab_fits(int k, int stride, int CC, int BN, int BM);
+int conv_wgs_per_cu(int BM);
 std::vector<int> conv_koff_table(int k, int stride, int CC, int BN);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
 
@@ -71,5 +73,11 @@ hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D,
 // y[b][u][t] (layout [B][H][T]) receives h_t.
 hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float* h_prev, float* h_next,
                             float* c, float* y, int B, int H, int T, int t, hipStream_t st);
+
+#define FC_LSTM_MAX_LAYERS 4
+// Layer-wavefront step s (see kernels.hip): w[0] = W_hh0 perm [4H][H]; w[l>=1] = [W_ih_l | W_hh_l] perm [4H][2H];
+// bias[l>=1] = perm(b_ih + b_hh); h [L][2][B][H] and c [L][B][H] zero-initialised by the caller.
+hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, const float* xproj, float* h, float* c,
+                            float* y, int B, int H, int T, int L, int s, hipStream_t st);
 
 }  // namespace fc

@@ -54,6 +54,7 @@ struct ConvArgs {
     int Wbuf;               // floats per packed weight chunk (multiple of 1024)
     int slabW, PL, rowStride, xs_floats;
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
+    const float* zeros;     // >= 4 zero floats in HBM: DMA source of padding elements
     const int* koff;        // [koff_n] B-operand LDS float offset per k-step (padded, multiple of 4)
     int koff_n;
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
@@ -115,16 +116,19 @@ __device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int t
 // (weight DMA + register-prefetched slab) runs across chunk AND tile boundaries, so per-workgroup fixed costs
 // (affine tables, slab descriptors, first-load latency) are paid once per range instead of once per tile.
 template <int BM, int BN, int WM, int WN, int MODE, int NU>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, (BM == 32 && NU == 8 ? 4 : 2)) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr bool PLAIN = MODE == 0;                 // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU
     constexpr bool DUAL = MODE >= 3;
     constexpr bool ELU = MODE == 2 || MODE == 4;
+    // PLAIN slabs can be DMA'd straight into their MFMA layout (no arithmetic), but 4-byte-per-lane LDS-DMA turned
+    // out slower than register staging on MI355X (decoder.model.3.convtr: 958 vs 734 us); kept for 16-byte variants.
+    constexpr bool DMAX = PLAIN && false;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem + 2 * p.Wbuf;
     const int cin_pad = (p.Cin + 1) & ~1;             // keeps everything behind the tables 16-byte aligned
-    float2* tab0 = (float2*)(Xs + p.xs_floats);
+    float2* tab0 = (float2*)(Xs + p.xs_floats * (DMAX ? 2 : 1));   // the DMA variant double-buffers the slab
     float2* tab1 = tab0 + (PLAIN ? 0 : cin_pad);
     int* kofs_i = (int*)(tab1 + (DUAL ? cin_pad : 0));
     float* bias_s = (float*)(kofs_i + p.koff_n);
@@ -161,11 +165,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
 
     // Register-staged slab.  Element e = tid + 256*u of every chunk of every tile maps to the same (local channel
     // cl, slab column tau); computed once:  base0[u] = cl*Tin + tau,  slot[u] = LDS float index | cl << 16.
-    unsigned base0[NU], slot[NU];
-    float v0[NU], v1[DUAL ? NU : 1];
+    unsigned base0[DMAX ? 1 : NU], slot[DMAX ? 1 : NU];
+    float v0[DMAX ? 1 : NU], v1[DUAL ? NU : 1];
     unsigned inmask = 0;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
         const int e = tid + 256 * u;
         base0[u] = 0u; slot[u] = (unsigned)p.xs_floats - 1u;   // dummy LDS slot (never read by the MFMA loop)
         if (e < total) {
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         if (interior) {
             const unsigned ubase = (unsigned)(c0 * p.Tin + tbase);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
+            for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
                 const unsigned off = ((inmask >> u) & 1u) ? base0[u] + ubase : 0u;
                 v0[u] = s0b[off];
                 if (DUAL) v1[u] = s1b[off];
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         } else {
             const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
+            for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
                 unsigned sl = slot[u];
                 asm volatile("" : "+v"(sl));            // keep the edge-tile index math out of the persistent registers
                 const int cl = (int)(sl >> 16);
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     // Branch-free per element: lanes without an element write a dummy slot, padding lanes select 0.
     auto write_slab_t = [&](int c0, auto use_div) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
+        for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
             float v = v0[u];
             if (!PLAIN) {
                 const int ci = c0 + (int)(slot[u] >> 16);            // a missing element has cl = 0
@@ -246,6 +250,60 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         if (p.ablate & 64) return;
         if (MODE == 1 && p.div0) write_slab_t(c0, std::true_type());
         else write_slab_t(c0, std::false_type());
+    };
+
+    // ---- PLAIN mode: the slab needs no arithmetic, so it is DMA'd straight into its MFMA layout -------
+    // LDS float L = u*256 + tid of a slab buffer holds (cl, ph, q): L = cl*rowStride + ph*PL + q, tau = q*S + ph.
+    // dsrc[u] = cl*Tin + tau (source offset relative to the chunk / tile origin), dmask: L is a real element.
+    unsigned dsrc[DMAX ? NU : 1];
+    unsigned dmask = 0;
+    if (DMAX) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int L = u * 256 + tid;
+            const int cl = L / p.rowStride;
+            const int r = L - cl * p.rowStride;
+            const int ph = r / p.PL;
+            const int q = r - ph * p.PL;
+            const int tau = q * p.stride + ph;
+            dsrc[u] = (unsigned)(cl * p.Tin + tau) | ((unsigned)cl << 26);   // cl < 64, offset < 2^26
+            if (cl < p.CC && tau < p.slabW) dmask |= 1u << u;
+        }
+    }
+    auto dma_slab = [&](int tile, int c0, float* dst) {
+        if (p.ablate & 4) return;
+        const int tbase = tile * BN * p.stride - p.padL;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int rounds = (p.CC * p.rowStride + 255) >> 8;
+        const bool interior = tbase >= 0 && tbase + p.slabW <= p.Tin && c0 + p.CC <= p.Cin;
+        if (interior) {
+            const float* gb = s0b + (size_t)c0 * p.Tin + tbase;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (u < rounds) {                     // wave-uniform: the buffer holds `rounds` x 256 floats
+                    const float* g = ((dmask >> u) & 1u) ? gb + (dsrc[u] & 0x3ffffffu) : p.zeros;
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(dst + u * 256 + wave * 64), 4, 0, 0);
+                }
+            }
+        } else {
+            const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                unsigned ds = dsrc[u];
+                asm volatile("" : "+v"(ds));
+                const int cl = (int)(ds >> 26);
+                const int tau = (int)(ds & 0x3ffffffu) - cl * p.Tin;
+                const int g0 = tbase + tau;
+                bool ok = ((dmask >> u) & 1u) && c0 + cl < p.Cin && g0 >= -p.padL && g0 < hi_lim;
+                int src = g0 < 0 ? -g0 : g0;
+                src = src >= p.Leff ? refl - src : src;
+                if (p.pad_zero) { src = g0; ok = ok && g0 >= 0; }
+                ok = ok && src < p.Tin;
+                const float* g = ok ? s0b + (size_t)(c0 + cl) * p.Tin + src : p.zeros;
+                if (u < rounds)
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(dst + u * 256 + wave * 64), 4, 0, 0);
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -339,15 +397,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
     const bool resident = p.nchunk <= 2;              // the whole K extent of this M tile stays in LDS
     dma_weights(wt_tile, smem, p.Wbuf, tid, p.ablate);
     if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, tid, p.ablate);
-    load_slab(t_begin, 0);
-    __syncthreads();          // tables visible; weights landed (the barrier drains vmcnt)
-    write_slab(0);
-    __syncthreads();
+    if (DMAX) {
+        dma_slab(t_begin, 0, Xs);
+        __syncthreads();      // weights + slab landed (the barrier drains vmcnt)
+    } else {
+        load_slab(t_begin, 0);
+        __syncthreads();      // tables visible; weights landed (the barrier drains vmcnt)
+        write_slab(0);
+        __syncthreads();
+    }
 
     const int a_off = hi * BM + wm * (TM * 32) + l31;
     const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
     const int nks = p.Kc >> 1;
-    const float* Xb = Xs + b_off;
 
     // Two workgroups share a CU; started together they run their load / MFMA / store phases in lock step and
     // contend instead of overlapping.  Skew the second resident set by about half a chunk period.
@@ -364,8 +426,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
         if (more) {
             if (!resident)
                 dma_weights(wt_tile + (size_t)nchunk_i * p.Wbuf, smem + ((step + 1) & 1) * p.Wbuf, p.Wbuf, tid, p.ablate);
-            load_slab(ntile, nchunk_i * p.CC);
+            if (DMAX) dma_slab(ntile, nchunk_i * p.CC, Xs + ((step + 1) & 1) * p.xs_floats);
+            else load_slab(ntile, nchunk_i * p.CC);
         }
+        const float* Xb = Xs + (DMAX ? (step & 1) * p.xs_floats : 0) + b_off;
         const float* Ws = smem + (resident ? chunk : (step & 1)) * p.Wbuf + a_off;
         // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16 LDS
         // fragment reads are issued ahead of 16 MFMAs; B offsets come from the LDS table, prefetched one ahead.
@@ -414,8 +478,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs p) {
             zero_acc();
         }
         if (!more) break;
-        write_slab(nchunk_i * p.CC);
-        __syncthreads();
+        if (!DMAX) {
+            write_slab(nchunk_i * p.CC);
+            __syncthreads();
+        }
         tile = ntile; chunk = nchunk_i; ++step;
     }
 }
@@ -438,8 +504,9 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.slabW = (c.BN - 1) * c.stride + c.k;
     a.PL = ceil_div(a.slabW, c.stride);
     a.rowStride = a.PL * c.stride;
-    a.xs_floats = ((c.CC * a.rowStride + 3) & ~3) + 4;   // + a dummy slot for lanes without a slab element
+    a.xs_floats = ((c.CC * a.rowStride + 255) & ~255) + 4;   // whole 256-float DMA rounds + a dummy slot
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
+    a.zeros = c.zeros;
     a.koff = c.koff;
     a.koff_n = (int)(((c.k * c.CC / 2) + 7) & ~3) + 4;
     a.cin_tail = (c.Cin % c.CC) != 0;
@@ -472,13 +539,21 @@ int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.
 size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab) {
     const int slabW = (BN - 1) * stride + k;
     const int rowStride = ceil_div(slabW, stride) * stride;
-    const int xs = ((CC * rowStride + 3) & ~3) + 4;
+    const int xs = ((CC * rowStride + 255) & ~255) + 4;
     const size_t koff_bytes = (size_t)((((k * CC / 2) + 7) & ~3) + 4) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
            (size_t)BM * sizeof(float) + 64;
 }
 
-bool conv_slab_fits(int k, int stride, int CC, int BN) { return CC * ((BN - 1) * stride + k) <= SLAB_MAX; }
+// Thin tiles (BM <= 64) stage 8 elements per thread per chunk so that they fit 128 / 168 VGPRs and run 4 / 3
+// workgroups per CU (latency hiding for the HBM-bound layers); 128-row tiles stage 16.
+int conv_wgs_per_cu(int BM) { return BM == 32 ? 4 : 2; }
+bool conv_slab_fits(int k, int stride, int CC, int BN, int BM) {
+    const int slabW = (BN - 1) * stride + k;
+    const int img = CC * ceil_div(slabW, stride) * stride;
+    if (BM == 32 && CC > 2) return img <= 8 * 256;                // prefer the 128-VGPR variant
+    return img <= SLAB_PER_THREAD * 256;
+}
 
 size_t conv_lds_bytes(const ConvLaunch& c) {
     const int ntab = c.s1.ptr ? 2 : ((c.s0.aff || c.s0.div || c.elu) ? 1 : 0);
@@ -505,7 +580,7 @@ static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t 
 
 template <int BM, int BN, int WM, int WN>
 static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    const int total = a.CC * a.slabW;
+    const int total = a.CC * a.rowStride;
     if (c.s1.ptr) return c.elu ? launch_conv_m<BM, BN, WM, WN, 4>(a, total, grid, lds, st)
                                : launch_conv_m<BM, BN, WM, WN, 3>(a, total, grid, lds, st);
     if (c.s0.aff || c.s0.div || c.elu) return c.elu ? launch_conv_m<BM, BN, WM, WN, 2>(a, total, grid, lds, st)
@@ -516,10 +591,11 @@ static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 gri
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
-    if (!conv_slab_fits(c.k, c.stride, c.CC, c.BN) || lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
+    if (!conv_slab_fits(c.k, c.stride, c.CC, c.BN, c.BM) || lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
     // one resident wave of workgroups (2 per CU): each takes a contiguous range of N tiles
     const int ntiles = ceil_div(c.Tout, c.BN), mtiles = ceil_div(c.M, c.BM);
-    static const int target_wgs = getenv("FC_TARGET_WGS") ? atoi(getenv("FC_TARGET_WGS")) : 512;
+    static const int target_env = getenv("FC_TARGET_WGS") ? atoi(getenv("FC_TARGET_WGS")) : 0;
+    const int target_wgs = target_env ? target_env : 256 * conv_wgs_per_cu(c.BM);
     int G = target_wgs / (mtiles * c.B);
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
@@ -963,6 +1039,135 @@ hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float*
         default: FC_LSTM_CASE(0); break;
     }
 #undef FC_LSTM_CASE
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Layer-wavefront LSTM step: launch s advances layer l by its timestep t = s - l for ALL layers at once
+// (T + L - 1 launches instead of L*T, and no separate x-projection GEMM for layers >= 1, whose input
+// h_{l-1}(t) is consumed straight from the previous launch):
+//   layer 0 : gates = xproj[t] + W_hh0 . h0(t-1)
+//   layer l : gates = bias_l + [W_ih_l | W_hh_l] . [h_{l-1}(t) ; h_l(t-1)]
+// hidden states ping-pong on the parity of their own timestep: h[l][t & 1].
+// -------------------------------------------------------------------------------------------------
+struct LstmWaveArgs {
+    const float* w[FC_LSTM_MAX_LAYERS];
+    const float* bias[FC_LSTM_MAX_LAYERS];
+    const float* xproj;
+    float* h;
+    float* c;
+    float* y;
+    int B, H, T, L, s, KS;
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void lstm_wave_kernel(const LstmWaveArgs p) {
+    __shared__ f32x4 red[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int H = p.H, B = p.B;
+    const int nblk = H >> 2;
+    const int layer = blockIdx.x / nblk, blk = blockIdx.x - layer * nblk;
+    const int t = p.s - layer;
+    if (t < 0 || t >= p.T) return;
+    const int kslice = H / p.KS;
+    const int nsteps = kslice >> 4;
+    const bool active = wid < p.KS;
+    const int nseg = layer == 0 ? 1 : 2;
+    const int wstride = layer == 0 ? H : 2 * H;
+    const float* wbase = p.w[layer] + ((size_t)blk * 16 + r16) * wstride + (active ? wid : 0) * kslice + 4 * g;
+    const size_t BH = (size_t)B * H;
+    float* hl = p.h + (size_t)layer * 2 * BH;
+    const float* h_own_prev = hl + (size_t)((t + 1) & 1) * BH;                  // h_l(t-1): parity (t-1)&1
+    const float* h_below = layer ? p.h + (size_t)(layer - 1) * 2 * BH + (size_t)(t & 1) * BH : nullptr;   // h_{l-1}(t)
+    float* h_out = hl + (size_t)(t & 1) * BH;
+    float* cl = p.c + (size_t)layer * BH;
+    constexpr int NA = NS > 0 ? NS : 1;
+    const int nbt = (B + 15) >> 4;
+    for (int nb = 0; nb < nbt; ++nb) {
+        const int brow = nb * 16 + r16;
+        const bool bvalid = brow < B;
+        const size_t ci = (size_t)(bvalid ? brow : 0) * H + (size_t)blk * 4 + g;
+        f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+        float cprev = 0.f;
+        if (wid == 0) {
+            if (layer == 0) xp = *(const f32x4*)(p.xproj + ((size_t)t * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
+            else xp = *(const f32x4*)(p.bias[layer] + (size_t)blk * 16 + 4 * g);
+            cprev = cl[ci];
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int seg = 0; seg < nseg; ++seg) {
+            const float* wrow = wbase + (nseg == 2 ? seg * H : 0);
+            const float* hsrc = (nseg == 2 && seg == 0) ? h_below : h_own_prev;
+            const float* hrow = hsrc + (size_t)(bvalid ? brow : 0) * H + (active ? wid : 0) * kslice + 4 * g;
+            if (NS > 0) {
+                f32x4 a4[NA], b4[NA];
+#pragma unroll
+                for (int q = 0; q < NA; ++q) {
+                    a4[q] = *(const f32x4*)(wrow + 16 * q);
+                    b4[q] = *(const f32x4*)(hrow + 16 * q);
+                    if (!bvalid) b4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < NA; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (q & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[q][j], acc1, 0, 0, 0);
+                        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[q][j], acc, 0, 0, 0);
+                    }
+                }
+            } else if (active) {
+                for (int q = 0; q < nsteps; ++q) {
+                    const f32x4 av = *(const f32x4*)(wrow + 16 * q);
+                    f32x4 bv = *(const f32x4*)(hrow + 16 * q);
+                    if (!bvalid) bv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+                }
+            }
+        }
+        acc = acc + acc1;
+        if (!active) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        red[wid][lane] = acc;
+        __syncthreads();
+        if (wid == 0) {
+            f32x4 sgate = red[0][lane];
+            for (int w = 1; w < p.KS; ++w) sgate = sgate + red[w][lane];
+            if (bvalid) {
+                const float gi = sigmoid_f(sgate[0] + xp[0]);
+                const float gf = sigmoid_f(sgate[1] + xp[1]);
+                const float gg = tanhf(sgate[2] + xp[2]);
+                const float go = sigmoid_f(sgate[3] + xp[3]);
+                const float cn = gf * cprev + gi * gg;
+                const float hn = go * tanhf(cn);
+                cl[ci] = cn;
+                h_out[ci] = hn;
+                if (layer == p.L - 1) p.y[ci * p.T + t] = hn;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, const float* xproj, float* h, float* c,
+                            float* y, int B, int H, int T, int L, int s, hipStream_t st) {
+    if (H % 16 != 0 || L < 1 || L > FC_LSTM_MAX_LAYERS) return hipErrorInvalidValue;
+    LstmWaveArgs a;
+    for (int l = 0; l < FC_LSTM_MAX_LAYERS; ++l) { a.w[l] = l < L ? w[l] : nullptr; a.bias[l] = l < L ? bias[l] : nullptr; }
+    a.xproj = xproj; a.h = h; a.c = c; a.y = y; a.B = B; a.H = H; a.T = T; a.L = L; a.s = s;
+    int KS = 4;
+    while (KS > 1 && (H % (16 * KS)) != 0) KS >>= 1;
+    a.KS = KS;
+    const int ns = H / (16 * KS);
+    dim3 grid(L * (H / 4)), block(256);
+    switch (ns) {
+        case 1: hipLaunchKernelGGL(lstm_wave_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(lstm_wave_kernel<2>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(lstm_wave_kernel<4>, grid, block, 0, st, a); break;
+        case 8: hipLaunchKernelGGL(lstm_wave_kernel<8>, grid, block, 0, st, a); break;
+        case 16: hipLaunchKernelGGL(lstm_wave_kernel<16>, grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL(lstm_wave_kernel<0>, grid, block, 0, st, a); break;
+    }
     return hipGetLastError();
 }
 
