@@ -280,7 +280,7 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     for (;;) {
         const int n = cc * 2;
         if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
-        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN, L.BM)) break;
+        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN, L.BM, L.dual)) break;
         if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, L.dual ? 2 : 1) > (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) break;
         cc = n;
     }

@@ -39,7 +39,7 @@ int conv_nblk(const ConvLaunch& c);                         // stat partials per
 size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
 size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab);
-bool conv_slab_fits(int k, int stride, int CC, int BN, int BM);
+bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual);
 int conv_wgs_per_cu(int BM);
 std::vector<int> conv_koff_table(int k, int stride, int CC, int BN);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);

@@ -110,202 +110,169 @@ __device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int t
 // MODE 0: plain single source (already activated input, no prologue math)
 // MODE 1/2: single source with GroupNorm affine (optional /div), without / with ELU
 // MODE 3/4: two summed sources with GroupNorm affines, without / with ELU
-// NU: slab elements staged per thread per chunk (compile time: every staging phase is one straight-line block)
+// NU: slab elements staged per staging thread per chunk (compile time)
 //
-// Each workgroup owns one (utterance b, M tile mt) and a CONTIGUOUS RANGE of N tiles; the load pipeline
-// (weight DMA + register-prefetched slab) runs across chunk AND tile boundaries, so per-workgroup fixed costs
-// (affine tables, slab descriptors, first-load latency) are paid once per range instead of once per tile.
+// Workgroup = 8 waves with two ROLES (wave specialisation):
+//   waves 0-3 "matrix": weight DMA, LDS fragment reads, MFMAs, epilogue stores + GroupNorm partials;
+//   waves 4-7 "staging": global loads of the NEXT slab into registers, prologue math (affine / residual / ELU /
+//                        padding) and the write into the other half of a double-buffered LDS slab.
+// Each SIMD hosts one matrix wave and one staging wave of a workgroup, so prologue VALU work and memory latency
+// overlap the matrix pipe by construction.  One barrier per K-chunk.  A workgroup owns one (utterance, M tile) and
+// a contiguous range of N tiles; the pipeline runs across chunk and tile boundaries.
 template <int BM, int BN, int WM, int WN, int MODE, int NU>
-__global__ __launch_bounds__(256, (BM == 32 && NU == 8 ? 4 : 2)) void conv_mfma_kernel(const ConvArgs p) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(const ConvArgs p) {
+    static_assert(WM * WN == 4, "4 matrix waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr bool PLAIN = MODE == 0;                 // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU
     constexpr bool DUAL = MODE >= 3;
     constexpr bool ELU = MODE == 2 || MODE == 4;
-    // PLAIN slabs can be DMA'd straight into their MFMA layout (no arithmetic), but 4-byte-per-lane LDS-DMA turned
-    // out slower than register staging on MI355X (decoder.model.3.convtr: 958 vs 734 us); kept for 16-byte variants.
-    constexpr bool DMAX = PLAIN && false;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem + 2 * p.Wbuf;
+    float* Xs0 = smem + 2 * p.Wbuf;                   // slab, double buffered
     const int cin_pad = (p.Cin + 1) & ~1;             // keeps everything behind the tables 16-byte aligned
-    float2* tab0 = (float2*)(Xs + p.xs_floats * (DMAX ? 2 : 1));   // the DMA variant double-buffers the slab
+    float2* tab0 = (float2*)(Xs0 + 2 * p.xs_floats);
     float2* tab1 = tab0 + (PLAIN ? 0 : cin_pad);
     int* kofs_i = (int*)(tab1 + (DUAL ? cin_pad : 0));
     float* bias_s = (float*)(kofs_i + p.koff_n);
-    double* red = (double*)(bias_s + BM);
+    double* red = (double*)(bias_s + BM);             // [2 tiles in flight][8]
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WN, wn = wid % WN;
+    const int tid = threadIdx.x;
+    const int role = __builtin_amdgcn_readfirstlane(tid >> 8);    // 0 matrix, 1 staging
+    const int rtid = tid & 255, lane = tid & 63, wid = (tid >> 6) & 3;
     const int b = blockIdx.z, mt = blockIdx.y;
     const int m0 = mt * BM;
-    const int hi = lane >> 5, l31 = lane & 31;
     const int ntiles = (p.Tout + BN - 1) / BN;
     const int t_begin = (int)(((long long)ntiles * blockIdx.x) / gridDim.x);
     const int t_end = (int)(((long long)ntiles * (blockIdx.x + 1)) / gridDim.x);
     if (t_begin >= t_end) return;
-
-    const int total = p.CC * p.slabW;                 // <= 256 * NU
-    const float divv = (!PLAIN && p.div0) ? p.div0[b] : 1.f;
-    const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
     const size_t rowbase = (size_t)b * p.Cin;
+    const int nitems = (t_end - t_begin) * p.nchunk;  // flattened (tile, chunk) work items of this workgroup
+    const bool resident = p.nchunk <= 2;              // the whole K extent of this M tile stays in LDS
 
+    // ---- common prologue: tables -------------------------------------------------------------------
     if (!PLAIN) {   // per-(b, channel) GroupNorm affine of the producers, staged once per workgroup
-        for (int c = tid; c < p.Cin; c += 256) {
+        for (int c = tid; c < p.Cin; c += 512) {
             tab0[c] = p.aff0 ? ((const float2*)p.aff0)[rowbase + c] : make_float2(1.f, 0.f);
             if (DUAL) tab1[c] = p.aff1 ? ((const float2*)p.aff1)[rowbase + c] : make_float2(1.f, 0.f);
         }
     }
-    for (int i = tid; i < p.koff_n; i += 256) kofs_i[i] = p.koff[i];
-    for (int i = tid; i < BM; i += 256) bias_s[i] = p.bias[m0 + i];
-    const int4* kofs = (const int4*)kofs_i;
+    for (int i = tid; i < p.koff_n; i += 512) kofs_i[i] = p.koff[i];
+    for (int i = tid; i < BM; i += 512) bias_s[i] = p.bias[m0 + i];
+    __syncthreads();
 
-    // utterance base pointers are wave-uniform (SGPR base + 32-bit lane offset addressing)
-    const float* __restrict__ s0b = p.src0 + rowbase * p.Tin;
-    const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
-
-    // Register-staged slab.  Element e = tid + 256*u of every chunk of every tile maps to the same (local channel
-    // cl, slab column tau); computed once:  base0[u] = cl*Tin + tau,  slot[u] = LDS float index | cl << 16.
-    unsigned base0[DMAX ? 1 : NU], slot[DMAX ? 1 : NU];
-    float v0[DMAX ? 1 : NU], v1[DUAL ? NU : 1];
-    unsigned inmask = 0;
-#pragma unroll
-    for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
-        const int e = tid + 256 * u;
-        base0[u] = 0u; slot[u] = (unsigned)p.xs_floats - 1u;   // dummy LDS slot (never read by the MFMA loop)
-        if (e < total) {
-            const int cl = (int)__umulhi((unsigned)e, p.magic_slabW);
-            const int tau = e - cl * p.slabW;
-            int ph, q;
-            switch (p.stride) {
-                case 1: ph = 0; q = tau; break;
-                case 2: q = tau >> 1; ph = tau & 1; break;
-                case 4: q = tau >> 2; ph = tau & 3; break;
-                case 8: q = tau >> 3; ph = tau & 7; break;
-                default: q = tau / p.stride; ph = tau - q * p.stride; break;
-            }
-            base0[u] = (unsigned)(cl * p.Tin + tau);
-            slot[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | ((unsigned)cl << 16);
-            inmask |= 1u << u;
-        }
-    }
-    // All loads of a chunk are unconditional (masked elements read offset 0) and issued back to back so that they
-    // stay in flight during the MFMA loop of the previous chunk.  Interior tiles (no padding, no channel tail)
-    // take the fast path: one uniform add per element.
-    unsigned vmask = 0;
-    auto load_slab = [&](int tile, int c0) {
-        const int tbase = tile * BN * p.stride - p.padL;
-        vmask = inmask;
-        if (p.ablate & 4) return;
-        const bool interior = tbase >= 0 && tbase + p.slabW <= p.Tin && c0 + p.CC <= p.Cin;
-        if (interior) {
-            const unsigned ubase = (unsigned)(c0 * p.Tin + tbase);
-#pragma unroll
-            for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
-                const unsigned off = ((inmask >> u) & 1u) ? base0[u] + ubase : 0u;
-                v0[u] = s0b[off];
-                if (DUAL) v1[u] = s1b[off];
-            }
-        } else {
-            const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
-#pragma unroll
-            for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
-                unsigned sl = slot[u];
-                asm volatile("" : "+v"(sl));            // keep the edge-tile index math out of the persistent registers
-                const int cl = (int)(sl >> 16);
-                const int tau = (tid + 256 * u) - cl * p.slabW;
-                const int g = tbase + tau;
-                bool ok = ((inmask >> u) & 1u) && c0 + cl < p.Cin && g >= -p.padL && g < hi_lim;
-                int src = g < 0 ? -g : g;
-                src = src >= p.Leff ? refl - src : src;
-                if (p.pad_zero) { src = g; ok = ok && g >= 0; }
-                ok = ok && src < p.Tin;              // zero padding / zero-extension of short inputs (conv.py:89-93)
-                const unsigned off = ok ? (unsigned)((c0 + cl) * p.Tin + src) : 0u;
-                v0[u] = s0b[off];
-                if (DUAL) v1[u] = s1b[off];
-                vmask &= ~((ok ? 0u : 1u) << u);
-            }
-        }
-    };
-    // Branch-free per element: lanes without an element write a dummy slot, padding lanes select 0.
-    auto write_slab_t = [&](int c0, auto use_div) {
-#pragma unroll
-        for (int u = 0; u < (DMAX ? 0 : NU); ++u) {
-            float v = v0[u];
-            if (!PLAIN) {
-                const int ci = c0 + (int)(slot[u] >> 16);            // a missing element has cl = 0
-                if (decltype(use_div)::value) v = v / divv;
-                const float2 a = tab0[ci];
-                v = fmaf(v, a.x, a.y);
-                if (DUAL) {
-                    const float2 a1 = tab1[ci];
-                    v = v + fmaf(v1[u], a1.x, a1.y);
-                }
-                if (ELU) v = elu_f(v, p.alpha);
-            }
-            v = ((vmask >> u) & 1u) ? v : 0.f;
-            Xs[slot[u] & 0xffffu] = v;
-        }
-    };
-    auto write_slab = [&](int c0) {
-        if (p.ablate & 64) return;
-        if (MODE == 1 && p.div0) write_slab_t(c0, std::true_type());
-        else write_slab_t(c0, std::false_type());
-    };
-
-    // ---- PLAIN mode: the slab needs no arithmetic, so it is DMA'd straight into its MFMA layout -------
-    // LDS float L = u*256 + tid of a slab buffer holds (cl, ph, q): L = cl*rowStride + ph*PL + q, tau = q*S + ph.
-    // dsrc[u] = cl*Tin + tau (source offset relative to the chunk / tile origin), dmask: L is a real element.
-    unsigned dsrc[DMAX ? NU : 1];
-    unsigned dmask = 0;
-    if (DMAX) {
+    if (role == 1) {
+        // =========================================== staging waves =====================================
+        const int total = p.CC * p.slabW;             // <= 256 * NU
+        const float divv = (MODE == 1 && p.div0) ? p.div0[b] : 1.f;
+        const float* __restrict__ s0b = p.src0 + rowbase * p.Tin;     // wave-uniform bases, 32-bit lane offsets
+        const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
+        // element e = rtid + 256*u of every chunk of every tile maps to the same (local channel cl, slab column tau):
+        //   base0[u] = cl*Tin + tau      slot[u] = LDS float index | cl << 16
+        unsigned base0[NU], slot[NU];
+        float v0[NU], v1[DUAL ? NU : 1];
+        unsigned inmask = 0, vmask = 0;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int L = u * 256 + tid;
-            const int cl = L / p.rowStride;
-            const int r = L - cl * p.rowStride;
-            const int ph = r / p.PL;
-            const int q = r - ph * p.PL;
-            const int tau = q * p.stride + ph;
-            dsrc[u] = (unsigned)(cl * p.Tin + tau) | ((unsigned)cl << 26);   // cl < 64, offset < 2^26
-            if (cl < p.CC && tau < p.slabW) dmask |= 1u << u;
+            const int e = rtid + 256 * u;
+            base0[u] = 0u; slot[u] = (unsigned)p.xs_floats - 1u;       // dummy LDS slot (never read by the MFMA loop)
+            if (e < total) {
+                const int cl = (int)__umulhi((unsigned)e, p.magic_slabW);
+                const int tau = e - cl * p.slabW;
+                int ph, q;
+                switch (p.stride) {
+                    case 1: ph = 0; q = tau; break;
+                    case 2: q = tau >> 1; ph = tau & 1; break;
+                    case 4: q = tau >> 2; ph = tau & 3; break;
+                    case 8: q = tau >> 3; ph = tau & 7; break;
+                    default: q = tau / p.stride; ph = tau - q * p.stride; break;
+                }
+                base0[u] = (unsigned)(cl * p.Tin + tau);
+                slot[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | ((unsigned)cl << 16);
+                inmask |= 1u << u;
+            }
         }
-    }
-    auto dma_slab = [&](int tile, int c0, float* dst) {
-        if (p.ablate & 4) return;
-        const int tbase = tile * BN * p.stride - p.padL;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int rounds = (p.CC * p.rowStride + 255) >> 8;
-        const bool interior = tbase >= 0 && tbase + p.slabW <= p.Tin && c0 + p.CC <= p.Cin;
-        if (interior) {
-            const float* gb = s0b + (size_t)c0 * p.Tin + tbase;
+        // loads are unconditional (masked elements read offset 0) and issued back to back
+        auto load_slab = [&](int item) {
+            const int tile = t_begin + item / p.nchunk;
+            const int c0 = (item - (tile - t_begin) * p.nchunk) * p.CC;
+            const int tbase = tile * BN * p.stride - p.padL;
+            vmask = inmask;
+            if (p.ablate & 4) return;
+            const bool interior = tbase >= 0 && tbase + p.slabW <= p.Tin && c0 + p.CC <= p.Cin;
+            if (interior) {
+                const unsigned ubase = (unsigned)(c0 * p.Tin + tbase);
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                if (u < rounds) {                     // wave-uniform: the buffer holds `rounds` x 256 floats
-                    const float* g = ((dmask >> u) & 1u) ? gb + (dsrc[u] & 0x3ffffffu) : p.zeros;
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(dst + u * 256 + wave * 64), 4, 0, 0);
+                for (int u = 0; u < NU; ++u) {
+                    const unsigned off = ((inmask >> u) & 1u) ? base0[u] + ubase : 0u;
+                    v0[u] = s0b[off];
+                    if (DUAL) v1[u] = s1b[off];
+                }
+            } else {
+                const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    unsigned sl = slot[u];
+                    asm volatile("" : "+v"(sl));        // keep the edge-tile index math out of the persistent registers
+                    const int cl = (int)(sl >> 16);
+                    const int tau = (rtid + 256 * u) - cl * p.slabW;
+                    const int g = tbase + tau;
+                    bool ok = ((inmask >> u) & 1u) && c0 + cl < p.Cin && g >= -p.padL && g < hi_lim;
+                    int src = g < 0 ? -g : g;
+                    src = src >= p.Leff ? refl - src : src;
+                    if (p.pad_zero) { src = g; ok = ok && g >= 0; }
+                    ok = ok && src < p.Tin;          // zero padding / zero-extension of short inputs (conv.py:89-93)
+                    const unsigned off = ok ? (unsigned)((c0 + cl) * p.Tin + src) : 0u;
+                    v0[u] = s0b[off];
+                    if (DUAL) v1[u] = s1b[off];
+                    vmask &= ~((ok ? 0u : 1u) << u);
                 }
             }
-        } else {
-            const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
+        };
+        // branch-free per element: lanes without an element write a dummy slot, padding lanes select 0
+        auto write_slab_t = [&](int item, float* Xd, auto use_div) {
+            const int c0 = (item % p.nchunk) * p.CC;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                unsigned ds = dsrc[u];
-                asm volatile("" : "+v"(ds));
-                const int cl = (int)(ds >> 26);
-                const int tau = (int)(ds & 0x3ffffffu) - cl * p.Tin;
-                const int g0 = tbase + tau;
-                bool ok = ((dmask >> u) & 1u) && c0 + cl < p.Cin && g0 >= -p.padL && g0 < hi_lim;
-                int src = g0 < 0 ? -g0 : g0;
-                src = src >= p.Leff ? refl - src : src;
-                if (p.pad_zero) { src = g0; ok = ok && g0 >= 0; }
-                ok = ok && src < p.Tin;
-                const float* g = ok ? s0b + (size_t)(c0 + cl) * p.Tin + src : p.zeros;
-                if (u < rounds)
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)(dst + u * 256 + wave * 64), 4, 0, 0);
+                float v = v0[u];
+                if (!PLAIN) {
+                    const int ci = c0 + (int)(slot[u] >> 16);        // a missing element has cl = 0
+                    if (decltype(use_div)::value) v = v / divv;
+                    const float2 a = tab0[ci];
+                    v = fmaf(v, a.x, a.y);
+                    if (DUAL) {
+                        const float2 a1 = tab1[ci];
+                        v = v + fmaf(v1[u], a1.x, a1.y);
+                    }
+                    if (ELU) v = elu_f(v, p.alpha);
+                }
+                v = ((vmask >> u) & 1u) ? v : 0.f;
+                Xd[slot[u] & 0xffffu] = v;
             }
-        }
-    };
+        };
+        auto write_slab = [&](int item, float* Xd) {
+            if (MODE == 1 && p.div0) write_slab_t(item, Xd, std::true_type());
+            else write_slab_t(item, Xd, std::false_type());
+        };
 
+        load_slab(0);
+        write_slab(0, Xs0);
+        if (nitems > 1) load_slab(1);
+        __syncthreads();                              // B0: slab 0 + weights 0 visible
+        for (int f = 0; f < nitems; ++f) {
+            if (f + 1 < nitems) {
+                write_slab(f + 1, Xs0 + ((f + 1) & 1) * p.xs_floats);   // registers were filled one iteration ago
+                if (f + 2 < nitems) load_slab(f + 2);
+            }
+            __syncthreads();                          // B(f+1)
+        }
+        __syncthreads();                              // final: matches the matrix waves' statistics hand-off
+        return;
+    }
+
+    // =============================================== matrix waves ======================================
+    const int wm = wid / WN, wn = wid % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
+    const int4* kofs = (const int4*)kofs_i;
     f32x16 acc[TM][TN];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -317,16 +284,14 @@ __global__ __launch_bounds__(256, (BM == 32 && NU == 8 ? 4 : 2)) void conv_mfma_
     };
     zero_acc();
 
-    // ---- epilogue of one tile: bias, store, GroupNorm partial statistics ---------------------------
-    auto epilogue = [&](int tile) {
+    // epilogue of one tile: bias, store, per-wave GroupNorm partial statistics into red[par][..]
+    auto epilogue = [&](int tile, int par) {
         const int n0 = tile * BN;
-        // opaque copies: keep the row-pointer arithmetic INSIDE the tile loop (hoisting it costs ~64 VGPRs)
-        int m0_l = m0, b_l = b;
+        int m0_l = m0, b_l = b;                        // opaque copies keep the row-pointer math inside the tile loop
         asm volatile("" : "+s"(m0_l), "+s"(b_l));
         float s1 = 0.f, s2 = 0.f;
         const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2);
         if (full) {
-            // interior tile, unit time stride: no bounds checks, one row pointer per accumulator row
             float* __restrict__ base = p.out + (size_t)b_l * p.out_sB + (size_t)(n0 + wn * (TN * 32) + l31);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -346,91 +311,70 @@ __global__ __launch_bounds__(256, (BM == 32 && NU == 8 ? 4 : 2)) void conv_mfma_
             }
         } else {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int m = m0_l + ml;
-                if (m >= p.M) continue;
-                const float bias = bias_s[ml];
-                int co = m, phs = 0;
-                if (p.up_r) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }
-                float* __restrict__ rowp = p.out + (size_t)b_l * p.out_sB + (size_t)co * p.out_sM;
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int m = m0_l + ml;
+                    if (m >= p.M) continue;
+                    const float bias = bias_s[ml];
+                    int co = m, phs = 0;
+                    if (p.up_r) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }
+                    float* __restrict__ rowp = p.out + (size_t)b_l * p.out_sB + (size_t)co * p.out_sM;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-                    if (n >= p.Tout) continue;
-                    const float v = acc[i][j][r] + bias;
-                    s1 += v;
-                    s2 = fmaf(v, v, s2);
-                    if (p.ablate & 2) continue;
-                    if (p.up_r) {
-                        const int t = n * p.up_r + phs - p.trimL;
-                        if (t >= 0 && t < p.Tfinal) rowp[t] = v;
-                    } else {
-                        rowp[(size_t)n * p.out_sT] = v;
+                    for (int j = 0; j < TN; ++j) {
+                        const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                        if (n >= p.Tout) continue;
+                        const float v = acc[i][j][r] + bias;
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                        if (p.ablate & 2) continue;
+                        if (p.up_r) {
+                            const int t = n * p.up_r + phs - p.trimL;
+                            if (t >= 0 && t < p.Tfinal) rowp[t] = v;
+                        } else {
+                            rowp[(size_t)n * p.out_sT] = v;
+                        }
                     }
                 }
             }
         }
-        }
-        if (p.partials && !(p.ablate & 32)) {
+        if (p.partials) {
             double d1 = (double)s1, d2 = (double)s2;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) {
                 d1 += __shfl_xor(d1, o, 64);
                 d2 += __shfl_xor(d2, o, 64);
             }
-            if (lane == 0) { red[wid] = d1; red[4 + wid] = d2; }
-            __syncthreads();
-            if (tid == 0) {
-                const int nblk = ntiles * gridDim.y;
-                const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
-                p.partials[slot_p] = ((red[0] + red[1]) + red[2]) + red[3];
-                p.partials[slot_p + 1] = ((red[4] + red[5]) + red[6]) + red[7];
-            }
-            // red is rewritten only after the next tile's barriers
+            if (lane == 0) { red[par * 8 + wid] = d1; red[par * 8 + 4 + wid] = d2; }
+        }
+    };
+    // fixed-order combine of the 4 per-wave partials of a finished tile (after the barrier that publishes them)
+    auto flush_stats = [&](int tile, int par) {
+        if (p.partials && tid == 0) {
+            const int nblk = ntiles * gridDim.y;
+            const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
+            const double* r = red + par * 8;
+            p.partials[slot_p] = ((r[0] + r[1]) + r[2]) + r[3];
+            p.partials[slot_p + 1] = ((r[4] + r[5]) + r[6]) + r[7];
         }
     };
 
-    // ---- pipeline over (tile, chunk) ---------------------------------------------------------------
-    const bool resident = p.nchunk <= 2;              // the whole K extent of this M tile stays in LDS
-    dma_weights(wt_tile, smem, p.Wbuf, tid, p.ablate);
-    if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, tid, p.ablate);
-    if (DMAX) {
-        dma_slab(t_begin, 0, Xs);
-        __syncthreads();      // weights + slab landed (the barrier drains vmcnt)
-    } else {
-        load_slab(t_begin, 0);
-        __syncthreads();      // tables visible; weights landed (the barrier drains vmcnt)
-        write_slab(0);
-        __syncthreads();
-    }
+    dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
+    if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
+    __syncthreads();                                  // B0 (drains the weight DMA)
 
     const int a_off = hi * BM + wm * (TM * 32) + l31;
     const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
     const int nks = p.Kc >> 1;
-
-    // Two workgroups share a CU; started together they run their load / MFMA / store phases in lock step and
-    // contend instead of overlapping.  Skew the second resident set by about half a chunk period.
-    if (p.skew) {
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if ((lin / p.skew_div) & 1u)
-            for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(64);
-    }
-    int tile = t_begin, chunk = 0, step = 0;
-    for (;;) {
-        int ntile = tile, nchunk_i = chunk + 1;
-        if (nchunk_i == p.nchunk) { nchunk_i = 0; ntile = tile + 1; }
-        const bool more = ntile < t_end;
-        if (more) {
-            if (!resident)
-                dma_weights(wt_tile + (size_t)nchunk_i * p.Wbuf, smem + ((step + 1) & 1) * p.Wbuf, p.Wbuf, tid, p.ablate);
-            if (DMAX) dma_slab(ntile, nchunk_i * p.CC, Xs + ((step + 1) & 1) * p.xs_floats);
-            else load_slab(ntile, nchunk_i * p.CC);
+    int tile = t_begin, chunk = 0, pending_tile = -1;
+    for (int f = 0; f < nitems; ++f) {
+        if (f + 1 < nitems && !resident) {
+            const int nc = chunk + 1 == p.nchunk ? 0 : chunk + 1;
+            dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
         }
-        const float* Xb = Xs + (DMAX ? (step & 1) * p.xs_floats : 0) + b_off;
-        const float* Ws = smem + (resident ? chunk : (step & 1)) * p.Wbuf + a_off;
+        const float* Ws = smem + (resident ? chunk : (f & 1)) * p.Wbuf + a_off;
+        const float* Xb = Xs0 + (f & 1) * p.xs_floats + b_off;
         // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16 LDS
         // fragment reads are issued ahead of 16 MFMAs; B offsets come from the LDS table, prefetched one ahead.
         int ks = (p.ablate & 1) ? nks : 0;
@@ -472,18 +416,17 @@ __global__ __launch_bounds__(256, (BM == 32 && NU == 8 ? 4 : 2)) void conv_mfma_
                 }
             }
         }
-        __syncthreads();      // every wave is done with Xs and this weight buffer; next weights + slab registers landed
-        if (chunk == p.nchunk - 1) {
-            if (!(p.ablate & 128)) epilogue(tile);
+        const bool tile_done = chunk == p.nchunk - 1;
+        if (tile_done) {
+            if (!(p.ablate & 128)) epilogue(tile, tile & 1);
             zero_acc();
         }
-        if (!more) break;
-        if (!DMAX) {
-            write_slab(nchunk_i * p.CC);
-            __syncthreads();
-        }
-        tile = ntile; chunk = nchunk_i; ++step;
+        __syncthreads();                              // B(f+1): slab f+1 + weights f+1 visible, buffers f free
+        if (pending_tile >= 0) { flush_stats(pending_tile, pending_tile & 1); pending_tile = -1; }
+        if (tile_done) { pending_tile = tile; ++tile; chunk = 0; } else { ++chunk; }
     }
+    __syncthreads();                                  // final: publish the last tile's per-wave partials
+    if (pending_tile >= 0) flush_stats(pending_tile, pending_tile & 1);
 }
 
 static ConvArgs make_args(const ConvLaunch& c) {
@@ -541,17 +484,17 @@ size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, in
     const int rowStride = ceil_div(slabW, stride) * stride;
     const int xs = ((CC * rowStride + 255) & ~255) + 4;
     const size_t koff_bytes = (size_t)((((k * CC / 2) + 7) & ~3) + 4) * sizeof(int);
-    return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
-           (size_t)BM * sizeof(float) + 64;
+    return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
+           (size_t)BM * sizeof(float) + 128;
 }
 
 // Thin tiles (BM <= 64) stage 8 elements per thread per chunk so that they fit 128 / 168 VGPRs and run 4 / 3
 // workgroups per CU (latency hiding for the HBM-bound layers); 128-row tiles stage 16.
-int conv_wgs_per_cu(int BM) { return BM == 32 ? 4 : 2; }
-bool conv_slab_fits(int k, int stride, int CC, int BN, int BM) {
+int conv_wgs_per_cu(int BM) { return BM == 32 ? 3 : 2; }
+bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual) {
     const int slabW = (BN - 1) * stride + k;
     const int img = CC * ceil_div(slabW, stride) * stride;
-    if (BM == 32 && CC > 2) return img <= 8 * 256;                // prefer the 128-VGPR variant
+    if ((BM == 32 || dual) && CC > 2) return img <= 8 * 256;      // prefer the low-register (NU = 8) variants
     return img <= SLAB_PER_THREAD * 256;
 }
 
@@ -568,7 +511,7 @@ static hipError_t launch_conv_k(const ConvArgs& a, dim3 grid, size_t lds, hipStr
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -591,7 +534,7 @@ static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 gri
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
-    if (!conv_slab_fits(c.k, c.stride, c.CC, c.BN, c.BM) || lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
+    if (c.CC * (ceil_div((c.BN - 1) * c.stride + c.k, c.stride) * c.stride) > SLAB_PER_THREAD * 256 || lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
     // one resident wave of workgroups (2 per CU): each takes a contiguous range of N tiles
     const int ntiles = ceil_div(c.Tout, c.BN), mtiles = ceil_div(c.M, c.BM);
     static const int target_env = getenv("FC_TARGET_WGS") ? atoi(getenv("FC_TARGET_WGS")) : 0;
