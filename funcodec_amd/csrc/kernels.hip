@@ -66,17 +66,14 @@ struct ConvArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// exp(x) for x <= 0 via the hardware exp2 with a two-term product x*log2(e) (hi + lo), ~1-2 ulp, no
-// range/denormal handling needed on this half line (results in (0, 1], underflow to 0 is the right answer).
-__device__ __forceinline__ float exp_neg(float x) {
-    const float L2E_HI = 1.44269502162933349609375f;      // fl(log2 e)
-    const float L2E_LO = 1.925963033500011e-08f;           // log2 e - L2E_HI
-    const float r = x * L2E_HI;
-    const float err = fmaf(x, L2E_HI, -r) + x * L2E_LO;    // exact rounding error of r + low-order term
-    const float p = __builtin_amdgcn_exp2f(r);
-    return fmaf(p, err * 0.693147182464599609375f, p);    // 2^(r+err) ~= 2^r * (1 + err ln 2)
+// ELU(alpha) on the hardware exp2: exp(v) = 2^(v*log2 e).  For v <= 0 the rounding of the product contributes
+// |v|*log2(e)*2^-24 relative error to e^v, i.e. at most 3e-8 absolute on the ELU output (below one fp32 ulp of the
+// result), so no compensated product is needed.  fp32 MFMA and fp32 VALU share the SIMD's FMA lanes on gfx950
+// (tests/micro/mfma_valu_overlap.hip: the two do not overlap), so every VALU instruction here is paid in full.
+__device__ __forceinline__ float elu_f(float v, float alpha) {
+    const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f);
+    return v > 0.f ? v : fmaf(e, alpha, -alpha);
 }
-__device__ __forceinline__ float elu_f(float v, float alpha) { return v > 0.f ? v : alpha * (exp_neg(v) - 1.f); }
 
 constexpr int SLAB_PER_THREAD = 16;          // register-staged slab elements per thread per chunk (NU = 8 or 16)
 constexpr int SLAB_MAX = SLAB_PER_THREAD * 256;
@@ -127,9 +124,10 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
     constexpr bool DUAL = MODE >= 3;
     constexpr bool ELU = MODE == 2 || MODE == 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int XSF = NU * 256 + 4;                 // floats per slab buffer (compile time: LDS immediates)
     float* Xs0 = smem + 2 * p.Wbuf;                   // slab, double buffered
     const int cin_pad = (p.Cin + 1) & ~1;             // keeps everything behind the tables 16-byte aligned
-    float2* tab0 = (float2*)(Xs0 + 2 * p.xs_floats);
+    float2* tab0 = (float2*)(Xs0 + 2 * XSF);
     float2* tab1 = tab0 + (PLAIN ? 0 : cin_pad);
     int* kofs_i = (int*)(tab1 + (DUAL ? cin_pad : 0));
     float* bias_s = (float*)(kofs_i + p.koff_n);
@@ -167,13 +165,19 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
         const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
         // element e = rtid + 256*u of every chunk of every tile maps to the same (local channel cl, slab column tau):
         //   base0[u] = cl*Tin + tau      slot[u] = LDS float index | cl << 16
-        unsigned base0[NU], slot[NU];
+        // Per-element descriptors, all in BYTES and unpacked (every extraction / shift would be a VALU instruction per
+        // element per chunk, and VALU time adds to MFMA time on this chip):
+        //   base0[u] = 4*(cl*Tin + tau)   source byte offset relative to the chunk / tile origin
+        //   slot[u]  = byte offset of the element inside a slab buffer (dummy slot for lanes without an element)
+        //   cl8[u]   = 8*cl               byte offset into the affine tables
+        unsigned base0[NU], slot[NU], cl8[PLAIN ? 1 : NU];
         float v0[NU], v1[DUAL ? NU : 1];
         unsigned inmask = 0, vmask = 0;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int e = rtid + 256 * u;
-            base0[u] = 0u; slot[u] = (unsigned)p.xs_floats - 1u;       // dummy LDS slot (never read by the MFMA loop)
+            base0[u] = 0u; slot[u] = (unsigned)(XSF - 1) * 4u;
+            if (!PLAIN) cl8[u] = 0u;
             if (e < total) {
                 const int cl = (int)__umulhi((unsigned)e, p.magic_slabW);
                 const int tau = e - cl * p.slabW;
@@ -185,11 +189,13 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
                     case 8: q = tau >> 3; ph = tau & 7; break;
                     default: q = tau / p.stride; ph = tau - q * p.stride; break;
                 }
-                base0[u] = (unsigned)(cl * p.Tin + tau);
-                slot[u] = (unsigned)(cl * p.rowStride + ph * p.PL + q) | ((unsigned)cl << 16);
+                base0[u] = 4u * (unsigned)(cl * p.Tin + tau);
+                slot[u] = 4u * (unsigned)(cl * p.rowStride + ph * p.PL + q);
+                if (!PLAIN) cl8[u] = (unsigned)cl * 8u;
                 inmask |= 1u << u;
             }
         }
+        bool all_valid = false;                       // current register contents need no padding mask
         // loads are unconditional (masked elements read offset 0) and issued back to back
         auto load_slab = [&](int item) {
             const int tile = t_begin + item / p.nchunk;
@@ -198,22 +204,24 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
             vmask = inmask;
             if (p.ablate & 4) return;
             const bool interior = tbase >= 0 && tbase + p.slabW <= p.Tin && c0 + p.CC <= p.Cin;
+            all_valid = interior;
             if (interior) {
-                const unsigned ubase = (unsigned)(c0 * p.Tin + tbase);
+                // lanes without an element (base0 = 0) read the tile origin: in bounds, value goes to the dummy slot
+                const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + tbase);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const unsigned off = ((inmask >> u) & 1u) ? base0[u] + ubase : 0u;
-                    v0[u] = s0b[off];
-                    if (DUAL) v1[u] = s1b[off];
+                    const unsigned off = base0[u] + ubase;
+                    v0[u] = *(const float*)((const char*)s0b + off);
+                    if (DUAL) v1[u] = *(const float*)((const char*)s1b + off);
                 }
             } else {
                 const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    unsigned sl = slot[u];
-                    asm volatile("" : "+v"(sl));        // keep the edge-tile index math out of the persistent registers
-                    const int cl = (int)(sl >> 16);
-                    const int tau = (rtid + 256 * u) - cl * p.slabW;
+                    unsigned ee = (unsigned)(rtid + 256 * u);
+                    asm volatile("" : "+v"(ee));        // keep the edge-tile index math out of the persistent registers
+                    const int cl = (int)__umulhi(ee, p.magic_slabW);
+                    const int tau = (int)ee - cl * p.slabW;
                     const int g = tbase + tau;
                     bool ok = ((inmask >> u) & 1u) && c0 + cl < p.Cin && g >= -p.padL && g < hi_lim;
                     int src = g < 0 ? -g : g;
@@ -228,38 +236,47 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
             }
         };
         // branch-free per element: lanes without an element write a dummy slot, padding lanes select 0
-        auto write_slab_t = [&](int item, float* Xd, auto use_div) {
+        // branch-free per element; interior tiles (the common case) skip the padding select
+        auto write_slab_t = [&](int item, char* Xd, auto use_div, auto masked) {
             const int c0 = (item % p.nchunk) * p.CC;
+            const char* t0 = (const char*)(tab0 + c0);
+            const char* t1 = (const char*)(tab1 + c0);
+            // all table reads first: LDS stores below may alias them as far as the compiler knows, and interleaving
+            // would serialise one LDS round trip per element
+            float2 a0[PLAIN ? 1 : NU], a1[DUAL ? NU : 1];
+            if (!PLAIN) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    a0[u] = *(const float2*)(t0 + cl8[u]);               // a missing element has cl = 0
+                    if (DUAL) a1[u] = *(const float2*)(t1 + cl8[u]);
+                }
+            }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 float v = v0[u];
                 if (!PLAIN) {
-                    const int ci = c0 + (int)(slot[u] >> 16);        // a missing element has cl = 0
                     if (decltype(use_div)::value) v = v / divv;
-                    const float2 a = tab0[ci];
-                    v = fmaf(v, a.x, a.y);
-                    if (DUAL) {
-                        const float2 a1 = tab1[ci];
-                        v = v + fmaf(v1[u], a1.x, a1.y);
-                    }
+                    v = fmaf(v, a0[u].x, a0[u].y);
+                    if (DUAL) v = v + fmaf(v1[u], a1[u].x, a1[u].y);
                     if (ELU) v = elu_f(v, p.alpha);
                 }
-                v = ((vmask >> u) & 1u) ? v : 0.f;
-                Xd[slot[u] & 0xffffu] = v;
+                if (decltype(masked)::value) v = ((vmask >> u) & 1u) ? v : 0.f;
+                *(float*)(Xd + slot[u]) = v;
             }
         };
-        auto write_slab = [&](int item, float* Xd) {
-            if (MODE == 1 && p.div0) write_slab_t(item, Xd, std::true_type());
-            else write_slab_t(item, Xd, std::false_type());
+        auto write_slab = [&](int item, char* Xd) {
+            if (MODE == 1 && p.div0) write_slab_t(item, Xd, std::true_type(), std::true_type());
+            else if (all_valid) write_slab_t(item, Xd, std::false_type(), std::false_type());
+            else write_slab_t(item, Xd, std::false_type(), std::true_type());
         };
 
         load_slab(0);
-        write_slab(0, Xs0);
+        write_slab(0, (char*)Xs0);
         if (nitems > 1) load_slab(1);
         __syncthreads();                              // B0: slab 0 + weights 0 visible
         for (int f = 0; f < nitems; ++f) {
             if (f + 1 < nitems) {
-                write_slab(f + 1, Xs0 + ((f + 1) & 1) * p.xs_floats);   // registers were filled one iteration ago
+                write_slab(f + 1, (char*)(Xs0 + ((f + 1) & 1) * XSF));   // registers were filled one iteration ago
                 if (f + 2 < nitems) load_slab(f + 2);
             }
             __syncthreads();                          // B(f+1)
@@ -274,13 +291,16 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
     const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
     const int4* kofs = (const int4*)kofs_i;
     f32x16 acc[TM][TN];
+    // accumulators start at the bias (the MFMA chain then adds the products): saves one VALU add per output element
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int r = 0; r < 16; ++r) {
+                const float bias = bias_s[(wid / WN) * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = bias;
+            }
     };
     zero_acc();
 
@@ -292,17 +312,19 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
         float s1 = 0.f, s2 = 0.f;
         const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2);
         if (full) {
-            float* __restrict__ base = p.out + (size_t)b_l * p.out_sB + (size_t)(n0 + wn * (TN * 32) + l31);
+            // one 64-bit lane pointer for accumulator row 0; every other row / column tile is a wave-uniform offset
+            const size_t sM = (size_t)p.out_sM;
+            const float* __restrict__ row0c = p.out + (size_t)b_l * p.out_sB + (size_t)(n0 + wn * (TN * 32) + l31) +
+                                             (size_t)(m0_l + wm * (TM * 32) + 4 * hi) * sM;
+            float* __restrict__ row0 = const_cast<float*>(row0c);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float bias = bias_s[ml];
-                    float* __restrict__ rowp = base + (size_t)(m0_l + ml) * p.out_sM;
+                    float* __restrict__ rowp = row0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * sM;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const float v = acc[i][j][r] + bias;
+                        const float v = acc[i][j][r];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
                         rowp[j * 32] = v;
@@ -317,7 +339,6 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
                     const int ml = wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const int m = m0_l + ml;
                     if (m >= p.M) continue;
-                    const float bias = bias_s[ml];
                     int co = m, phs = 0;
                     if (p.up_r) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }
                     float* __restrict__ rowp = p.out + (size_t)b_l * p.out_sB + (size_t)co * p.out_sM;
@@ -325,7 +346,7 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
                     for (int j = 0; j < TN; ++j) {
                         const int n = n0 + wn * (TN * 32) + j * 32 + l31;
                         if (n >= p.Tout) continue;
-                        const float v = acc[i][j][r] + bias;
+                        const float v = acc[i][j][r];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
                         if (p.ablate & 2) continue;
@@ -374,7 +395,7 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
             dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
         }
         const float* Ws = smem + (resident ? chunk : (f & 1)) * p.Wbuf + a_off;
-        const float* Xb = Xs0 + (f & 1) * p.xs_floats + b_off;
+        const float* Xb = Xs0 + (f & 1) * XSF + b_off;
         // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16 LDS
         // fragment reads are issued ahead of 16 MFMAs; B offsets come from the LDS table, prefetched one ahead.
         int ks = (p.ablate & 1) ? nks : 0;
@@ -482,7 +503,8 @@ int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.
 size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab) {
     const int slabW = (BN - 1) * stride + k;
     const int rowStride = ceil_div(slabW, stride) * stride;
-    const int xs = ((CC * rowStride + 255) & ~255) + 4;
+    const int img = CC * rowStride;
+    const int xs = (img <= 8 * 256 ? 8 : 16) * 256 + 4;            // XSF of the NU variant the launcher will pick
     const size_t koff_bytes = (size_t)((((k * CC / 2) + 7) & ~3) + 4) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
            (size_t)BM * sizeof(float) + 128;
