@@ -33,7 +33,7 @@ class FcProf(C.Structure):
                 ("launches", C.c_int32), ("reserved", C.c_int32)]
 
 
-FC_PROF_CLASSES = 6
+FC_PROF_CLASSES = 48
 
 # every symbol include/funcodec_amd.h declares: name -> (restype, argtypes)
 _P = C.c_void_p

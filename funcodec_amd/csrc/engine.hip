@@ -92,10 +92,8 @@ struct Ctx {
 
 int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
-enum ProfClass { PC_CONV128 = 0, PC_CONV64 = 1, PC_CONV32 = 2, PC_LSTM = 3, PC_RVQ = 4, PC_OTHER = 5 };
-const char* kProfNames[FC_PROF_CLASSES] = {"conv_mfma_kernel<128,128,2,2>", "conv_mfma_kernel<64,256,1,4>",
-                                           "conv_mfma_kernel<32,256,1,4>", "lstm_step_kernel (whole recurrence, incl. gaps)",
-                                           "rvq_encode_kernel", "other"};
+const char* kLstmClass = "lstm_wave_kernel (whole recurrence of one SLSTM block, incl. launch gaps)";
+const char* kRvqClass = "rvq_encode_kernel<128>";
 
 }  // namespace
 
@@ -122,6 +120,14 @@ struct fc_engine {
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
+    std::vector<std::string> prof_names;     // class id -> kernel name as rocprofv3 prints it
+    int prof_class(const std::string& name) {
+        for (size_t i = 0; i < prof_names.size(); ++i)
+            if (prof_names[i] == name) return (int)i;
+        if ((int)prof_names.size() >= FC_PROF_CLASSES) return FC_PROF_CLASSES - 1;
+        prof_names.push_back(name);
+        return (int)prof_names.size() - 1;
+    }
 };
 
 namespace {
@@ -467,7 +473,16 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     const double by = 4.0 * cx.B * ((double)L.cin * Tin * (s1.used ? 2 : 1) + (double)L.cout * g.Tout);
     hipError_t er;
     {
-        ProfSpan sp(e, cx, L.BM == 128 ? PC_CONV128 : (L.BM == 64 ? PC_CONV64 : PC_CONV32), fl, by);
+        int cls = 0;
+        if (e->profiling) {
+            int mode = 0, nu = 0;
+            fc::conv_variant(c, &mode, &nu);
+            char nm[64];
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d>", L.BM, L.BN, L.BM == 128 ? 2 : 1,
+                     L.BM == 128 ? 2 : 4, mode, nu);
+            cls = e->prof_class(nm);
+        }
+        ProfSpan sp(e, cx, cls, fl, by);
         er = fc::launch_conv(c, cx.st);
     }
     if (er != hipSuccess) { cx.err = 1; g_err = "conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); return out; }
@@ -495,14 +510,20 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
     cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H * (2 * L - 1);
     cx.launches += T + L;
     if (!cx.dry && !cx.err) {
-        ProfSpan sp(e, cx, PC_LSTM, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
+        ProfSpan sp(e, cx, e->profiling ? e->prof_class(kLstmClass) : 0, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
         hipError_t er = hipMemsetAsync(state, 0, (size_t)3 * L * B * H * sizeof(float), cx.st);
         const float* w[FC_LSTM_MAX_LAYERS] = {nullptr};
         const float* bias[FC_LSTM_MAX_LAYERS] = {nullptr};
         for (int l = 0; l < L; ++l) { w[l] = l == 0 ? lb.layers[0].whh : lb.layers[l].wcat; bias[l] = lb.layers[l].bperm; }
         float *h = state, *c = state + (size_t)2 * L * B * H;
-        for (int s = 0; s < T + L - 1 && er == hipSuccess; ++s)
-            er = fc::launch_lstm_wave(w, bias, xproj, h, c, y.raw, B, H, T, L, s, cx.st);
+        static const int persist_env = getenv("FC_LSTM_PERSIST") ? atoi(getenv("FC_LSTM_PERSIST")) : 1;
+        if (persist_env && fc::lstm_persist_supported(B, H, L, e->device)) {
+            // the tail of the (zeroed) state block doubles as the barrier words: c is not used by this path
+            er = fc::launch_lstm_persist(w[0], w[1], bias[1], xproj, h, y.raw, (unsigned*)c, B, H, T, cx.st);
+        } else {
+            for (int s = 0; s < T + L - 1 && er == hipSuccess; ++s)
+                er = fc::launch_lstm_wave(w, bias, xproj, h, c, y.raw, B, H, T, L, s, cx.st);
+        }
         if (er != hipSuccess) { cx.err = 1; g_err = std::string("lstm step failed: ") + hipGetErrorString(er); }
     }
     return y;
@@ -586,7 +607,7 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
         // encoder output permuted to [B,Tf,D] (seanet_encoder.py:175) with the last GroupNorm applied
         if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, emb, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
             return fail("combine launch failed");
-        ProfSpan sp(e, cx, PC_RVQ, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D, 0.0);
+        ProfSpan sp(e, cx, e->profiling ? e->prof_class(kRvqClass) : 0, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D, 0.0);
         if (fc::launch_rvq_encode(emb, B * Tf, D, e->arch.codebook_size, n_q, e->cb, e->enorm, codes, quantized, qbdt,
                                   sub_quants, Tf, cx.st) != hipSuccess)
             return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256})");
@@ -658,7 +679,7 @@ int fc_engine_profile_read(fc_engine* e, fc_prof* out) {
     if (!e || !out) return fail("null argument");
     for (int i = 0; i < FC_PROF_CLASSES; ++i) {
         memset(&out[i], 0, sizeof(fc_prof));
-        strncpy(out[i].kernel, kProfNames[i], sizeof(out[i].kernel) - 1);
+        if (i < (int)e->prof_names.size()) strncpy(out[i].kernel, e->prof_names[i].c_str(), sizeof(out[i].kernel) - 1);
     }
     if (!e->spans.empty()) HIP_TRY(hipEventSynchronize(e->spans.back().b));
     for (auto& s : e->spans) {

@@ -43,6 +43,7 @@ bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual);
 int conv_wgs_per_cu(int BM);
 std::vector<int> conv_koff_table(int k, int stride, int CC, int BN);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
+void conv_variant(const ConvLaunch& c, int* mode, int* nu);    // template instantiation launch_conv() picks
 
 // Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)
 hipError_t launch_gn_finalize(const double* partials, int nblk, double count, const float* gamma,
@@ -79,5 +80,10 @@ hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float*
 // bias[l>=1] = perm(b_ih + b_hh); h [L][2][B][H] and c [L][B][H] zero-initialised by the caller.
 hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, const float* xproj, float* h, float* c,
                             float* y, int B, int H, int T, int L, int s, hipStream_t st);
+
+// Persistent 2-layer recurrence (one launch); sync = 2 zeroed words; h [2][2][B][H] zeroed by the caller.
+hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* h, float* y,
+                               unsigned* sync, int B, int H, int T, hipStream_t st);
+bool lstm_persist_supported(int B, int H, int L, int device);
 
 }  // namespace fc

@@ -553,6 +553,15 @@ static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 gri
     return launch_conv_m<BM, BN, WM, WN, 0>(a, total, grid, lds, st);
 }
 
+// which template instantiation launch_conv() will pick (profiling labels)
+void conv_variant(const ConvLaunch& c, int* mode, int* nu) {
+    const ConvArgs a = make_args(c);
+    *nu = a.CC * a.rowStride <= 256 * 8 ? 8 : 16;
+    if (c.s1.ptr) *mode = c.elu ? 4 : 3;
+    else if (c.s0.aff || c.s0.div || c.elu) *mode = c.elu ? 2 : 1;
+    else *mode = 0;
+}
+
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
@@ -1134,6 +1143,175 @@ hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, con
         default: hipLaunchKernelGGL(lstm_wave_kernel<0>, grid, block, 0, st, a); break;
     }
     return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
+// Persistent 2-layer LSTM: ONE launch for the whole recurrence.  Workgroup j keeps the 16 gate rows of layer 0
+// (W_hh0) and of layer 1 ([W_ih1 | W_hh1]) for its 4 hidden units in REGISTERS for all T steps (192 KiB per CU,
+// one 4-wave workgroup per CU owns the whole 512-register file), cell states stay in registers too; per wavefront
+// step only h0(s-1) / h1(s-2) (64 KiB each, L2 resident) are exchanged through HBM-backed buffers, behind one
+// grid-wide barrier (agent-scope release -> monotonic counter -> agent-scope acquire, bounded spin: on a timeout
+// the error word is set and every workgroup runs to completion instead of hanging).
+// Same arithmetic order as lstm_wave_kernel (bit-identical results).
+// -------------------------------------------------------------------------------------------------
+struct LstmPersistArgs {
+    const float *w0, *w1, *bias1, *xproj;
+    float *h, *y;
+    unsigned* sync;      // [0] arrival counter, [1] error flag; zeroed by the caller before every launch
+    int B, H, T;
+};
+
+// Hidden states are exchanged WRITE-THROUGH: stores carry sc1 (relaxed agent-scope atomics) and loads carry sc1
+// (buffer loads with aux = sc1, L1 bypass), so the barrier needs neither an L2 write-back nor an L1 invalidate
+// (each ~1.7 us on this chip) -- only: every storing wave drains vmcnt, one lane bumps a monotonic counter and polls it.
+__device__ __forceinline__ void lstm_grid_barrier(unsigned* sync, unsigned target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its own write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 255u) == 0u) {
+                if (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1u << 21)) { __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load_h_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16 /* sc1 */);
+    return __builtin_bit_cast(f32x4, r);
+}
+
+template <int NS, int NBT>
+__global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistArgs p) {
+    __shared__ f32x4 red[2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int H = p.H, B = p.B, T = p.T;
+    const int blk = blockIdx.x;
+    const int nwg = gridDim.x;
+    const int kslice = NS * 16;                      // H / 4 waves
+    const size_t BH = (size_t)B * H;
+    // ---- weights -> registers (once)
+    f32x4 a0[NS], a1i[NS], a1h[NS];
+    {
+        const float* w0r = p.w0 + ((size_t)blk * 16 + r16) * H + wid * kslice + 4 * g;
+        const float* w1r = p.w1 + ((size_t)blk * 16 + r16) * 2 * H + wid * kslice + 4 * g;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            a0[q] = *(const f32x4*)(w0r + 16 * q);
+            a1i[q] = *(const f32x4*)(w1r + 16 * q);
+            a1h[q] = *(const f32x4*)(w1r + H + 16 * q);
+        }
+    }
+    float cst[NBT];                                  // cell state of (batch row, unit): wave 0 -> layer 0, wave 1 -> layer 1
+#pragma unroll
+    for (int nb = 0; nb < NBT; ++nb) cst[nb] = 0.f;
+    const f32x4 bias1 = *(const f32x4*)(p.bias1 + (size_t)blk * 16 + 4 * g);
+    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, (int)(4 * BH * sizeof(float)), 0x00020000);
+
+    for (int s = 0; s <= T; ++s) {
+        const bool act0 = s < T, act1 = s >= 1;
+        const unsigned h0p = (unsigned)(((size_t)((s + 1) & 1) * BH) * 4);          // h0(s-1): parity (s-1)&1  (byte offsets)
+        const unsigned h1p = (unsigned)((2 * BH + (size_t)(s & 1) * BH) * 4);       // h1(s-2): parity (s-2)&1
+        float* h0o = p.h + (size_t)(s & 1) * BH;                           // h0(s)
+        float* h1o = p.h + 2 * BH + (size_t)((s + 1) & 1) * BH;            // h1(s-1)
+#pragma unroll
+        for (int nb = 0; nb < NBT; ++nb) {
+            const int brow = nb * 16 + r16;
+            const bool bvalid = brow < B;
+            const unsigned hoff = (unsigned)(((size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g) * 4);
+            f32x4 xp = {0.f, 0.f, 0.f, 0.f};
+            if (wid == 0 && act0)
+                xp = *(const f32x4*)(p.xproj + ((size_t)s * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
+            f32x4 b0[NS], b1[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                b0[q] = load_h_sc1(hrsrc, h0p + hoff + 64 * q);
+                b1[q] = load_h_sc1(hrsrc, h1p + hoff + 64 * q);
+                if (!bvalid) { b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            }
+            f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c1a = {0.f, 0.f, 0.f, 0.f}, c1b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (q & 1) c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0b, 0, 0, 0);
+                    else c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0a, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (q & 1) c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1b, 0, 0, 0);
+                    else c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (q & 1) c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1b, 0, 0, 0);
+                    else c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1a, 0, 0, 0);
+                }
+            }
+            red[0][wid][lane] = c0a + c0b;
+            red[1][wid][lane] = c1a + c1b;
+            __syncthreads();
+            if (wid < 2) {
+                const int layer = wid;
+                const bool act = layer ? act1 : act0;
+                f32x4 sg = red[layer][0][lane];
+                for (int w = 1; w < 4; ++w) sg = sg + red[layer][w][lane];
+                const f32x4 add = layer ? bias1 : xp;
+                if (act && bvalid) {
+                    const float gi = sigmoid_f(sg[0] + add[0]);
+                    const float gf = sigmoid_f(sg[1] + add[1]);
+                    const float gg = tanhf(sg[2] + add[2]);
+                    const float go = sigmoid_f(sg[3] + add[3]);
+                    const float cn = gf * cst[nb] + gi * gg;
+                    const float hn = go * tanhf(cn);
+                    cst[nb] = cn;
+                    const size_t ci = (size_t)brow * H + (size_t)blk * 4 + g;
+                    if (layer == 0) __hip_atomic_store(&h0o[ci], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else { __hip_atomic_store(&h1o[ci], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); p.y[ci * T + (s - 1)] = hn; }
+                }
+            }
+            __syncthreads();
+        }
+        if (s < T) lstm_grid_barrier(p.sync, (unsigned)(s + 1) * (unsigned)nwg);
+    }
+}
+
+hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* h, float* y,
+                               unsigned* sync, int B, int H, int T, hipStream_t st) {
+    LstmPersistArgs a;
+    a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.h = h; a.y = y; a.sync = sync; a.B = B; a.H = H; a.T = T;
+    const int nbt = (B + 15) / 16;
+    dim3 grid(H / 4), block(256);
+#define FC_LP(NS, NBT) hipLaunchKernelGGL((lstm_persist_kernel<NS, NBT>), grid, block, 0, st, a)
+    if (H == 1024 && nbt == 1) FC_LP(16, 1);
+    else if (H == 1024 && nbt == 2) FC_LP(16, 2);
+    else if (H == 512 && nbt == 1) FC_LP(8, 1);
+    else if (H == 512 && nbt == 2) FC_LP(8, 2);
+    else return hipErrorInvalidValue;
+#undef FC_LP
+    return hipGetLastError();
+}
+
+// can the persistent kernel be used? (every workgroup must be co-resident: one per CU)
+bool lstm_persist_supported(int B, int H, int L, int device) {
+    if (L != 2 || (H != 1024 && H != 512) || B > 32) return false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+    return prop.multiProcessorCount >= H / 4;
 }
 
 }  // namespace fc

@@ -147,14 +147,15 @@ int fc_engine_work(const fc_engine* e, int B, int T, int n_q, fc_work* out);
  * bracketed by hipEventRecord on the caller's stream.  fc_engine_profile_read() synchronises on the
  * last event, returns per-kernel-class totals accumulated since the last read and resets them. */
 typedef struct fc_prof {
-    char    kernel[64];      /* e.g. "conv_mfma_kernel<128,128,2,2>" */
+    char    kernel[64];      /* named like rocprofv3 prints it, e.g. "conv_mfma_kernel<128, 128, 2, 2, 0, 8>" */
     double  total_ms;        /* sum of event-to-event durations */
     double  flops, bytes;    /* algorithmic work of those launches */
     int32_t launches;
     int32_t reserved;
 } fc_prof;
-#define FC_PROF_CLASSES 6
+#define FC_PROF_CLASSES 48
 int fc_engine_profile(fc_engine* e, int enable);
+/* fills out[0..n) (n <= FC_PROF_CLASSES, returned through *n_out); unused entries have launches == 0 */
 int fc_engine_profile_read(fc_engine* e, fc_prof* out /* [FC_PROF_CLASSES] */);
 
 #ifdef __cplusplus

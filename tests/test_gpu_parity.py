@@ -312,3 +312,30 @@ def test_full_size_matches_oracle_on_a_sampled_utterance(config_b):
     assert rep["frames_bad"] <= 2, rep
     if rep["frames_bad"] == 0:
         assert rms(r["recon"][3:4], o["recon_speech"]) < WAV_RMS_TOL
+
+
+def test_lstm_launch_wavefront_fallback_matches_persistent_kernel():
+    """The persistent recurrence (one launch, grid barrier) and the per-step launch path (FC_LSTM_PERSIST=0, used when
+    the workgroups cannot all be co-resident) must agree bit for bit and with torch."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, torch, numpy as np\n"
+        "sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle'); sys.path.insert(0, '.')\n"
+        "from helpers import engine_for, oracle_for\n"
+        "m = engine_for('ds640', 0); orc = oracle_for('ds640', 0)\n"
+        "x = torch.randn(5, 1024, 11, generator=torch.Generator().manual_seed(6))\n"
+        "got = m.engine.lstm_forward('encoder.model.16.lstm', x).cpu()\n"
+        "ref = orc._slstm(x, 'encoder.model.16.lstm')\n"
+        "assert (got - ref).abs().max().item() < 1e-5\n"
+        "np.save(sys.argv[1], got.numpy())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        path = os.path.join(root, "gpurun_out", f"_lstm_{flag}.npy")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        env = dict(os.environ, FC_LSTM_PERSIST=flag)
+        subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=env, timeout=300)
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1])
