@@ -715,7 +715,7 @@ hipError_t launch_transpose_btd(const float* in, int B, int T, int D, float* out
 //      |e|^2   : precomputed at load time (engine.hip), sequential d = 0..D-1, squares rounded separately.
 // =================================================================================================
 template <int D>
-__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict__ x, int N, int K, int nq,
+__global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict__ x, int N, int K, int nq,
                                                          const float* __restrict__ cb, const float* __restrict__ enorm,
                                                          int64_t* __restrict__ codes, float* __restrict__ quant,
                                                          float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf) {
@@ -723,21 +723,22 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
     __shared__ __attribute__((aligned(16))) float R[16][D];
     __shared__ __attribute__((aligned(16))) float Q[16][D];
     __shared__ float xn[16];
-    __shared__ float bestv[4][16];
-    __shared__ int besti[4][16];
+    __shared__ float bestv[8][16];
+    __shared__ int besti[8][16];
     __shared__ int sel[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
     const int row0 = blockIdx.x * 16;
 
-    for (int e = tid; e < 16 * D; e += 256) {
+    for (int e = tid; e < 16 * D; e += 512) {
         const int r = e / D, d = e - r * D;
         const int n = row0 + r;
         R[r][d] = n < N ? x[(size_t)n * D + d] : 0.f;
         Q[r][d] = 0.f;
     }
-    const int codes_per_wave = K >> 2;
+    const int codes_per_wave = (K >> 3) < 16 ? 16 : (K >> 3);   // 8 waves: two per SIMD hide the codebook-row load latency
+    const bool wactive = wid * codes_per_wave < K;            // small codebooks keep only K/16 waves busy
 
     for (int i = 0; i < nq; ++i) {
         __syncthreads();
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
         // two code tiles per iteration: independent accumulators hide the 40-cycle dependent-MFMA latency and
         // keep 2*NQ4 16-byte codebook loads in flight; each (row, code) chain keeps its own d order.
         constexpr bool TWO = (D <= 128);
-        for (int nt = 0; nt < codes_per_wave; nt += (TWO ? 32 : 16)) {
+        for (int nt = 0; wactive && nt < codes_per_wave; nt += (TWO ? 32 : 16)) {
             const int codeA = wid * codes_per_wave + nt + r16;
             const bool hasB = TWO && (nt + 16 < codes_per_wave);
             const int codeB = hasB ? codeA + 16 : codeA;
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
         if (tid < 16) {
             float bv = bestv[0][tid];
             int bi = besti[0][tid];
-            for (int w = 1; w < 4; ++w) {
+            for (int w = 1; w < 8; ++w) {
                 const float ov = bestv[w][tid];
                 const int oi = besti[w][tid];
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
             if (row0 + tid < N) codes[(size_t)i * N + row0 + tid] = (int64_t)bi;
         }
         __syncthreads();
-        for (int e = tid; e < 16 * D; e += 256) {
+        for (int e = tid; e < 16 * D; e += 512) {
             const int r = e / D, d = e - r * D;
             const float qv = cbi[(size_t)sel[r] * D + d];
             R[r][d] = R[r][d] - qv;
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    for (int e = tid; e < 16 * D; e += 256) {
+    for (int e = tid; e < 16 * D; e += 512) {
         const int r = e / D, d = e - r * D;
         const int n = row0 + r;
         if (n >= N) continue;
@@ -858,8 +859,8 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* __restrict
 hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* enorm,
                              int64_t* codes, float* quant, float* quant_bdt, float* subq, int Tf, hipStream_t st) {
     if (N <= 0) return hipSuccess;
-    if (K % 64 != 0) return hipErrorInvalidValue;
-    dim3 grid(ceil_div(N, 16)), block(256);
+    if (K % 16 != 0 || (K > 128 && K % 128 != 0)) return hipErrorInvalidValue;
+    dim3 grid(ceil_div(N, 16)), block(512);
 #define FC_RVQ_CASE(DD)                                                                                            \
     case DD:                                                                                                       \
         hipLaunchKernelGGL(rvq_encode_kernel<DD>, grid, block, 0, st, x, N, K, nq, cb, enorm, codes, quant, quant_bdt, \
