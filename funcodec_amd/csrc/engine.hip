@@ -278,16 +278,20 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
         if (L.small_n && L.M <= 256) { L.BM = 32; L.BN = 128; }   // too few 128x128 tiles at the bottleneck rate
     } else if (L.M > 32) { L.BM = 64; L.BN = 256; }
     else { L.BM = 32; L.BN = 256; }
-    // channels per K-chunk: as many as fit (a) the register-staged slab, (b) K-chunk <= 64, (c) 80 KiB of LDS
-    // (two workgroups per CU: one stages while the other feeds the matrix cores)
+    // channels per K-chunk: as many as fit (a) the register-staged slab, (b) K-chunk <= 64, (c) half of the LDS
+    // (two workgroups per CU).  Layers with >= 3 M tiles get their input materialised (run_conv) and therefore
+    // always run the PLAIN variant: no affine tables, and the 16-element staging variant has no register pressure.
+    const bool plain = ceil_div_i(L.M, L.BM) >= 3 || !L.has_norm;
+    const bool dual_eff = L.dual && !plain;
     int cin_p2 = 2;
     while (cin_p2 < L.cin) cin_p2 *= 2;
     int cc = 2;
     for (;;) {
         const int n = cc * 2;
         if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
-        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN, L.BM, L.dual)) break;
-        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, L.dual ? 2 : 1) > (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) break;
+        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN, L.BM, dual_eff)) break;
+        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1)) >
+            (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) break;
         cc = n;
     }
     L.CC = cc;

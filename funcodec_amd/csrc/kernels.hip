@@ -197,9 +197,12 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
         }
         bool all_valid = false;                       // current register contents need no padding mask
         // loads are unconditional (masked elements read offset 0) and issued back to back
-        auto load_slab = [&](int item) {
-            const int tile = t_begin + item / p.nchunk;
-            const int c0 = (item - (tile - t_begin) * p.nchunk) * p.CC;
+        // (tile, chunk) cursors advance incrementally: no integer divisions on the per-chunk path
+        int ld_tile = t_begin, ld_chunk = 0, wr_chunk = 0;
+        auto load_slab = [&](int) {
+            const int tile = ld_tile;
+            const int c0 = ld_chunk * p.CC;
+            if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
             const int tbase = tile * BN * p.stride - p.padL;
             vmask = inmask;
             if (p.ablate & 4) return;
@@ -237,8 +240,9 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
         };
         // branch-free per element: lanes without an element write a dummy slot, padding lanes select 0
         // branch-free per element; interior tiles (the common case) skip the padding select
-        auto write_slab_t = [&](int item, char* Xd, auto use_div, auto masked) {
-            const int c0 = (item % p.nchunk) * p.CC;
+        auto write_slab_t = [&](int, char* Xd, auto use_div, auto masked) {
+            const int c0 = wr_chunk * p.CC;
+            if (++wr_chunk == p.nchunk) wr_chunk = 0;
             const char* t0 = (const char*)(tab0 + c0);
             const char* t1 = (const char*)(tab1 + c0);
             // all table reads first: LDS stores below may alias them as far as the compiler knows, and interleaving
