@@ -107,3 +107,195 @@ class Token2Speech:
     def __call__(self, tokens: torch.Tensor, bit_width: int = None) -> torch.Tensor:
         """tokens [B,Tf,n_q] int64 -> waveform [B,1,Tf*hop]"""
         return self.s2t(tokens, bit_width=bit_width, run_mod="decode")[2]
+
+
+# ================================================================================================
+# CLI / batch pipeline: same function names, arguments and output files as the reference's
+# funcodec/bin/codec_inference.py:164-580 (egs/LibriTTS/codec/encoding_decoding.sh drives exactly this).
+# ================================================================================================
+def save_audio(wav, path, sample_rate: int, rescale: bool = False):
+    from ..io import save_audio as _save
+    _save(wav, str(path), sample_rate, rescale)
+
+
+def inference_modelscope(
+        output_dir: Optional[str] = None,
+        batch_size: int = 1,
+        dtype: str = "float32",
+        ngpu: int = 1,
+        seed: int = 0,
+        num_workers: int = 0,
+        log_level: Union[int, str] = "INFO",
+        key_file: Optional[str] = None,
+        config_file: Optional[str] = "config.yaml",
+        model_file: Optional[str] = "model.pth",
+        model_tag: Optional[str] = None,
+        allow_variable_data_keys: bool = True,
+        streaming: bool = False,
+        sampling_rate: int = 16_000,
+        bit_width: int = 8_000,
+        param_dict: Optional[dict] = None,
+        use_scale: Optional[bool] = True,
+        **kwargs,
+):
+    """Returns ``_forward(data_path_and_name_and_type | raw_inputs, output_dir_v2, param_dict)`` (reference :164-382)."""
+    import os
+    from .. import io as fio
+    if param_dict is not None:
+        kwargs.update(param_dict)
+    if ngpu > 1:
+        raise NotImplementedError("only single GPU decoding is supported")       # reference :190-191
+    if ngpu < 1:
+        raise RuntimeError("funcodec_amd runs on MI355X only (ngpu must be >= 1); use the reference for CPU decoding")
+    logging.basicConfig(level=log_level, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    torch.manual_seed(seed)
+    my_model = Speech2Token.from_pretrained(model_tag=model_tag, config_file=config_file, model_file=model_file,
+                                            device="cuda", dtype=dtype, streaming=streaming,
+                                            sampling_rate=sampling_rate, bit_width=bit_width)
+
+    def _forward(data_path_and_name_and_type=None, raw_inputs=None, output_dir_v2: Optional[str] = None,
+                 param_dict: Optional[dict] = None):
+        if param_dict is not None:
+            kwargs.update(param_dict)
+        if data_path_and_name_and_type is None and raw_inputs is not None:
+            uttid = "utt"
+            if isinstance(raw_inputs, str):
+                uttid = os.path.basename(raw_inputs).rsplit(".")[0]
+                raw_inputs, sr = fio.read_wav(raw_inputs)
+                if sr != sampling_rate:
+                    raise NotImplementedError("resampling is not built yet (SURVEY.md §8f)")
+            if isinstance(raw_inputs, torch.Tensor):
+                raw_inputs = raw_inputs.numpy()
+            loader = [([uttid], dict(speech=torch.from_numpy(np.asarray(raw_inputs))[None, :],
+                                     speech_lengths=torch.tensor([raw_inputs.shape[0]], dtype=torch.int64)))]
+        else:
+            loader = fio.iter_batches(data_path_and_name_and_type, batch_size, key_file)
+        output_path = output_dir_v2 if output_dir_v2 is not None else output_dir
+        if output_path is not None:
+            os.makedirs(output_path, exist_ok=True)
+        if kwargs.get("file_sampling_rate") not in (None, sampling_rate):
+            raise NotImplementedError("file_sampling_rate != sampling_rate: resampling is not built yet (SURVEY.md §8f)")
+        indices_writer, sub_quants_writer = None, None
+        ark_indices = kwargs.get("indices_save_type") == "ark"
+        if kwargs.get("need_indices"):
+            if ark_indices:
+                indices_writer = fio.KaldiMatrixWriter(os.path.join(output_path, "indices"))
+            else:
+                indices_writer = open(os.path.join(output_path, "codecs.txt"), "wt")
+        if kwargs.get("need_sub_quants"):
+            sub_quants_writer = fio.KaldiMatrixWriter(os.path.join(output_path, "codec_emb"))
+
+        result_list = []
+        run_mod = kwargs.get("run_mod", "inference")
+        hop = my_model.model.quantizer.encoder_hop_length
+        for keys, batch in loader:
+            speech_length = batch.pop("speech_lengths")
+            bw = param_dict["bit_width"] if param_dict is not None and "bit_width" in param_dict else bit_width
+            token_id, token_emb, recon_speech, sub_quants = my_model(**batch, need_recon=True, bit_width=bw,
+                                                                     use_scale=use_scale, run_mod=run_mod)
+            for i, key in enumerate(keys):
+                if run_mod in ["decode", "decode_emb"]:
+                    codec_len = int(speech_length[i])
+                    ilen = codec_len * hop
+                else:
+                    ilen = int(speech_length[i])
+                    codec_len = int(math.ceil(ilen / hop))
+                recon_wav = recon_speech[i].cpu()[:, :ilen] if recon_speech is not None else None
+                if output_path is None:
+                    result_list.append({"key": key, "value": recon_wav})
+                    continue
+                if recon_wav is not None:
+                    save_audio(recon_wav, os.path.join(output_path, key + ".wav" if not key.endswith(".wav") else key),
+                               rescale=True, sample_rate=sampling_rate)
+                if token_id is not None and indices_writer is not None:
+                    if ark_indices:                                            # [T, n_q] float matrix (reference :292-294)
+                        mats = [x[:, i, :codec_len].cpu().float().numpy().T for x in token_id]
+                        indices_writer(key, np.concatenate(mats, axis=0))
+                    else:
+                        indices_writer.write(fio.format_codec_line(key, token_id, i, codec_len))
+                if sub_quants is not None and sub_quants_writer is not None:     # [T, n_q*D] (reference :301-311)
+                    sq = torch.cat(sub_quants, dim=-1).permute(1, 3, 0, 2)[i][:codec_len]
+                    sub_quants_writer(key, sq.reshape(sq.shape[0], -1).cpu().numpy())
+        for w in (indices_writer, sub_quants_writer):
+            if w is not None:
+                w.close()
+        return result_list
+
+    return _forward
+
+
+def inference(output_dir, batch_size, dtype, ngpu, seed, num_workers, log_level, data_path_and_name_and_type, key_file,
+              config_file, model_file, model_tag, allow_variable_data_keys=True, streaming=False, sampling_rate=24_000,
+              bit_width=24_000, use_scale=True, **kwargs):
+    pipeline = inference_modelscope(output_dir=output_dir, batch_size=batch_size, dtype=dtype, ngpu=ngpu, seed=seed,
+                                    num_workers=num_workers, log_level=log_level, key_file=key_file, config_file=config_file,
+                                    model_file=model_file, model_tag=model_tag,
+                                    allow_variable_data_keys=allow_variable_data_keys, streaming=streaming,
+                                    sampling_rate=sampling_rate, bit_width=bit_width, use_scale=use_scale, **kwargs)
+    return pipeline(data_path_and_name_and_type, raw_inputs=None)
+
+
+def _str2bool(v: str) -> bool:
+    return str(v).lower() in ("true", "1", "yes", "y", "t")
+
+
+def _str2triple(v: str):
+    a, b, c = v.split(",")
+    return a.strip(), b.strip(), c.strip()
+
+
+def get_parser():
+    """Same flags (names, types, defaults) as the reference parser (:428-558)."""
+    import argparse
+    p = argparse.ArgumentParser(description="Speech Tokenizer", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--log_level", type=lambda x: x.upper(), default="INFO",
+                   choices=("CRITICAL", "ERROR", "WARNING", "INFO", "DEBUG", "NOTSET"))
+    p.add_argument("--output_dir", type=str, required=False)
+    p.add_argument("--ngpu", type=int, default=0)
+    p.add_argument("--gpuid_list", type=str, default="")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--dtype", default="float32", choices=["float16", "float32", "float64"])
+    p.add_argument("--num_workers", type=int, default=0)
+    g = p.add_argument_group("Input data related")
+    g.add_argument("--data_path_and_name_and_type", type=_str2triple, required=False, action="append")
+    g.add_argument("--key_file", type=lambda s: None if s in ("none", "None", "null", "") else s)
+    g.add_argument("--allow_variable_data_keys", type=_str2bool, default=False)
+    g = p.add_argument_group("The model configuration related")
+    g.add_argument("--config_file", type=str)
+    g.add_argument("--model_file", type=str)
+    g.add_argument("--model_tag", type=str)
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--sampling_rate", type=int, default=24_000)
+    p.add_argument("--file_sampling_rate", type=int, default=None)
+    p.add_argument("--bit_width", type=int, default=16_000)
+    p.add_argument("--use_scale", type=_str2bool, default=True)
+    g.add_argument("--need_indices", type=_str2bool)
+    g.add_argument("--indices_save_type", type=str, default="text")
+    g.add_argument("--need_sub_quants", type=_str2bool)
+    g.add_argument("--run_mod", type=str, choices=["inference", "encode", "decode", "decode_emb"], default="inference")
+    g.add_argument("--stat_flops", type=_str2bool, default=False)
+    return p
+
+
+def main(cmd=None):
+    """One process per GPU; the job index and the GPU come from the suffix of --output_dir (``output.JOB``) and
+    --gpuid_list exactly as in the reference (:561-580); on ROCm the mask is HIP_VISIBLE_DEVICES and the process then
+    uses device 0 (the reference's set_device(int(gpuid)) after masking is only correct for gpuid 0)."""
+    import os
+    import sys
+    print(" ".join(sys.argv), file=sys.stderr)
+    args = get_parser().parse_args(cmd)
+    if args.file_sampling_rate is None:
+        args.file_sampling_rate = args.sampling_rate
+    kwargs = vars(args)
+    gpus = [g for g in args.gpuid_list.split(",") if g != ""]
+    if gpus:
+        jobid = 1 if args.output_dir is None else int(args.output_dir.split(".")[-1])
+        os.environ["HIP_VISIBLE_DEVICES"] = gpus[(jobid - 1) % len(gpus)]
+    kwargs.pop("gpuid_list", None)
+    kwargs.pop("stat_flops", None)
+    inference(**kwargs)
+
+
+if __name__ == "__main__":
+    main()

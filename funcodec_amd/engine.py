@@ -27,6 +27,11 @@ class CodecEngine:
     """One engine per (device, checkpoint).  Calls on one engine are serialised by the caller,
     like a torch module's forward."""
 
+    #: utterances processed per engine call.  Every op of the path is per-utterance, so results do not depend on it
+    #: (tests/test_gpu_parity.py::test_full_size_determinism_and_batch_independence); it bounds the workspace
+    #: (~0.57 GB per 10 s utterance for ds640) and keeps the persistent LSTM kernel (B <= 32) on its fast path.
+    micro_batch = 16
+
     def __init__(self, arch: ArchSpec, device: "torch.device | str | int" = "cuda:0"):
         self.lib = _lib.load()
         self.arch = arch
@@ -159,10 +164,23 @@ class CodecEngine:
         return t.to(device=self.device, dtype=dtype).contiguous()
 
     # -- hot path ------------------------------------------------------------------------------
+    @staticmethod
+    def _cat(parts, dims):
+        """Concatenate per-micro-batch result dicts along each tensor's batch dimension."""
+        out = {}
+        for k, dim in dims.items():
+            vals = [p[k] for p in parts]
+            out[k] = None if vals[0] is None else torch.cat(vals, dim)
+        return out
+
     def encode(self, wav: torch.Tensor, n_q: int, want_sub_quants: bool = True, want_enc_out: bool = False):
         """wav [B,T] -> dict(codes [n_q,B,Tf] i64, quantized [B,Tf,D], sub_quants [n_q,B,D,Tf], scale [B,1]|None)."""
         wav = self._dev(wav, torch.float32)
         B, T = wav.shape
+        if B > self.micro_batch:
+            parts = [self.encode(wav[i:i + self.micro_batch], n_q, want_sub_quants, want_enc_out)
+                     for i in range(0, B, self.micro_batch)]
+            return self._cat(parts, dict(codes=1, quantized=0, sub_quants=1, scale=0, enc_out=0))
         Tf, D = self.frames(T), self.arch.dimension
         dev = self.device
         codes = torch.empty((n_q, B, Tf), dtype=torch.int64, device=dev)
@@ -179,6 +197,10 @@ class CodecEngine:
     def encode_decode(self, wav: torch.Tensor, n_q: int, use_scale: bool = True, want_sub_quants: bool = True):
         wav = self._dev(wav, torch.float32)
         B, T = wav.shape
+        if B > self.micro_batch:
+            parts = [self.encode_decode(wav[i:i + self.micro_batch], n_q, use_scale, want_sub_quants)
+                     for i in range(0, B, self.micro_batch)]
+            return self._cat(parts, dict(codes=1, quantized=0, sub_quants=1, scale=0, recon=0))
         Tf, D = self.frames(T), self.arch.dimension
         dev = self.device
         codes = torch.empty((n_q, B, Tf), dtype=torch.int64, device=dev)
@@ -196,6 +218,9 @@ class CodecEngine:
         """tokens [B,Tf,n_q] i64 -> (wav [B,1,Tf*hop], emb [B,Tf,D])."""
         tokens = self._dev(tokens, torch.int64)
         B, Tf, n_q = tokens.shape
+        if B > self.micro_batch:
+            parts = [self.decode_codes(tokens[i:i + self.micro_batch]) for i in range(0, B, self.micro_batch)]
+            return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
         L = Tf * self.hop_length
         wav = torch.empty((B, 1, L), dtype=torch.float32, device=self.device)
         emb = torch.empty((B, Tf, self.arch.dimension), dtype=torch.float32, device=self.device)
@@ -210,6 +235,10 @@ class CodecEngine:
         B, Tf, D = emb.shape
         if D != self.arch.dimension:
             raise EngineError(f"embedding dim {D} != {self.arch.dimension}")
+        if B > self.micro_batch:
+            return torch.cat([self.decode_emb(emb[i:i + self.micro_batch],
+                                              None if scale is None else scale.reshape(-1)[i:i + self.micro_batch], out_len)
+                              for i in range(0, B, self.micro_batch)], 0)
         L = Tf * self.hop_length
         out_len = L if out_len is None else int(out_len)
         sc = None if scale is None else self._dev(scale.reshape(-1), torch.float32)

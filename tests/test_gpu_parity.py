@@ -1,6 +1,8 @@
 """`-m gpu` parity tests: every call goes through the C ABI (libfuncodec_amd.so) on a real MI355X and is
 compared with (a) the golden vectors produced by the real reference, (b) the oracle on the same seeded inputs,
 (c) size-independent properties at the benchmark size."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -339,3 +341,76 @@ def test_lstm_launch_wavefront_fallback_matches_persistent_kernel():
         subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=env, timeout=300)
         outs.append(np.load(path))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_micro_batching_and_large_batches_are_bit_identical():
+    """B = 37 > micro_batch: results must equal the per-utterance results bit for bit (also covers the LSTM batch-tile
+    tail, B % 16 != 0), and a 33-utterance single call exercises the per-step LSTM fallback (persistent kernel: B <= 32)."""
+    m = engine_for("ds320", 0)
+    wav = audio(37, 6400, 4242, "tones").cuda()
+    full = m.engine.encode_decode(wav, 32)
+    for i in (0, 15, 16, 36):
+        one = m.engine.encode_decode(wav[i:i + 1], 32)
+        assert torch.equal(one["codes"], full["codes"][:, i:i + 1]) and torch.equal(one["recon"], full["recon"][i:i + 1])
+    old = m.engine.micro_batch
+    try:
+        m.engine.micro_batch = 64
+        big = m.engine.encode_decode(wav[:33], 32)
+    finally:
+        m.engine.micro_batch = old
+    assert torch.equal(big["codes"], full["codes"][:, :33]) and torch.equal(big["recon"], full["recon"][:33])
+    tok = full["codes"].permute(1, 2, 0).contiguous()
+    w, e = m.engine.decode_codes(tok)
+    assert w.shape[0] == 37 and torch.equal(e, full["quantized"])
+
+
+def test_cli_encoding_decoding_pipeline(tmp_path):
+    """encoding_decoding.sh stage 1-3 equivalent: scp of ragged wavs -> codecs.txt + wavs -> decode from codecs.txt.
+    Shorter utterances are wrap-padded inside a batch exactly like the reference (quirk 4 in SURVEY.md §8b), so the
+    oracle is run on the same padded batch."""
+    from funcodec_amd import io as fio
+    from funcodec_amd.bin.codec_inference import main
+    from funcodec_amd.synth import make_checkpoint
+    cfg_path, pth_path = make_checkpoint(str(tmp_path / "model"), "ds320", 0)
+    orc = oracle_for("ds320", 0)
+    lens = [4000, 6400, 3333]
+    wavs = audio(3, 6400, 77, "tones")
+    scp = tmp_path / "wav.scp"
+    with open(scp, "wt") as f:
+        for i, n in enumerate(lens):
+            p = str(tmp_path / f"u{i}.wav")
+            fio.save_audio(wavs[i:i + 1, :n], p, 16000, rescale=False)
+            f.write(f"u{i} {p}\n")
+    out = str(tmp_path / "out.1")
+    main(["--ngpu", "1", "--gpuid_list", "0", "--output_dir", out, "--batch_size", "2", "--sampling_rate", "16000",
+          "--config_file", cfg_path, "--model_file", pth_path, "--bit_width", "8000", "--use_scale", "false",
+          "--need_indices", "true", "--run_mod", "inference",
+          "--data_path_and_name_and_type", f"{scp},speech,sound"])
+    lines = fio.read_scp(os.path.join(out, "codecs.txt"))
+    assert [k for k, _ in lines] == ["u0", "u1", "u2"]
+    # oracle on the same wrap-padded batches (batch 0 = u0,u1 ; batch 1 = u2)
+    batches = list(fio.iter_batches([(str(scp), "speech", "sound")], 2))
+    got = {k: fio.load_codec_json(v) for k, v in lines}
+    for keys, b in batches:
+        o = orc.inference(b["speech"], bit_width=8000, use_scale=False)
+        for i, k in enumerate(keys):
+            n = int(b["speech_lengths"][i])
+            cl = -(-n // 320)
+            ref = o["code_indices"][0][:, i, :cl].numpy().T
+            assert got[k].shape == (cl, 16) and np.array_equal(got[k], ref), k
+            y, sr = fio.read_wav(os.path.join(out, k + ".wav"))
+            assert sr == 16000 and y.shape[0] == n
+            r = o["recon_speech"][i, 0, :n].numpy()
+            r = r * min(0.99 / np.abs(r).max(), 1.0)                   # save_audio(rescale=True)
+            assert np.abs(y - r).max() < 2.0 / 32768
+    # decode stage: codecs.txt -> wavs (run_mod=decode, data type codec_json), ark index dump on the way
+    out2 = str(tmp_path / "dec.1")
+    main(["--ngpu", "1", "--gpuid_list", "0", "--output_dir", out2, "--batch_size", "1", "--sampling_rate", "16000",
+          "--config_file", cfg_path, "--model_file", pth_path, "--bit_width", "8000", "--run_mod", "decode",
+          "--data_path_and_name_and_type", f"{os.path.join(out, 'codecs.txt')},speech,codec_json"])
+    for k, v in lines:
+        y, _ = fio.read_wav(os.path.join(out2, k + ".wav"))
+        tok = torch.from_numpy(fio.load_codec_json(v))[None]
+        ref = orc.decode_codes(tok)[0][0, 0].numpy()
+        ref = ref * min(0.99 / np.abs(ref).max(), 1.0)
+        assert y.shape == ref.shape and np.abs(y - ref).max() < 2.0 / 32768
