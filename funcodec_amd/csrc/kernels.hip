@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
     float2* tab1 = tab0 + (PLAIN ? 0 : cin_pad);
     int* kofs_i = (int*)(tab1 + (DUAL ? cin_pad : 0));
     float* bias_s = (float*)(kofs_i + p.koff_n);
-    double* red = (double*)(bias_s + BM);             // [2 tiles in flight][8]
+    float2* red = (float2*)(bias_s + BM);             // [2 tiles in flight][256 matrix lanes] (sum, sum of squares)
 
     const int tid = threadIdx.x;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 8);    // 0 matrix, 1 staging
@@ -274,18 +274,40 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
             else write_slab_t(item, Xd, std::false_type(), std::true_type());
         };
 
+        // GroupNorm partial of a finished tile: fixed-order fp64 reduction of the 256 per-lane fp32 partials the
+        // matrix waves left in LDS (done here because the staging waves idle at the barrier anyway)
+        auto flush_stats = [&](int tile) {
+            if (!p.partials || wid != 0) return;
+            const float2* r = red + (tile & 1) * 256;
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float2 v = r[lane + 64 * j]; d1 += (double)v.x; d2 += (double)v.y; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                d1 += __shfl_xor(d1, o, 64);
+                d2 += __shfl_xor(d2, o, 64);
+            }
+            if (lane == 0) {
+                const int nblk = ntiles * gridDim.y;
+                const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
+                p.partials[slot_p] = d1;
+                p.partials[slot_p + 1] = d2;
+            }
+        };
         load_slab(0);
         write_slab(0, (char*)Xs0);
         if (nitems > 1) load_slab(1);
         __syncthreads();                              // B0: slab 0 + weights 0 visible
+        int st_tile = t_begin, st_chunk = 0;
         for (int f = 0; f < nitems; ++f) {
             if (f + 1 < nitems) {
                 write_slab(f + 1, (char*)(Xs0 + ((f + 1) & 1) * XSF));   // registers were filled one iteration ago
                 if (f + 2 < nitems) load_slab(f + 2);
             }
-            __syncthreads();                          // B(f+1)
+            __syncthreads();                          // B(f+1): the matrix waves have finished item f
+            if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
         }
-        __syncthreads();                              // final: matches the matrix waves' statistics hand-off
+        __syncthreads();                              // final (kept symmetric with the matrix role)
         return;
     }
 
@@ -364,27 +386,10 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
                 }
             }
         }
-        if (p.partials) {
-            double d1 = (double)s1, d2 = (double)s2;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                d1 += __shfl_xor(d1, o, 64);
-                d2 += __shfl_xor(d2, o, 64);
-            }
-            if (lane == 0) { red[par * 8 + wid] = d1; red[par * 8 + 4 + wid] = d2; }
-        }
+        // per-lane partials go to LDS as they are; the STAGING waves (which have slack) reduce them after the next
+        // barrier, so the matrix waves never pay for the cross-lane reduction
+        if (p.partials) red[par * 256 + rtid] = make_float2(s1, s2);
     };
-    // fixed-order combine of the 4 per-wave partials of a finished tile (after the barrier that publishes them)
-    auto flush_stats = [&](int tile, int par) {
-        if (p.partials && tid == 0) {
-            const int nblk = ntiles * gridDim.y;
-            const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
-            const double* r = red + par * 8;
-            p.partials[slot_p] = ((r[0] + r[1]) + r[2]) + r[3];
-            p.partials[slot_p + 1] = ((r[4] + r[5]) + r[6]) + r[7];
-        }
-    };
-
     dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
     if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
     __syncthreads();                                  // B0 (drains the weight DMA)
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
     const int a_off = hi * BM + wm * (TM * 32) + l31;
     const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
     const int nks = p.Kc >> 1;
-    int tile = t_begin, chunk = 0, pending_tile = -1;
+    int tile = t_begin, chunk = 0;
     for (int f = 0; f < nitems; ++f) {
         if (f + 1 < nitems && !resident) {
             const int nc = chunk + 1 == p.nchunk ? 0 : chunk + 1;
@@ -447,11 +452,9 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
             zero_acc();
         }
         __syncthreads();                              // B(f+1): slab f+1 + weights f+1 visible, buffers f free
-        if (pending_tile >= 0) { flush_stats(pending_tile, pending_tile & 1); pending_tile = -1; }
-        if (tile_done) { pending_tile = tile; ++tile; chunk = 0; } else { ++chunk; }
+        if (tile_done) { ++tile; chunk = 0; } else { ++chunk; }
     }
-    __syncthreads();                                  // final: publish the last tile's per-wave partials
-    if (pending_tile >= 0) flush_stats(pending_tile, pending_tile & 1);
+    __syncthreads();                                  // final: publishes the last tile's per-lane partials
 }
 
 static ConvArgs make_args(const ConvLaunch& c) {
@@ -511,7 +514,7 @@ size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, in
     const int xs = (img <= 8 * 256 ? 8 : 16) * 256 + 4;            // XSF of the NU variant the launcher will pick
     const size_t koff_bytes = (size_t)((((k * CC / 2) + 7) & ~3) + 4) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
-           (size_t)BM * sizeof(float) + 128;
+           (size_t)BM * sizeof(float) + 2 * 256 * 8;
 }
 
 // Thin tiles (BM <= 64) stage 8 elements per thread per chunk so that they fit 128 / 168 VGPRs and run 4 / 3
