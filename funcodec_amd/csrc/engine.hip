@@ -507,24 +507,25 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
     const int H = lb.H, B = cx.B, L = (int)lb.layers.size();
     float* xproj = cx.alloc<float>((size_t)T * B * 4 * H);
     run_conv(e, cx, lb.layers[0].inproj, src_of(in), fc::Src(), 0, T, xproj, (long long)4 * H, 1, (long long)B * 4 * H);
-    float* state = cx.alloc<float>((size_t)3 * L * B * H);   // h [L][2][B][H], c [L][B][H]
+    static const int persist_env = getenv("FC_LSTM_PERSIST") ? atoi(getenv("FC_LSTM_PERSIST")) : 1;
+    const bool persist = persist_env && fc::lstm_persist_supported(B, H, L, e->device);
+    // persistent kernel: barrier words + hidden-state history; per-step launches: h [L][2][B][H], c [L][B][H]
+    float* state = cx.alloc<float>(persist ? fc::lstm_persist_state_floats(B, H, T) : (size_t)3 * L * B * H);
     Act y;
     y.C = H; y.T = T;
     y.raw = cx.alloc<float>((size_t)B * H * T);
     cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H * (2 * L - 1);
-    cx.launches += T + L;
+    cx.launches += persist ? 2 : T + L;
     if (!cx.dry && !cx.err) {
         ProfSpan sp(e, cx, e->profiling ? e->prof_class(kLstmClass) : 0, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
-        hipError_t er = hipMemsetAsync(state, 0, (size_t)3 * L * B * H * sizeof(float), cx.st);
+        hipError_t er = hipMemsetAsync(state, 0, (persist ? fc::lstm_persist_clear_floats(B, H) : (size_t)3 * L * B * H) * sizeof(float), cx.st);
         const float* w[FC_LSTM_MAX_LAYERS] = {nullptr};
         const float* bias[FC_LSTM_MAX_LAYERS] = {nullptr};
         for (int l = 0; l < L; ++l) { w[l] = l == 0 ? lb.layers[0].whh : lb.layers[l].wcat; bias[l] = lb.layers[l].bperm; }
-        float *h = state, *c = state + (size_t)2 * L * B * H;
-        static const int persist_env = getenv("FC_LSTM_PERSIST") ? atoi(getenv("FC_LSTM_PERSIST")) : 1;
-        if (persist_env && fc::lstm_persist_supported(B, H, L, e->device)) {
-            // the tail of the (zeroed) state block doubles as the barrier words: c is not used by this path
-            er = fc::launch_lstm_persist(w[0], w[1], bias[1], xproj, h, y.raw, (unsigned*)c, B, H, T, cx.st);
+        if (persist) {
+            if (er == hipSuccess) er = fc::launch_lstm_persist(w[0], w[1], bias[1], xproj, state, y.raw, B, H, T, cx.st);
         } else {
+            float *h = state, *c = state + (size_t)2 * L * B * H;
             for (int s = 0; s < T + L - 1 && er == hipSuccess; ++s)
                 er = fc::launch_lstm_wave(w, bias, xproj, h, c, y.raw, B, H, T, L, s, cx.st);
         }

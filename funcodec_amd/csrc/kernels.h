@@ -82,8 +82,10 @@ hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, con
                             float* y, int B, int H, int T, int L, int s, hipStream_t st);
 
 // Persistent 2-layer recurrence (one launch); sync = 2 zeroed words; h [2][2][B][H] zeroed by the caller.
-hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* h, float* y,
-                               unsigned* sync, int B, int H, int T, hipStream_t st);
+hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* state, float* y,
+                               int B, int H, int T, hipStream_t st);
+size_t lstm_persist_state_floats(int B, int H, int T);   // barrier words + zero slot + hidden-state history of both layers
+size_t lstm_persist_clear_floats(int B, int H);
 bool lstm_persist_supported(int B, int H, int L, int device);
 
 }  // namespace fc

@@ -1156,53 +1156,61 @@ hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, con
 // -------------------------------------------------------------------------------------------------
 // Persistent 2-layer LSTM: ONE launch for the whole recurrence.  Workgroup j keeps the 16 gate rows of layer 0
 // (W_hh0) and of layer 1 ([W_ih1 | W_hh1]) for its 4 hidden units in REGISTERS for all T steps (192 KiB per CU,
-// one 4-wave workgroup per CU owns the whole 512-register file), cell states stay in registers too; per wavefront
-// step only h0(s-1) / h1(s-2) (64 KiB each, L2 resident) are exchanged through HBM-backed buffers, behind one
-// grid-wide barrier (agent-scope release -> monotonic counter -> agent-scope acquire, bounded spin: on a timeout
-// the error word is set and every workgroup runs to completion instead of hanging).
-// Same arithmetic order as lstm_wave_kernel (bit-identical results).
+// one 4-wave workgroup per CU owns the whole 512-register file), cell states stay in registers too.
+//
+// Hidden-state exchange.  Every wavefront step writes h0(s) / h1(s-1) into a HISTORY buffer that is never
+// overwritten inside one launch ([T+1][B][H] per layer, slot 0 = zeros).  Stores are write-through (sc1), so when a
+// wave's vmcnt drains its values are in memory; the consumers read slot s only after the grid barrier of step s-1 and
+// nobody has touched those addresses before in this launch, so no cache on the chip can hold a stale copy of them:
+// the loads are PLAIN loads, the first workgroup of an XCD to touch a line pulls it over the fabric and the other 31
+// hit that XCD's L2 (with double-buffered h and sc1 loads every workgroup fetched all 128 KiB over the fabric every
+// step: 32 MiB per step, the largest term of the step time).
+//
+// Grid barrier: 16 arrival counters on separate cache lines (16 arrivals each instead of 256 atomics serialised on
+// one address), polled by the 16 low lanes of wave 0 with one load each; monotonic targets, bounded spin (on a
+// timeout the error word is set and every workgroup runs to completion instead of hanging).
+// Same arithmetic order per accumulator as lstm_wave_kernel (bit-identical results).
 // -------------------------------------------------------------------------------------------------
 struct LstmPersistArgs {
     const float *w0, *w1, *bias1, *xproj;
-    float *h, *y;
-    unsigned* sync;      // [0] arrival counter, [1] error flag; zeroed by the caller before every launch
+    float* hist;         // [BH zeros][T x BH: h0(0..T-1)][T x BH: h1(0..T-1)]
+    float* y;
+    unsigned* sync;      // 16 counters at [32*i], error flag at [512]; zeroed by the caller before every launch
     int B, H, T;
+    int ablate;          // profiling aid (FC_ABLATE_LSTM env): 1 no grid barrier, 2 no h loads, 16 no MFMA, 32 no gate math/stores
 };
 
-// Hidden states are exchanged WRITE-THROUGH: stores carry sc1 (relaxed agent-scope atomics) and loads carry sc1
-// (buffer loads with aux = sc1, L1 bypass), so the barrier needs neither an L2 write-back nor an L1 invalidate
-// (each ~1.7 us on this chip) -- only: every storing wave drains vmcnt, one lane bumps a monotonic counter and polls it.
-__device__ __forceinline__ void lstm_grid_barrier(unsigned* sync, unsigned target) {
+constexpr int kLstmSyncWords = 1024;
+
+__device__ __forceinline__ void lstm_grid_barrier(unsigned* sync, unsigned target, int blk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its own write-through stores
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 32 * (blk & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned* mine = sync + 32 * (threadIdx.x & 15);
         unsigned spins = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while (true) {
+            const unsigned v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v >= target)) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 255u) == 0u) {
-                if (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-                if (spins > (1u << 21)) { __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (__hip_atomic_load(sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+                if (spins > (1u << 21)) { __hip_atomic_store(sync + 512, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         }
     }
     __syncthreads();
 }
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 load_h_sc1(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 16 /* sc1 */);
-    return __builtin_bit_cast(f32x4, r);
-}
-
 template <int NS, int NBT>
 __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistArgs p) {
+    static_assert(NS % 2 == 0, "k slices are issued in pairs");
     __shared__ f32x4 red[2][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
     const int H = p.H, B = p.B, T = p.T;
     const int blk = blockIdx.x;
-    const int nwg = gridDim.x;
+    const unsigned arrivals = gridDim.x >> 4;        // per counter per step
     const int kslice = NS * 16;                      // H / 4 waves
     const size_t BH = (size_t)B * H;
     // ---- weights -> registers (once)
@@ -1221,59 +1229,61 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
 #pragma unroll
     for (int nb = 0; nb < NBT; ++nb) cst[nb] = 0.f;
     const f32x4 bias1 = *(const f32x4*)(p.bias1 + (size_t)blk * 16 + 4 * g);
-    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, (int)(4 * BH * sizeof(float)), 0x00020000);
+    float* const hist0 = p.hist;                     // slot k = h0(k-1), slot 0 = zeros
+    float* const hist1 = p.hist + (size_t)T * BH;    // slot k >= 1 = h1(k-1) (slot 0 is never addressed through this base)
 
     for (int s = 0; s <= T; ++s) {
         const bool act0 = s < T, act1 = s >= 1;
-        const unsigned h0p = (unsigned)(((size_t)((s + 1) & 1) * BH) * 4);          // h0(s-1): parity (s-1)&1  (byte offsets)
-        const unsigned h1p = (unsigned)((2 * BH + (size_t)(s & 1) * BH) * 4);       // h1(s-2): parity (s-2)&1
-        float* h0o = p.h + (size_t)(s & 1) * BH;                           // h0(s)
-        float* h1o = p.h + 2 * BH + (size_t)((s + 1) & 1) * BH;            // h1(s-1)
+        const float* h0in = hist0 + (size_t)s * BH;                                  // h0(s-1)
+        const float* h1in = s >= 2 ? hist1 + (size_t)(s - 1) * BH : hist0;           // h1(s-2)
+        float* h0o = hist0 + (size_t)(s + 1) * BH;                                   // h0(s)     (s < T)
+        float* h1o = hist1 + (size_t)s * BH;                                         // h1(s-1)   (s >= 1)
 #pragma unroll
         for (int nb = 0; nb < NBT; ++nb) {
             const int brow = nb * 16 + r16;
             const bool bvalid = brow < B;
-            const unsigned hoff = (unsigned)(((size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g) * 4);
+            const size_t hoff = (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
             f32x4 xp = {0.f, 0.f, 0.f, 0.f};
             if (wid == 0 && act0)
                 xp = *(const f32x4*)(p.xproj + ((size_t)s * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
             f32x4 b0[NS], b1[NS];
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                b0[q] = load_h_sc1(hrsrc, h0p + hoff + 64 * q);
-                b1[q] = load_h_sc1(hrsrc, h1p + hoff + 64 * q);
+                if (!(p.ablate & 2)) {
+                    b0[q] = *(const f32x4*)(h0in + hoff + 16 * q);
+                    b1[q] = *(const f32x4*)(h1in + hoff + 16 * q);
+                } else { b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
                 if (!bvalid) { b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
             }
+            // four accumulators (layer 0 / layer 1 x even / odd k slice); the ISSUE order interleaves them so that two
+            // MFMAs on the same accumulator are never back to back, the order WITHIN each accumulator is that of
+            // lstm_wave_kernel
             f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = {0.f, 0.f, 0.f, 0.f};
             f32x4 c1a = {0.f, 0.f, 0.f, 0.f}, c1b = {0.f, 0.f, 0.f, 0.f};
+            if (!(p.ablate & 16)) {
 #pragma unroll
-            for (int q = 0; q < NS; ++q) {
+                for (int q = 0; q < NS; q += 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (q & 1) c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0b, 0, 0, 0);
-                    else c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0a, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0a, 0, 0, 0);
+                        c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
+                        c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q + 1][j], b0[q + 1][j], c0b, 0, 0, 0);
+                        c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q + 1][j], b0[q + 1][j], c1b, 0, 0, 0);
+                    }
                 }
-            }
 #pragma unroll
-            for (int q = 0; q < NS; ++q) {
+                for (int q = 0; q < NS; q += 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (q & 1) c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1b, 0, 0, 0);
-                    else c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (q & 1) c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1b, 0, 0, 0);
-                    else c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1a, 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1a, 0, 0, 0);
+                        c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q + 1][j], b1[q + 1][j], c1b, 0, 0, 0);
+                    }
                 }
             }
             red[0][wid][lane] = c0a + c0b;
             red[1][wid][lane] = c1a + c1b;
             __syncthreads();
-            if (wid < 2) {
+            if (wid < 2 && !(p.ablate & 32)) {
                 const int layer = wid;
                 const bool act = layer ? act1 : act0;
                 f32x4 sg = red[layer][0][lane];
@@ -1294,14 +1304,22 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             }
             __syncthreads();
         }
-        if (s < T) lstm_grid_barrier(p.sync, (unsigned)(s + 1) * (unsigned)nwg);
+        if (s < T && !(p.ablate & 1)) lstm_grid_barrier(p.sync, (unsigned)(s + 1) * arrivals, blk);
     }
 }
 
-hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* h, float* y,
-                               unsigned* sync, int B, int H, int T, hipStream_t st) {
+size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords + (size_t)(2 * T + 1) * B * H; }
+size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords + (size_t)B * H; }
+
+// `state`: lstm_persist_state_floats() floats whose first lstm_persist_clear_floats() are zero (barrier words + the
+// all-zero initial hidden state)
+hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* state, float* y,
+                               int B, int H, int T, hipStream_t st) {
     LstmPersistArgs a;
-    a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.h = h; a.y = y; a.sync = sync; a.B = B; a.H = H; a.T = T;
+    a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.hist = state + kLstmSyncWords; a.y = y;
+    a.sync = (unsigned*)state; a.B = B; a.H = H; a.T = T;
+    static const int ablate = getenv("FC_ABLATE_LSTM") ? atoi(getenv("FC_ABLATE_LSTM")) : 0;
+    a.ablate = ablate;
     const int nbt = (B + 15) / 16;
     dim3 grid(H / 4), block(256);
 #define FC_LP(NS, NBT) hipLaunchKernelGGL((lstm_persist_kernel<NS, NBT>), grid, block, 0, st, a)

@@ -277,6 +277,9 @@ class CodecEngine:
     def lstm_forward(self, prefix: str, x: torch.Tensor) -> torch.Tensor:
         x = self._dev(x, torch.float32)
         B, H, T = x.shape
+        want = self.expected_tensors().get(prefix + ".weight_hh_l0")
+        if want is None or want[1] != H:
+            raise EngineError(f"lstm {prefix!r}: expected input [B, {want[1] if want else '?'}, T], got {tuple(x.shape)}")
         y = torch.empty_like(x)
         need = (T * B * 4 * H + 3 * B * H + B * H * T) * 4 * self.arch.lstm_layers + (1 << 20)
         if self._ws is None or self._ws.numel() < need:

@@ -316,6 +316,20 @@ def test_full_size_matches_oracle_on_a_sampled_utterance(config_b):
         assert rms(r["recon"][3:4], o["recon_speech"]) < WAV_RMS_TOL
 
 
+def test_lstm_persistent_kernel_back_to_back_calls_full_size():
+    """The persistent recurrence exchanges hidden states through a write-once history buffer read with plain (cacheable)
+    loads; two calls on DIFFERENT inputs through the same workspace at the benchmark shape (B=16, T=250) must both match
+    torch (a stale cache line from the first call would surface in the second)."""
+    m = engine_for("ds640", 0)
+    orc = oracle_for("ds640", 0)
+    p = "decoder.model.1.lstm"
+    for seed in (1, 2):
+        x = torch.randn(16, 1024, 250, generator=torch.Generator().manual_seed(seed))
+        got = m.engine.lstm_forward(p, x).cpu()
+        ref = orc._slstm(x, p)
+        assert (got - ref).abs().max().item() < 2e-5, seed
+
+
 def test_lstm_launch_wavefront_fallback_matches_persistent_kernel():
     """The persistent recurrence (one launch, grid barrier) and the per-step launch path (FC_LSTM_PERSIST=0, used when
     the workgroups cannot all be co-resident) must agree bit for bit and with torch."""
