@@ -195,47 +195,64 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
                 inmask |= 1u << u;
             }
         }
+        // base0 holds the descriptors of the tile being LOADED: the static ones above for interior tiles, per-tile
+        // reflected / zero-padded ones for the (at most two) edge tiles of a row -- computed once per tile, not per
+        // chunk: the index math is ~25 VALU instructions per element and VALU time adds to MFMA time on this chip
+        bool base_static = true, ld_interior = true;
+        unsigned tile_mask = 0;
         bool all_valid = false;                       // current register contents need no padding mask
-        // loads are unconditional (masked elements read offset 0) and issued back to back
         // (tile, chunk) cursors advance incrementally: no integer divisions on the per-chunk path
         int ld_tile = t_begin, ld_chunk = 0, wr_chunk = 0;
-        auto load_slab = [&](int) {
-            const int tile = ld_tile;
-            const int c0 = ld_chunk * p.CC;
-            if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
-            const int tbase = tile * BN * p.stride - p.padL;
-            vmask = inmask;
-            if (p.ablate & 4) return;
-            const bool interior = tbase >= 0 && tbase + p.slabW <= p.Tin && c0 + p.CC <= p.Cin;
-            all_valid = interior;
-            if (interior) {
-                // lanes without an element (base0 = 0) read the tile origin: in bounds, value goes to the dummy slot
-                const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + tbase);
+        auto setup_tile = [&](int tbase) {
+            ld_interior = tbase >= 0 && tbase + p.slabW <= p.Tin;
+            tile_mask = inmask;
+            if (ld_interior && base_static) return;
+            const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const unsigned off = base0[u] + ubase;
-                    v0[u] = *(const float*)((const char*)s0b + off);
-                    if (DUAL) v1[u] = *(const float*)((const char*)s1b + off);
-                }
-            } else {
-                const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    unsigned ee = (unsigned)(rtid + 256 * u);
-                    asm volatile("" : "+v"(ee));        // keep the edge-tile index math out of the persistent registers
-                    const int cl = (int)__umulhi(ee, p.magic_slabW);
-                    const int tau = (int)ee - cl * p.slabW;
+            for (int u = 0; u < NU; ++u) {
+                unsigned ee = (unsigned)(rtid + 256 * u);
+                asm volatile("" : "+v"(ee));            // keep the index math out of the persistent registers
+                const int cl = (int)__umulhi(ee, p.magic_slabW);
+                const int tau = (int)ee - cl * p.slabW;
+                if (ld_interior) {
+                    base0[u] = ((inmask >> u) & 1u) ? 4u * (unsigned)(cl * p.Tin + tau) : 0u;
+                } else {
                     const int g = tbase + tau;
-                    bool ok = ((inmask >> u) & 1u) && c0 + cl < p.Cin && g >= -p.padL && g < hi_lim;
+                    bool ok = ((inmask >> u) & 1u) && g >= -p.padL && g < hi_lim;
                     int src = g < 0 ? -g : g;
                     src = src >= p.Leff ? refl - src : src;
                     if (p.pad_zero) { src = g; ok = ok && g >= 0; }
                     ok = ok && src < p.Tin;          // zero padding / zero-extension of short inputs (conv.py:89-93)
-                    const unsigned off = ok ? (unsigned)((c0 + cl) * p.Tin + src) : 0u;
-                    v0[u] = s0b[off];
-                    if (DUAL) v1[u] = s1b[off];
-                    vmask &= ~((ok ? 0u : 1u) << u);
+                    base0[u] = ok ? 4u * (unsigned)(cl * p.Tin + src) : 0u;
+                    tile_mask &= ~((ok ? 0u : 1u) << u);
                 }
+            }
+            base_static = ld_interior;
+        };
+        // loads are unconditional (masked elements read the chunk origin) and issued back to back
+        auto load_slab = [&](int) {
+            const int tbase = ld_tile * BN * p.stride - p.padL;
+            if (ld_chunk == 0) setup_tile(tbase);
+            const int c0 = ld_chunk * p.CC;
+            if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
+            vmask = tile_mask;
+            if (p.ablate & 4) return;
+            all_valid = ld_interior;
+            // lanes without an element (base0 = 0) read the origin: in bounds, value goes to the dummy slot / is masked
+            const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + (ld_interior ? tbase : 0));
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                unsigned off = base0[u] + ubase;
+                if (p.cin_tail && c0 + p.CC > p.Cin) {  // last chunk runs past the real channels (uniform, rare)
+                    unsigned ee = (unsigned)(rtid + 256 * u);
+                    asm volatile("" : "+v"(ee));
+                    const bool ok = c0 + (int)__umulhi(ee, p.magic_slabW) < p.Cin;
+                    off = ok ? off : 0u;
+                    vmask &= ~((ok ? 0u : 1u) << u);
+                    all_valid = false;
+                }
+                v0[u] = *(const float*)((const char*)s0b + off);
+                if (DUAL) v1[u] = *(const float*)((const char*)s1b + off);
             }
         };
         // branch-free per element: lanes without an element write a dummy slot, padding lanes select 0
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
 
     const int a_off = hi * BM + wm * (TM * 32) + l31;
     const int b_off = hi * p.rowStride + wn * (TN * 32) + l31;
-    const int nks = p.Kc >> 1;
+    const int nks2 = ((p.Kc >> 1) + 3) >> 2 << 1;     // groups of 2 k-steps, rounded up to pairs of groups
     int tile = t_begin, chunk = 0;
     for (int f = 0; f < nitems; ++f) {
         if (f + 1 < nitems && !resident) {
@@ -405,45 +422,48 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
         }
         const float* Ws = smem + (resident ? chunk : (f & 1)) * p.Wbuf + a_off;
         const float* Xb = Xs0 + (f & 1) * XSF + b_off;
-        // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi.  Four k-steps per iteration: 16 LDS
-        // fragment reads are issued ahead of 16 MFMAs; B offsets come from the LDS table, prefetched one ahead.
-        int ks = (p.ablate & 1) ? nks : 0;
-        int4 ko = kofs[0];
-        for (; ks + 4 <= nks; ks += 4) {
-            const int kos[4] = {ko.x, ko.y, ko.z, ko.w};
-            float a[4][TM], bb[4][TN];
+        // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi, in groups of two.  The loop is software
+        // pipelined by hand: the LDS fragment reads (and the B-offset table entry) of group g+1 are issued BEFORE the 8
+        // MFMAs of group g and the scheduler is fenced so that it keeps them there -- left alone hipcc sinks every read
+        // to just above its first use and each MFMA quad then eats a full LDS round trip (visible whenever fewer than
+        // ~3 matrix waves share a SIMD).  Reads past the chunk's last k-step stay inside LDS and are never used.
+        auto load_group = [&](int g, const int2 k2, float (&a)[2][TM], float (&bb)[2][TN]) {
+            const int kos[2] = {k2.x, k2.y};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[u][i] = Ws[(ks + u) * 2 * BM + i * 32];
+                for (int i = 0; i < TM; ++i) a[u][i] = Ws[(g * 2 + u) * 2 * BM + i * 32];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bb[u][j] = Xb[kos[u] + j * 32];
             }
-            ko = kofs[(ks >> 2) + 1];                 // table is padded: always in bounds
+        };
+        auto mfma_group = [&](const float (&a)[2][TM], const float (&bb)[2][TN]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
-        }
-        if (ks < nks) {
-            const int kos[4] = {ko.x, ko.y, ko.z, ko.w};
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                if (ks + u < nks) {
-                    float a[TM], bb[TN];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = Ws[(ks + u) * 2 * BM + i * 32];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) bb[j] = Xb[kos[u] + j * 32];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
-                }
+        };
+        if (!(p.ablate & 1)) {
+            // the packed weight image is zero-padded to a multiple of 4 k-steps (conv_wbuf_floats) and the offset
+            // table to two groups more, so there is no tail: padded k-steps multiply zeros into the accumulators
+            const int2* kofs2 = (const int2*)kofs;
+            float fa0[2][TM], fb0[2][TN], fa1[2][TM], fb1[2][TN];
+            load_group(0, kofs2[0], fa0, fb0);
+            int2 ko = kofs2[1];
+            for (int g = 0; g < nks2; g += 2) {
+                load_group(g + 1, ko, fa1, fb1);
+                ko = kofs2[g + 2];
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_group(g + 2, ko, fa0, fb0);
+                ko = kofs2[g + 3];
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_group(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const bool tile_done = chunk == p.nchunk - 1;
@@ -456,6 +476,10 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
     }
     __syncthreads();                                  // final: publishes the last tile's per-lane partials
 }
+
+// entries of the k-step offset table: the k-steps of a chunk rounded up to whole groups of 4, plus two zero groups the
+// pipelined main loop may read ahead
+static int conv_koff_len(int k, int CC) { return (((k * CC / 2) + 3) & ~3) + 8; }
 
 static ConvArgs make_args(const ConvLaunch& c) {
     ConvArgs a;
@@ -479,7 +503,7 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.zeros = c.zeros;
     a.koff = c.koff;
-    a.koff_n = (int)(((c.k * c.CC / 2) + 7) & ~3) + 4;
+    a.koff_n = conv_koff_len(c.k, c.CC);
     a.cin_tail = (c.Cin % c.CC) != 0;
     static const int ablate = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
     static const int skew = getenv("FC_SKEW") ? atoi(getenv("FC_SKEW")) : 0;
@@ -495,7 +519,7 @@ std::vector<int> conv_koff_table(int k, int stride, int CC, int BN) {
     const int slabW = (BN - 1) * stride + k;
     const int PL = ceil_div(slabW, stride), rowStride = PL * stride;
     const int nks = k * CC / 2, half_cc = CC / 2;
-    std::vector<int> t(((nks + 7) & ~3) + 4, 0);
+    std::vector<int> t(conv_koff_len(k, CC), 0);
     for (int ks = 0; ks < nks; ++ks) {
         const int kk = ks / half_cc, c2 = ks % half_cc;
         t[ks] = 2 * c2 * rowStride + (kk % stride) * PL + kk / stride;
@@ -503,7 +527,8 @@ std::vector<int> conv_koff_table(int k, int stride, int CC, int BN) {
     return t;
 }
 
-int conv_wbuf_floats(int k, int CC, int BM) { return ((k * CC * BM + 1023) / 1024) * 1024; }
+// K of a chunk is zero-padded to a multiple of 4 k-steps (8 k values): the main loop has no tail
+int conv_wbuf_floats(int k, int CC, int BM) { return ((((k * CC + 7) & ~7) * BM + 1023) / 1024) * 1024; }
 
 int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM); }
 
@@ -512,7 +537,7 @@ size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, in
     const int rowStride = ceil_div(slabW, stride) * stride;
     const int img = CC * rowStride;
     const int xs = (img <= 8 * 256 ? 8 : 16) * 256 + 4;            // XSF of the NU variant the launcher will pick
-    const size_t koff_bytes = (size_t)((((k * CC / 2) + 7) & ~3) + 4) * sizeof(int);
+    const size_t koff_bytes = (size_t)conv_koff_len(k, CC) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
            (size_t)BM * sizeof(float) + 2 * 256 * 8;
 }
