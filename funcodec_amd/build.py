@@ -32,6 +32,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if os.environ.get("FC_TIMELINE"):       # profiling build: phase timestamps inside the conv kernel (fc_debug_timeline)
+        cmd.insert(1, "-DFC_TIMELINE")
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -906,4 +906,10 @@ int fc_lstm_forward(fc_engine* e, const char* prefix, const float* x, int B, int
     return 0;
 }
 
+int fc_debug_timeline(unsigned long long* dst) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(fc::debug_timeline(dst));
+    return 0;
+}
+
 }  // extern "C"

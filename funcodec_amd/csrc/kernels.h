@@ -84,6 +84,7 @@ hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, con
 // Persistent 2-layer recurrence (one launch); sync = 2 zeroed words; h [2][2][B][H] zeroed by the caller.
 hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* state, float* y,
                                int B, int H, int T, hipStream_t st);
+hipError_t debug_timeline(unsigned long long* dst);      // [2 roles][24 items][8 slots], profiling builds only
 size_t lstm_persist_state_floats(int B, int H, int T);   // barrier words + zero slot + hidden-state history of both layers
 size_t lstm_persist_clear_floats(int B, int H);
 bool lstm_persist_supported(int B, int H, int L, int device);

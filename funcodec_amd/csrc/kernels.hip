@@ -116,8 +116,20 @@ __device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int t
 // Each SIMD hosts one matrix wave and one staging wave of a workgroup, so prologue VALU work and memory latency
 // overlap the matrix pipe by construction.  One barrier per K-chunk.  A workgroup owns one (utterance, M tile) and
 // a contiguous range of N tiles; the pipeline runs across chunk and tile boundaries.
+#ifdef FC_TIMELINE
+// Profiling build only (python -m funcodec_amd.build with FC_TIMELINE=1): wave 0 of each role of workgroup (1, 0, 0)
+// stamps s_memtime at its phase boundaries for the first 24 work items; read back with fc_debug_timeline().
+__device__ unsigned long long g_timeline[2][24][8];
+#define FC_STAMP(role_, f_, slot_)                                                                          \
+    do {                                                                                                    \
+        if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && wid == 0 && lane == 0 && (f_) < 24)     \
+            g_timeline[role_][f_][slot_] = __builtin_amdgcn_s_memtime();                                    \
+    } while (0)
+#else
+#define FC_STAMP(role_, f_, slot_) do {} while (0)
+#endif
 template <int BM, int BN, int WM, int WN, int MODE, int NU>
-__global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(WM * WN == 4, "4 matrix waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr bool PLAIN = MODE == 0;                 // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU
@@ -240,17 +252,23 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
             all_valid = ld_interior;
             // lanes without an element (base0 = 0) read the origin: in bounds, value goes to the dummy slot / is masked
             const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + (ld_interior ? tbase : 0));
+            if (p.cin_tail && c0 + p.CC > p.Cin) {      // last chunk runs past the real channels (uniform, rare)
+                all_valid = false;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                unsigned off = base0[u] + ubase;
-                if (p.cin_tail && c0 + p.CC > p.Cin) {  // last chunk runs past the real channels (uniform, rare)
+                for (int u = 0; u < NU; ++u) {
                     unsigned ee = (unsigned)(rtid + 256 * u);
                     asm volatile("" : "+v"(ee));
                     const bool ok = c0 + (int)__umulhi(ee, p.magic_slabW) < p.Cin;
-                    off = ok ? off : 0u;
+                    const unsigned off = ok ? base0[u] + ubase : 0u;
                     vmask &= ~((ok ? 0u : 1u) << u);
-                    all_valid = false;
+                    v0[u] = *(const float*)((const char*)s0b + off);
+                    if (DUAL) v1[u] = *(const float*)((const char*)s1b + off);
                 }
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const unsigned off = base0[u] + ubase;
                 v0[u] = *(const float*)((const char*)s0b + off);
                 if (DUAL) v1[u] = *(const float*)((const char*)s1b + off);
             }
@@ -317,12 +335,17 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
         __syncthreads();                              // B0: slab 0 + weights 0 visible
         int st_tile = t_begin, st_chunk = 0;
         for (int f = 0; f < nitems; ++f) {
+            FC_STAMP(1, f, 0);
             if (f + 1 < nitems) {
                 write_slab(f + 1, (char*)(Xs0 + ((f + 1) & 1) * XSF));   // registers were filled one iteration ago
+                FC_STAMP(1, f, 1);
                 if (f + 2 < nitems) load_slab(f + 2);
+                FC_STAMP(1, f, 2);
             }
             __syncthreads();                          // B(f+1): the matrix waves have finished item f
+            FC_STAMP(1, f, 3);
             if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
+            FC_STAMP(1, f, 4);
         }
         __syncthreads();                              // final (kept symmetric with the matrix role)
         return;
@@ -416,6 +439,7 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
     const int nks2 = ((p.Kc >> 1) + 3) >> 2 << 1;     // groups of 2 k-steps, rounded up to pairs of groups
     int tile = t_begin, chunk = 0;
     for (int f = 0; f < nitems; ++f) {
+        FC_STAMP(0, f, 0);
         if (f + 1 < nitems && !resident) {
             const int nc = chunk + 1 == p.nchunk ? 0 : chunk + 1;
             dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
@@ -466,12 +490,15 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        FC_STAMP(0, f, 1);
         const bool tile_done = chunk == p.nchunk - 1;
         if (tile_done) {
             if (!(p.ablate & 128)) epilogue(tile, tile & 1);
             zero_acc();
         }
+        FC_STAMP(0, f, 2);
         __syncthreads();                              // B(f+1): slab f+1 + weights f+1 visible, buffers f free
+        FC_STAMP(0, f, 3);
         if (tile_done) { ++tile; chunk = 0; } else { ++chunk; }
     }
     __syncthreads();                                  // final: publishes the last tile's per-lane partials
@@ -480,6 +507,16 @@ __global__ __launch_bounds__(512, (BM == 32 ? 6 : 4)) void conv_mfma_kernel(cons
 // entries of the k-step offset table: the k-steps of a chunk rounded up to whole groups of 4, plus two zero groups the
 // pipelined main loop may read ahead
 static int conv_koff_len(int k, int CC) { return (((k * CC / 2) + 3) & ~3) + 8; }
+
+// copy of the timeline stamps of a profiling build (zeros otherwise): [role][item][slot]
+hipError_t debug_timeline(unsigned long long* dst) {
+#ifdef FC_TIMELINE
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * 2 * 24 * 8);
+#else
+    for (int i = 0; i < 2 * 24 * 8; ++i) dst[i] = 0ull;
+    return hipSuccess;
+#endif
+}
 
 static ConvArgs make_args(const ConvLaunch& c) {
     ConvArgs a;
@@ -542,13 +579,13 @@ size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, in
            (size_t)BM * sizeof(float) + 2 * 256 * 8;
 }
 
-// Thin tiles (BM <= 64) stage 8 elements per thread per chunk so that they fit 128 / 168 VGPRs and run 4 / 3
-// workgroups per CU (latency hiding for the HBM-bound layers); 128-row tiles stage 16.
-int conv_wgs_per_cu(int BM) { return BM == 32 ? 3 : 2; }
+// Every tiling runs two 512-thread workgroups per CU (128 VGPRs per wave).  Three workgroups of the 32-row tiles at 80
+// VGPRs forced the 8-element staging variant and therefore 4x smaller K chunks: measured slower (per-item overheads).
+int conv_wgs_per_cu(int) { return 2; }
 bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual) {
     const int slabW = (BN - 1) * stride + k;
     const int img = CC * ceil_div(slabW, stride) * stride;
-    if ((BM == 32 || dual) && CC > 2) return img <= 8 * 256;      // prefer the low-register (NU = 8) variants
+    if (dual && CC > 2) return img <= 8 * 256;      // two-source prologue: keep the low-register (NU = 8) variant
     return img <= SLAB_PER_THREAD * 256;
 }
 

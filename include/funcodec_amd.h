@@ -158,6 +158,10 @@ int fc_engine_profile(fc_engine* e, int enable);
 /* fills out[0..n) (n <= FC_PROF_CLASSES, returned through *n_out); unused entries have launches == 0 */
 int fc_engine_profile_read(fc_engine* e, fc_prof* out /* [FC_PROF_CLASSES] */);
 
+/* Kernel-phase timeline of the last conv launch, [2 roles][24 work items][8 stamps] of shader-clock ticks.
+ * Only builds made with FC_TIMELINE=1 record anything (all zeros otherwise); a tuning aid, not part of the path. */
+int fc_debug_timeline(unsigned long long* dst /* [2*24*8] */);
+
 #ifdef __cplusplus
 }
 #endif

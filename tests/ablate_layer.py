@@ -41,3 +41,19 @@ for _ in range(n):
 prof = [p for p in eng.read_profile() if p["launches"]]
 us = sum(p["total_ms"] for p in prof if p["kernel"].startswith("conv")) * 1e3 / n
 print(f"ablate={os.environ.get('FC_ABLATE','0'):>3s} {prefix} T={T} elu={elu}: conv kernel {us:8.1f} us")
+
+tl = (C.c_ulonglong * (2 * 24 * 8))()
+if hasattr(eng.lib, "fc_debug_timeline") and eng.lib.fc_debug_timeline(tl) == 0 and any(tl):
+    import numpy as np
+    a = np.array(list(tl), dtype=np.int64).reshape(2, 24, 8)
+    t0 = a[a > 0].min()
+    print("matrix role  : item start | +mainloop | +epilogue | +barrier   (shader ticks, 100 MHz => x10 ns)")
+    for f in range(24):
+        r = a[0, f]
+        if r[0]:
+            print(f"  item {f:2d} @ {r[0] - t0:7d}: {r[1] - r[0]:6d} {r[2] - r[1]:6d} {r[3] - r[2]:6d}")
+    print("staging role : item start | +write_slab | +load issue | +barrier | +flush")
+    for f in range(24):
+        r = a[1, f]
+        if r[0]:
+            print(f"  item {f:2d} @ {r[0] - t0:7d}: {r[1] - r[0]:6d} {r[2] - r[1]:6d} {r[3] - r[2]:6d} {r[4] - r[3]:6d}")
