@@ -1244,11 +1244,14 @@ struct LstmPersistArgs {
 
 constexpr int kLstmSyncWords = 1024;
 
-__device__ __forceinline__ void lstm_grid_barrier(unsigned* sync, unsigned target, int blk) {
+// split grid barrier: arrive (after this workgroup's stores have drained) ... independent work ... wait
+__device__ __forceinline__ void lstm_barrier_arrive(unsigned* sync, int blk) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its own write-through stores
     __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 32 * (blk & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void lstm_barrier_wait(unsigned* sync, unsigned target) {
     if (threadIdx.x < 64) {
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 32 * (blk & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned* mine = sync + 32 * (threadIdx.x & 15);
         unsigned spins = 0;
         while (true) {
@@ -1264,6 +1267,10 @@ __device__ __forceinline__ void lstm_grid_barrier(unsigned* sync, unsigned targe
     __syncthreads();
 }
 
+// Wavefront schedule (T + 2 steps): at step s layer 0 produces h0(s) and layer 1 produces h1(s-2).  Layer 1 runs one
+// step later than its data dependence requires so that its input half, P = W_ih1 . h0(s-1), is computed in the SHADOW
+// of the grid barrier of step s (after this workgroup has arrived, before it starts polling) and only the two
+// recurrent products (W_hh0 . h0(s-1), W_hh1 . h1(s-3)) sit on the critical path between two barriers.
 template <int NS, int NBT>
 __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistArgs p) {
     static_assert(NS % 2 == 0, "k slices are issued in pairs");
@@ -1288,18 +1295,24 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
         }
     }
     float cst[NBT];                                  // cell state of (batch row, unit): wave 0 -> layer 0, wave 1 -> layer 1
+    f32x4 pa[NBT], pb[NBT];                          // P = W_ih1 . h0 of the NEXT step's layer-1 timestep (even / odd k slices)
 #pragma unroll
-    for (int nb = 0; nb < NBT; ++nb) cst[nb] = 0.f;
+    for (int nb = 0; nb < NBT; ++nb) {
+        cst[nb] = 0.f;
+        pa[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        pb[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     const f32x4 bias1 = *(const f32x4*)(p.bias1 + (size_t)blk * 16 + 4 * g);
     float* const hist0 = p.hist;                     // slot k = h0(k-1), slot 0 = zeros
     float* const hist1 = p.hist + (size_t)T * BH;    // slot k >= 1 = h1(k-1) (slot 0 is never addressed through this base)
+    f32x4 b0keep[NS];
 
-    for (int s = 0; s <= T; ++s) {
-        const bool act0 = s < T, act1 = s >= 1;
-        const float* h0in = hist0 + (size_t)s * BH;                                  // h0(s-1)
-        const float* h1in = s >= 2 ? hist1 + (size_t)(s - 1) * BH : hist0;           // h1(s-2)
+    for (int s = 0; s <= T + 1; ++s) {
+        const bool act0 = s < T, act1 = s >= 2;
+        const float* h0in = hist0 + (size_t)(s <= T ? s : T) * BH;                   // h0(s-1)
+        const float* h1in = s >= 3 ? hist1 + (size_t)(s - 2) * BH : hist0;           // h1(s-3)
         float* h0o = hist0 + (size_t)(s + 1) * BH;                                   // h0(s)     (s < T)
-        float* h1o = hist1 + (size_t)s * BH;                                         // h1(s-1)   (s >= 1)
+        float* h1o = hist1 + (size_t)(s - 1) * BH;                                   // h1(s-2)   (s >= 2)
 #pragma unroll
         for (int nb = 0; nb < NBT; ++nb) {
             const int brow = nb * 16 + r16;
@@ -1308,7 +1321,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             f32x4 xp = {0.f, 0.f, 0.f, 0.f};
             if (wid == 0 && act0)
                 xp = *(const f32x4*)(p.xproj + ((size_t)s * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
-            f32x4 b0[NS], b1[NS];
+            f32x4 b0l[NBT == 1 ? 1 : NS], b1[NS];
+            f32x4 (&b0)[NS] = *(NBT == 1 ? &b0keep : (f32x4 (*)[NS])&b0l);   // single batch tile: h0(s-1) stays in registers for the shadow phase
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
                 if (!(p.ablate & 2)) {
@@ -1319,25 +1333,17 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             }
             // four accumulators (layer 0 / layer 1 x even / odd k slice); the ISSUE order interleaves them so that two
             // MFMAs on the same accumulator are never back to back, the order WITHIN each accumulator is that of
-            // lstm_wave_kernel
+            // lstm_wave_kernel (layer 1: the W_ih1 terms -- already in pa / pb -- then the W_hh1 terms)
             f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = {0.f, 0.f, 0.f, 0.f};
-            f32x4 c1a = {0.f, 0.f, 0.f, 0.f}, c1b = {0.f, 0.f, 0.f, 0.f};
+            f32x4 c1a = pa[nb], c1b = pb[nb];
             if (!(p.ablate & 16)) {
 #pragma unroll
                 for (int q = 0; q < NS; q += 2) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0a, 0, 0, 0);
-                        c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
-                        c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q + 1][j], b0[q + 1][j], c0b, 0, 0, 0);
-                        c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q + 1][j], b0[q + 1][j], c1b, 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NS; q += 2) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
                         c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1a, 0, 0, 0);
+                        c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q + 1][j], b0[q + 1][j], c0b, 0, 0, 0);
                         c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q + 1][j], b1[q + 1][j], c1b, 0, 0, 0);
                     }
                 }
@@ -1361,12 +1367,45 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
                     cst[nb] = cn;
                     const size_t ci = (size_t)brow * H + (size_t)blk * 4 + g;
                     if (layer == 0) __hip_atomic_store(&h0o[ci], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else { __hip_atomic_store(&h1o[ci], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); p.y[ci * T + (s - 1)] = hn; }
+                    else { __hip_atomic_store(&h1o[ci], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); p.y[ci * T + (s - 2)] = hn; }
                 }
             }
             __syncthreads();
         }
-        if (s < T && !(p.ablate & 1)) lstm_grid_barrier(p.sync, (unsigned)(s + 1) * arrivals, blk);
+        if (s > T) break;
+        const bool sync = !(p.ablate & 1);
+        if (sync) lstm_barrier_arrive(p.sync, blk);
+        // ---- barrier shadow: P for the next step's layer-1 timestep t = s - 1 (needs h0(s-1), already visible)
+        if (s >= 1) {
+#pragma unroll
+            for (int nb = 0; nb < NBT; ++nb) {
+                const int brow = nb * 16 + r16;
+                const bool bvalid = brow < B;
+                const size_t hoff = (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
+                f32x4 b0l[NBT == 1 ? 1 : NS];
+                f32x4 (&b0)[NS] = *(NBT == 1 ? &b0keep : (f32x4 (*)[NS])&b0l);
+                if (NBT > 1) {                        // several batch tiles: re-read (L2 hit) instead of holding NBT x 64 registers
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        b0[q] = (p.ablate & 2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(h0in + hoff + 16 * q);
+                        if (!bvalid) b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                f32x4 c1a = {0.f, 0.f, 0.f, 0.f}, c1b = {0.f, 0.f, 0.f, 0.f};
+                if (!(p.ablate & 16)) {
+#pragma unroll
+                    for (int q = 0; q < NS; q += 2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
+                            c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q + 1][j], b0[q + 1][j], c1b, 0, 0, 0);
+                        }
+                    }
+                }
+                pa[nb] = c1a; pb[nb] = c1b;
+            }
+        }
+        if (sync) lstm_barrier_wait(p.sync, (unsigned)(s + 1) * arrivals);
     }
 }
 
