@@ -59,8 +59,8 @@ struct ConvArgs {
     int koff_n;
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
     int skew, skew_div;     // phase skew between co-resident workgroups (units of 64*64 cycles), see kernel
-    int ablate;             // profiling aid (FC_ABLATE env): 1 no MFMA, 2 no stores, 4 no slab loads, 8 no slab transform,
-                            // 16 no weight DMA.  0 in production.
+    int ablate;             // profiling aid (FC_ABLATE env): 1 no MFMA, 2 no stores, 4 no slab loads, 16 no weight DMA,
+                            // 128 no epilogue.  0 in production.
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -123,7 +123,7 @@ __device__ unsigned long long g_timeline[2][24][8];
 #define FC_STAMP(role_, f_, slot_)                                                                          \
     do {                                                                                                    \
         if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && wid == 0 && lane == 0 && (f_) < 24)     \
-            g_timeline[role_][f_][slot_] = __builtin_amdgcn_s_memtime();                                    \
+            g_timeline[role_][f_][slot_] = (slot_) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define FC_STAMP(role_, f_, slot_) do {} while (0)
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool PLAIN = MODE == 0;                 // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU
     constexpr bool DUAL = MODE >= 3;
     constexpr bool ELU = MODE == 2 || MODE == 4;
+    constexpr bool STAGING_DMA = PLAIN;               // which role streams the weight chunks
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int XSF = NU * 256 + 4;                 // floats per slab buffer (compile time: LDS immediates)
     float* Xs0 = smem + 2 * p.Wbuf;                   // slab, double buffered
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     const size_t rowbase = (size_t)b * p.Cin;
     const int nitems = (t_end - t_begin) * p.nchunk;  // flattened (tile, chunk) work items of this workgroup
     const bool resident = p.nchunk <= 2;              // the whole K extent of this M tile stays in LDS
+    const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
 
     // ---- common prologue: tables -------------------------------------------------------------------
     if (!PLAIN) {   // per-(b, channel) GroupNorm affine of the producers, staged once per workgroup
@@ -329,13 +331,23 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 p.partials[slot_p + 1] = d2;
             }
         };
+        // PLAIN staging (no prologue math) has time to spare: these waves then also stream the weight chunks (global ->
+        // LDS DMA); issuing a DMA piece between MFMAs costs the issuing wave 100+ cycles
+        if (STAGING_DMA) {
+            dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
+            if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
+        }
         load_slab(0);
         write_slab(0, (char*)Xs0);
         if (nitems > 1) load_slab(1);
-        __syncthreads();                              // B0: slab 0 + weights 0 visible
+        __syncthreads();                              // B0: slab 0 + weights 0 visible (the barrier drains the DMA)
         int st_tile = t_begin, st_chunk = 0;
         for (int f = 0; f < nitems; ++f) {
             FC_STAMP(1, f, 0);
+            if (STAGING_DMA && f + 1 < nitems && !resident) {
+                const int nc = st_chunk + 1 == p.nchunk ? 0 : st_chunk + 1;
+                dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
+            }
             if (f + 1 < nitems) {
                 write_slab(f + 1, (char*)(Xs0 + ((f + 1) & 1) * XSF));   // registers were filled one iteration ago
                 FC_STAMP(1, f, 1);
@@ -354,7 +366,6 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     // =============================================== matrix waves ======================================
     const int wm = wid / WN, wn = wid % WN;
     const int hi = lane >> 5, l31 = lane & 31;
-    const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
     const int4* kofs = (const int4*)kofs_i;
     f32x16 acc[TM][TN];
     // accumulators start at the bias (the MFMA chain then adds the products): saves one VALU add per output element
@@ -430,8 +441,10 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         // barrier, so the matrix waves never pay for the cross-lane reduction
         if (p.partials) red[par * 256 + rtid] = make_float2(s1, s2);
     };
-    dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
-    if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
+    if (!STAGING_DMA) {
+        dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
+        if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
+    }
     __syncthreads();                                  // B0 (drains the weight DMA)
 
     const int a_off = hi * BM + wm * (TM * 32) + l31;
@@ -440,7 +453,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     int tile = t_begin, chunk = 0;
     for (int f = 0; f < nitems; ++f) {
         FC_STAMP(0, f, 0);
-        if (f + 1 < nitems && !resident) {
+        FC_STAMP(0, f, 7);
+        if (!STAGING_DMA && f + 1 < nitems && !resident) {
             const int nc = chunk + 1 == p.nchunk ? 0 : chunk + 1;
             dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
         }

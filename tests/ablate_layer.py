@@ -47,6 +47,10 @@ if hasattr(eng.lib, "fc_debug_timeline") and eng.lib.fc_debug_timeline(tl) == 0 
     import numpy as np
     a = np.array(list(tl), dtype=np.int64).reshape(2, 24, 8)
     t0 = a[a > 0].min()
+    rt = a[0, :, 7]
+    n = int((rt > 0).sum())
+    if n > 1:
+        print(f"calibration: {(a[0, n - 1, 0] - a[0, 0, 0]) / ((rt[n - 1] - rt[0]) * 10.0):.3f} s_memtime ticks per ns (s_memrealtime = 100 MHz)")
     print("matrix role  : item start | +mainloop | +epilogue | +barrier   (shader ticks, 100 MHz => x10 ns)")
     for f in range(24):
         r = a[0, f]
