@@ -136,6 +136,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool DUAL = MODE >= 3;
     constexpr bool ELU = MODE == 2 || MODE == 4;
     constexpr bool STAGING_DMA = PLAIN;               // which role streams the weight chunks
+    constexpr bool DEEP = PLAIN;                      // two register sets of staged input in flight
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int XSF = NU * 256 + 4;                 // floats per slab buffer (compile time: LDS immediates)
     float* Xs0 = smem + 2 * p.Wbuf;                   // slab, double buffered
@@ -185,8 +186,11 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         //   slot[u]  = byte offset of the element inside a slab buffer (dummy slot for lanes without an element)
         //   cl8[u]   = 8*cl               byte offset into the affine tables
         unsigned base0[NU], slot[NU], cl8[PLAIN ? 1 : NU];
-        float v0[NU], v1[DUAL ? NU : 1];
-        unsigned inmask = 0, vmask = 0;
+        // TWO register sets: the loads of item f+3 are issued while the values of item f+2 are still in flight, so a load
+        // has two item times (not one) to return -- the T=250 layers saw ~2.6 us load latency against ~2.9 us items
+        constexpr int NSET = DEEP ? 2 : 1;
+        float v0[NSET][NU], v1[NSET][DUAL ? NU : 1];
+        unsigned inmask = 0, vmask[NSET] = {};
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int e = rtid + 256 * u;
@@ -214,10 +218,10 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         // chunk: the index math is ~25 VALU instructions per element and VALU time adds to MFMA time on this chip
         bool base_static = true, ld_interior = true;
         unsigned tile_mask = 0;
-        bool all_valid = false;                       // current register contents need no padding mask
+        bool all_valid[NSET] = {};                    // the set's register contents need no padding mask
         // (tile, chunk) cursors advance incrementally: no integer divisions on the per-chunk path
         int ld_tile = t_begin, ld_chunk = 0, wr_chunk = 0;
-        auto setup_tile = [&](int tbase) {
+        auto setup_tile = [&](int tbase) __attribute__((always_inline)) {
             ld_interior = tbase >= 0 && tbase + p.slabW <= p.Tin;
             tile_mask = inmask;
             if (ld_interior && base_static) return;
@@ -244,40 +248,42 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             base_static = ld_interior;
         };
         // loads are unconditional (masked elements read the chunk origin) and issued back to back
-        auto load_slab = [&](int) {
+        auto load_slab = [&](auto set_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_tag)::value;
             const int tbase = ld_tile * BN * p.stride - p.padL;
             if (ld_chunk == 0) setup_tile(tbase);
             const int c0 = ld_chunk * p.CC;
             if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
-            vmask = tile_mask;
+            vmask[S] = tile_mask;
             if (p.ablate & 4) return;
-            all_valid = ld_interior;
+            all_valid[S] = ld_interior;
             // lanes without an element (base0 = 0) read the origin: in bounds, value goes to the dummy slot / is masked
             const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + (ld_interior ? tbase : 0));
             if (p.cin_tail && c0 + p.CC > p.Cin) {      // last chunk runs past the real channels (uniform, rare)
-                all_valid = false;
+                all_valid[S] = false;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     unsigned ee = (unsigned)(rtid + 256 * u);
                     asm volatile("" : "+v"(ee));
                     const bool ok = c0 + (int)__umulhi(ee, p.magic_slabW) < p.Cin;
                     const unsigned off = ok ? base0[u] + ubase : 0u;
-                    vmask &= ~((ok ? 0u : 1u) << u);
-                    v0[u] = *(const float*)((const char*)s0b + off);
-                    if (DUAL) v1[u] = *(const float*)((const char*)s1b + off);
+                    vmask[S] &= ~((ok ? 0u : 1u) << u);
+                    v0[S][u] = *(const float*)((const char*)s0b + off);
+                    if (DUAL) v1[S][u] = *(const float*)((const char*)s1b + off);
                 }
                 return;
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const unsigned off = base0[u] + ubase;
-                v0[u] = *(const float*)((const char*)s0b + off);
-                if (DUAL) v1[u] = *(const float*)((const char*)s1b + off);
+                v0[S][u] = *(const float*)((const char*)s0b + off);
+                if (DUAL) v1[S][u] = *(const float*)((const char*)s1b + off);
             }
         };
         // branch-free per element: lanes without an element write a dummy slot, padding lanes select 0
         // branch-free per element; interior tiles (the common case) skip the padding select
-        auto write_slab_t = [&](int, char* Xd, auto use_div, auto masked) {
+        auto write_slab_t = [&](auto set_tag, char* Xd, auto use_div, auto masked) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_tag)::value;
             const int c0 = wr_chunk * p.CC;
             if (++wr_chunk == p.nchunk) wr_chunk = 0;
             const char* t0 = (const char*)(tab0 + c0);
@@ -294,26 +300,27 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-                float v = v0[u];
+                float v = v0[S][u];
                 if (!PLAIN) {
                     if (decltype(use_div)::value) v = v / divv;
                     v = fmaf(v, a0[u].x, a0[u].y);
-                    if (DUAL) v = v + fmaf(v1[u], a1[u].x, a1[u].y);
+                    if (DUAL) v = v + fmaf(v1[S][u], a1[u].x, a1[u].y);
                     if (ELU) v = elu_f(v, p.alpha);
                 }
-                if (decltype(masked)::value) v = ((vmask >> u) & 1u) ? v : 0.f;
+                if (decltype(masked)::value) v = ((vmask[S] >> u) & 1u) ? v : 0.f;
                 *(float*)(Xd + slot[u]) = v;
             }
         };
-        auto write_slab = [&](int item, char* Xd) {
-            if (MODE == 1 && p.div0) write_slab_t(item, Xd, std::true_type(), std::true_type());
-            else if (all_valid) write_slab_t(item, Xd, std::false_type(), std::false_type());
-            else write_slab_t(item, Xd, std::false_type(), std::true_type());
+        auto write_slab = [&](auto set_tag, char* Xd) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_tag)::value;
+            if (MODE == 1 && p.div0) write_slab_t(set_tag, Xd, std::true_type(), std::true_type());
+            else if (all_valid[S]) write_slab_t(set_tag, Xd, std::false_type(), std::false_type());
+            else write_slab_t(set_tag, Xd, std::false_type(), std::true_type());
         };
 
         // GroupNorm partial of a finished tile: fixed-order fp64 reduction of the 256 per-lane fp32 partials the
         // matrix waves left in LDS (done here because the staging waves idle at the barrier anyway)
-        auto flush_stats = [&](int tile) {
+        auto flush_stats = [&](int tile) __attribute__((always_inline)) {
             if (!p.partials || wid != 0) return;
             const float2* r = red + (tile & 1) * 256;
             double d1 = 0.0, d2 = 0.0;
@@ -337,27 +344,44 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
             if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
         }
-        load_slab(0);
-        write_slab(0, (char*)Xs0);
-        if (nitems > 1) load_slab(1);
-        __syncthreads();                              // B0: slab 0 + weights 0 visible (the barrier drains the DMA)
+        using Set0 = std::integral_constant<int, 0>;
+        using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
         int st_tile = t_begin, st_chunk = 0;
-        for (int f = 0; f < nitems; ++f) {
+        // one pipeline step: (optionally) stream weights of item f+1, turn the registers of item f+1 into its slab, refill
+        // that register set with item f+1+NSET, meet the matrix waves at the barrier, reduce a finished tile's statistics
+        auto step = [&](int f, auto wr_set) __attribute__((always_inline)) {
             FC_STAMP(1, f, 0);
             if (STAGING_DMA && f + 1 < nitems && !resident) {
                 const int nc = st_chunk + 1 == p.nchunk ? 0 : st_chunk + 1;
                 dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
             }
             if (f + 1 < nitems) {
-                write_slab(f + 1, (char*)(Xs0 + ((f + 1) & 1) * XSF));   // registers were filled one iteration ago
+                write_slab(wr_set, (char*)(Xs0 + ((f + 1) & 1) * XSF));
                 FC_STAMP(1, f, 1);
-                if (f + 2 < nitems) load_slab(f + 2);
+                if (f + 1 + NSET < nitems) load_slab(wr_set);
                 FC_STAMP(1, f, 2);
             }
             __syncthreads();                          // B(f+1): the matrix waves have finished item f
             FC_STAMP(1, f, 3);
             if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
             FC_STAMP(1, f, 4);
+        };
+        load_slab(Set0());
+        write_slab(Set0(), (char*)Xs0);
+        if (DEEP) {
+            if (nitems > 1) load_slab(Set1());        // item 1
+            if (nitems > 2) load_slab(Set0());        // item 2
+        } else {
+            if (nitems > 1) load_slab(Set0());
+        }
+        __syncthreads();                              // B0: slab 0 + weights 0 visible (the barrier drains the DMA)
+        if (DEEP) {
+            for (int f = 0; f < nitems; f += 2) {     // item f+1 lives in set 1, item f+2 in set 0
+                step(f, Set1());
+                if (f + 1 < nitems) step(f + 1, Set0());
+            }
+        } else {
+            for (int f = 0; f < nitems; ++f) step(f, Set0());
         }
         __syncthreads();                              // final (kept symmetric with the matrix role)
         return;
