@@ -135,7 +135,9 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool PLAIN = MODE == 0;                 // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU
     constexpr bool DUAL = MODE >= 3;
     constexpr bool ELU = MODE == 2 || MODE == 4;
-    constexpr bool STAGING_DMA = PLAIN;               // which role streams the weight chunks
+    // which role streams the weight chunks: the staging waves when they have no prologue math (PLAIN), else the matrix
+    // waves, one DMA piece per loop trip (measured: each choice loses 5-8 % on the other kind of layer)
+    constexpr bool STAGING_DMA = PLAIN;
     constexpr bool DEEP = PLAIN;                      // two register sets of staged input in flight
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int XSF = NU * 256 + 4;                 // floats per slab buffer (compile time: LDS immediates)
@@ -478,10 +480,14 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     for (int f = 0; f < nitems; ++f) {
         FC_STAMP(0, f, 0);
         FC_STAMP(0, f, 7);
-        if (!STAGING_DMA && f + 1 < nitems && !resident) {
-            const int nc = chunk + 1 == p.nchunk ? 0 : chunk + 1;
-            dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
-        }
+        // the next weight chunk streams in as 1 KiB DMA pieces issued BETWEEN MFMA groups (one per loop trip): a piece
+        // costs the issuing wave ~100 cycles, which is free while its previous MFMAs are still executing but not when
+        // all pieces are issued back to back ahead of the loop
+        const bool stream_w = !STAGING_DMA && f + 1 < nitems && !resident && !(p.ablate & 16);
+        const int nc = chunk + 1 == p.nchunk ? 0 : chunk + 1;
+        const float* wsrc = wt_tile + (size_t)nc * p.Wbuf + rtid * 4;
+        float* wdst = smem + ((f + 1) & 1) * p.Wbuf + __builtin_amdgcn_readfirstlane(wid) * 256;
+        int wleft = stream_w ? p.Wbuf : 0;            // floats still to request (1024 per piece over the 4 waves)
         const float* Ws = smem + (resident ? chunk : (f & 1)) * p.Wbuf + a_off;
         const float* Xb = Xs0 + (f & 1) * XSF + b_off;
         // k-steps (2 k values each): kidx = 2*ks + hi = kk*CC + 2*c2 + hi, in groups of two.  The loop is software
@@ -521,6 +527,10 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_group(fa0, fb0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (wleft > 0) {
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)wdst, 16, 0, 0);
+                    wsrc += 1024; wdst += 1024; wleft -= 1024;
+                }
                 load_group(g + 2, ko, fa0, fb0);
                 ko = kofs2[g + 3];
                 __builtin_amdgcn_sched_barrier(0);
@@ -528,6 +538,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        for (; wleft > 0; wleft -= 1024, wsrc += 1024, wdst += 1024)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)wdst, 16, 0, 0);
         FC_STAMP(0, f, 1);
         const bool tile_done = chunk == p.nchunk - 1;
         if (tile_done) {
