@@ -60,6 +60,7 @@ SYMBOLS = {
     "fc_engine_work": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(FcWork)]),
     "fc_engine_profile": (C.c_int, [_P, C.c_int]),
     "fc_engine_profile_read": (C.c_int, [_P, C.POINTER(FcProf)]),
+    "fc_debug_timeline": (C.c_int, [_P]),
 }
 
 _lib = None

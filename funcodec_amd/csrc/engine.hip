@@ -47,6 +47,7 @@ struct ConvLayer {
     // GEMM view
     int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
     int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
+    bool row = false;       // stride-1 row staging (kernels.hip)
     float *wt = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;   // device
     int* koff = nullptr;                                                        // device
 };
@@ -170,7 +171,16 @@ void add_conv_expect(fc_engine* e, ConvLayer& L) {
 void choose_tiling(ConvLayer& L);
 
 ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed = false,
-                  bool dual = false, bool small_n = false) {
+                  bool dual = false, bool small_n = false);
+ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n);
+ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n) {
+    ConvLayer L = mk_conv_(prefix, cin, cout, k, stride, transposed, dual, small_n);
+    if (getenv("FC_DUMP_PLAN"))     // tuning aid: the tiling every layer gets
+        fprintf(stderr, "plan %-36s cin=%4d M=%4d k=%2d s=%d  tile %3dx%3d CC=%2d nchunk=%3d %s\n", L.prefix.c_str(), L.cin, L.M,
+                L.gk, L.gstride, L.BM, L.BN, L.CC, L.nchunk, L.row ? "row" : "");
+    return L;
+}
+ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n) {
     ConvLayer L;
     L.prefix = prefix; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.transposed = transposed;
     L.dual = dual; L.small_n = small_n;
@@ -290,9 +300,24 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
         const int n = cc * 2;
         if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
         if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN, L.BM, dual_eff)) break;
-        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1)) >
+        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 0) >
             (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) break;
         cc = n;
+    }
+    // stride-1 layers: row staging (16-byte loads and LDS stores) lifts the register bound on the chunk; take it when
+    // it allows at least the same chunk
+    static const int row_env = getenv("FC_ROW") ? atoi(getenv("FC_ROW")) : 1;
+    L.row = false;
+    if (row_env && L.gstride == 1) {
+        int best = 0;
+        for (int n = 4; n <= 64 && n <= L.cin; n *= 2) {
+            if (!fc::conv_row_ok(L.gk, L.gstride, n, L.BM, L.BN, L.cin, dual_eff)) continue;
+            if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 1) >
+                (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) continue;
+            best = n;
+        }
+        if (best > cc || (best == cc && !plain)) { L.row = true; cc = best; }   // equal chunk + no prologue: the general
+                                                                                // path's two register sets win
     }
     L.CC = cc;
     L.nchunk = ceil_div_i(L.cin, cc);
@@ -330,7 +355,7 @@ int pack_gemm(fc_engine* e, ConvLayer& L, const std::vector<float>& wg /*[M][cin
     for (int m = 0; m < L.M; ++m) bpad[m] = bg[m];
     if (upload(e, packed, &L.wt)) return 1;
     if (upload(e, bpad, &L.bias)) return 1;
-    if (upload(e, fc::conv_koff_table(L.gk, L.gstride, L.CC, L.BN), &L.koff)) return 1;
+    if (upload(e, fc::conv_koff_table(L.gk, L.gstride, L.CC, L.BN, L.row ? 1 : 0), &L.koff)) return 1;
     return 0;
 }
 
@@ -444,7 +469,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     c.wt = L.wt; c.bias = L.bias; c.koff = L.koff; c.zeros = e->zeros;
     c.B = cx.B; c.Cin = L.cin; c.Tin = Tin; c.M = L.M;
     c.k = L.gk; c.stride = L.gstride; c.padL = g.padL; c.padR = g.padR;
-    c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk;
+    c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
     Act out;
     out.C = L.cout; out.T = g.Tout;
     if (L.transposed) {
@@ -480,10 +505,11 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
         int cls = 0;
         if (e->profiling) {
             int mode = 0, nu = 0;
-            fc::conv_variant(c, &mode, &nu);
+            int row = 0;
+            fc::conv_variant(c, &mode, &nu, &row);
             char nm[64];
-            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d>", L.BM, L.BN, L.BM == 128 ? 2 : 1,
-                     L.BM == 128 ? 2 : 4, mode, nu);
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM == 128 ? 2 : 1,
+                     L.BM == 128 ? 2 : 4, mode, nu, row ? "true" : "false");
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);

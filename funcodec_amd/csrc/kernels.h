@@ -33,17 +33,19 @@ struct ConvLaunch {
     int up_r = 0, trimL = 0, Tfinal = 0;          // transposed-conv scatter epilogue when up_r > 0
     double* partials = nullptr;   // [B][nblk][2] (sum, sumsq) or null
     int BM = 128, BN = 128, CC = 2, nchunk = 1;   // tiling chosen at pack time
+    int row = 0;                  // stride-1 row staging (conv_row_ok() at pack time)
 };
 
 int conv_nblk(const ConvLaunch& c);                         // stat partials per utterance
 size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
-size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab);
+size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab, int row);
+bool conv_row_ok(int k, int stride, int CC, int BM, int BN, int Cin, bool dual);   // row staging usable with this chunking?
 bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual);
 int conv_wgs_per_cu(int BM);
-std::vector<int> conv_koff_table(int k, int stride, int CC, int BN);
+std::vector<int> conv_koff_table(int k, int stride, int CC, int BN, int row);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
-void conv_variant(const ConvLaunch& c, int* mode, int* nu);    // template instantiation launch_conv() picks
+void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row);    // template instantiation launch_conv() picks
 
 // Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)
 hipError_t launch_gn_finalize(const double* partials, int nblk, double count, const float* gamma,

@@ -53,6 +53,8 @@ struct ConvArgs {
     int CC, nchunk, Kc;
     int Wbuf;               // floats per packed weight chunk (multiple of 1024)
     int slabW, PL, rowStride, xs_floats;
+    int row;                // stride-1 row staging (16-byte loads / LDS stores, one channel row per 32 or 64 lanes)
+    int xsf;                // floats per slab buffer
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
     const float* zeros;     // >= 4 zero floats in HBM: DMA source of padding elements
     const int* koff;        // [koff_n] B-operand LDS float offset per k-step (padded, multiple of 4)
@@ -128,7 +130,7 @@ __device__ unsigned long long g_timeline[2][24][8];
 #else
 #define FC_STAMP(role_, f_, slot_) do {} while (0)
 #endif
-template <int BM, int BN, int WM, int WN, int MODE, int NU>
+template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW>
 __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(WM * WN == 4, "4 matrix waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool STAGING_DMA = PLAIN;
     constexpr bool DEEP = PLAIN;                      // two register sets of staged input in flight
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int XSF = NU * 256 + 4;                 // floats per slab buffer (compile time: LDS immediates)
+    const int XSF = ROW ? p.xsf : NU * 256 + 4;       // floats per slab buffer
     float* Xs0 = smem + 2 * p.Wbuf;                   // slab, double buffered
     const int cin_pad = (p.Cin + 1) & ~1;             // keeps everything behind the tables 16-byte aligned
     float2* tab0 = (float2*)(Xs0 + 2 * XSF);
@@ -176,10 +178,199 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
 
     if (role == 1) {
         // =========================================== staging waves =====================================
-        const int total = p.CC * p.slabW;             // <= 256 * NU
-        const float divv = (MODE == 1 && p.div0) ? p.div0[b] : 1.f;
         const float* __restrict__ s0b = p.src0 + rowbase * p.Tin;     // wave-uniform bases, 32-bit lane offsets
         const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
+        // GroupNorm partial of a finished tile: fixed-order fp64 reduction of the 256 per-lane fp32 partials the
+        // matrix waves left in LDS (done here because the staging waves idle at the barrier anyway)
+        auto flush_stats = [&](int tile) __attribute__((always_inline)) {
+            if (!p.partials || wid != 0) return;
+            const float2* r = red + (tile & 1) * 256;
+            double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float2 v = r[lane + 64 * j]; d1 += (double)v.x; d2 += (double)v.y; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                d1 += __shfl_xor(d1, o, 64);
+                d2 += __shfl_xor(d2, o, 64);
+            }
+            if (lane == 0) {
+                const int nblk = ntiles * gridDim.y;
+                const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
+                p.partials[slot_p] = d1;
+                p.partials[slot_p + 1] = d2;
+            }
+        };
+        // PLAIN staging (no prologue math) has time to spare: these waves then also stream the weight chunks (global ->
+        // LDS DMA); issuing a DMA piece between MFMAs costs the issuing wave 100+ cycles
+        if (STAGING_DMA) {
+            dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
+            if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
+        }
+        if constexpr (ROW) {
+            // ---------------------------------------------------------------------------------------------
+            // Row staging (stride-1 layers).  A slab row = one input channel, BN main columns + k-1 tail columns.
+            // BN/4 lanes cover the main columns of a row with ONE 16-byte global load and ONE 16-byte LDS store each
+            // (64/(BN/4) rows per wave instruction, the 4 waves take consecutive row groups: 4 or 8 rows per round,
+            // CC/rows-per-round rounds per item); the CC*(k-1) tail elements go one per thread.  Per element that is
+            // 1/4 load + 1/4 store + the prologue math, against 1 load + 1 address add + 1 table read + 1 store per
+            // element of the general path, and the only per-element registers are the values themselves, so the K
+            // chunk of an item is bounded by LDS and not by the staging registers.
+            // Edge tiles (reflect / zero padding inside the slab) load the 4 columns of a lane with 4 dword loads
+            // from per-tile column offsets instead.
+            // ---------------------------------------------------------------------------------------------
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            constexpr int LPR = BN / 4, RPI = 64 / LPR, RPR = 4 * RPI;     // lanes per row, rows per instruction / round
+            constexpr int MAXR = DUAL ? 4 : 8;
+            const int NR = p.CC / RPR;                     // rounds per item (host: 1 <= NR <= MAXR)
+            const int rsub = wid * RPI + lane / LPR;       // my row inside a round
+            const int c4 = lane % LPR;                     // my 4-column group
+            const unsigned slot0 = 4u * (unsigned)(rsub * p.rowStride + 4 * c4);
+            const unsigned lds_round = 4u * (unsigned)(RPR * p.rowStride);
+            const size_t src_round = (size_t)RPR * p.Tin;  // floats between the rows of consecutive rounds
+            const int km1 = p.k - 1;
+            const bool has_tail = rtid < p.CC * km1;
+            const int t_cl = has_tail ? rtid / km1 : 0, t_j = has_tail ? rtid - t_cl * km1 : 0;
+            const unsigned t_slot = 4u * (unsigned)(t_cl * p.rowStride + BN + t_j);
+            // per-tile state of the item being LOADED, and of the registers waiting to be written
+            unsigned src_off = 0, eoff[4] = {0, 0, 0, 0}, emask = 0, t_off = 0;
+            bool ld_edge = false, t_ok = true;
+            bool r_edge = false, r_tok = true; unsigned r_emask = 0;
+            f32x4 v0[MAXR], v1[DUAL ? MAXR : 1];
+            float tv0 = 0.f, tv1 = 0.f;
+            int ld_tile = t_begin, ld_chunk = 0, wr_chunk = 0;
+            const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
+            auto resolve = [&](int g, bool& ok) __attribute__((always_inline)) {   // slab column (global time index) -> source index
+                ok = g >= -p.padL && g < hi_lim;
+                int src = g < 0 ? -g : g;
+                src = src >= p.Leff ? refl - src : src;
+                if (p.pad_zero) { src = g; ok = ok && g >= 0; }
+                ok = ok && src < p.Tin;                  // zero padding / zero-extension of short inputs (conv.py:89-93)
+                return ok ? src : 0;
+            };
+            auto setup_tile = [&](int tbase) __attribute__((always_inline)) {
+                ld_edge = !(tbase >= 0 && tbase + p.slabW <= p.Tin);
+                if (!ld_edge) {
+                    src_off = 4u * (unsigned)(rsub * p.Tin + tbase + 4 * c4);
+                    t_off = 4u * (unsigned)(t_cl * p.Tin + tbase + BN + t_j);
+                    t_ok = true;
+                } else {
+                    emask = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bool ok;
+                        const int src = resolve(tbase + 4 * c4 + j, ok);
+                        eoff[j] = 4u * (unsigned)(rsub * p.Tin + src);
+                        emask |= (ok ? 1u : 0u) << j;
+                    }
+                    const int src = resolve(tbase + BN + t_j, t_ok);
+                    t_off = 4u * (unsigned)(t_cl * p.Tin + src);
+                }
+            };
+            auto load_slab = [&]() __attribute__((always_inline)) {
+                const int tbase = ld_tile * BN - p.padL;
+                if (ld_chunk == 0) setup_tile(tbase);
+                const size_t cbase = (size_t)(ld_chunk * p.CC) * p.Tin;
+                if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
+                r_edge = ld_edge; r_emask = emask; r_tok = t_ok;
+                if (p.ablate & 4) return;
+                const float* r0 = s0b + cbase;
+                const float* r1 = s1b + cbase;
+                if (!ld_edge) {
+#pragma unroll
+                    for (int r = 0; r < MAXR; ++r) {
+                        if (r < NR) {
+                            v0[r] = *(const f32x4u*)((const char*)(r0 + r * src_round) + src_off);
+                            if (DUAL) v1[r] = *(const f32x4u*)((const char*)(r1 + r * src_round) + src_off);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < MAXR; ++r) {
+                        if (r < NR) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                v0[r][j] = *(const float*)((const char*)(r0 + r * src_round) + eoff[j]);
+                                if (DUAL) v1[r][j] = *(const float*)((const char*)(r1 + r * src_round) + eoff[j]);
+                            }
+                        }
+                    }
+                }
+                if (has_tail) {
+                    tv0 = *(const float*)((const char*)r0 + t_off);
+                    if (DUAL) tv1 = *(const float*)((const char*)r1 + t_off);
+                }
+            };
+            auto prologue = [&](float v, float w, float2 a, float2 a1) __attribute__((always_inline)) {
+                if (PLAIN) return v;
+                v = fmaf(v, a.x, a.y);
+                if (DUAL) v = v + fmaf(w, a1.x, a1.y);
+                if (ELU) v = elu_f(v, p.alpha);
+                return v;
+            };
+            auto write_slab = [&](char* Xd) __attribute__((always_inline)) {
+                const int c0 = wr_chunk * p.CC;
+                if (++wr_chunk == p.nchunk) wr_chunk = 0;
+                float2 a[PLAIN ? 1 : MAXR], a1[DUAL ? MAXR : 1], ta = {1.f, 0.f}, ta1 = {1.f, 0.f};
+                if (!PLAIN) {                             // all table reads ahead of the stores (possible aliasing)
+#pragma unroll
+                    for (int r = 0; r < MAXR; ++r) {
+                        if (r < NR) {
+                            a[r] = tab0[c0 + r * RPR + rsub];
+                            if (DUAL) a1[r] = tab1[c0 + r * RPR + rsub];
+                        }
+                    }
+                    ta = tab0[c0 + t_cl];
+                    if (DUAL) ta1 = tab1[c0 + t_cl];
+                }
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r) {
+                    if (r < NR) {
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = prologue(v0[r][j], DUAL ? v1[r][j] : 0.f, PLAIN ? ta : a[r], DUAL ? a1[r] : ta1);
+                            if (r_edge) v[j] = ((r_emask >> j) & 1u) ? v[j] : 0.f;
+                        }
+                        *(f32x4*)(Xd + slot0 + r * lds_round) = v;
+                    }
+                }
+                if (has_tail) {
+                    float v = prologue(tv0, tv1, ta, ta1);
+                    v = r_tok ? v : 0.f;
+                    *(float*)(Xd + t_slot) = v;
+                }
+            };
+            if (STAGING_DMA) {
+                dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
+                if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
+            }
+            load_slab();
+            write_slab((char*)Xs0);
+            if (nitems > 1) load_slab();
+            __syncthreads();                              // B0
+            int st_tile = t_begin, st_chunk = 0;
+            for (int f = 0; f < nitems; ++f) {
+                FC_STAMP(1, f, 0);
+                if (STAGING_DMA && f + 1 < nitems && !resident) {
+                    const int nc = st_chunk + 1 == p.nchunk ? 0 : st_chunk + 1;
+                    dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
+                }
+                if (f + 1 < nitems) {
+                    write_slab((char*)(Xs0 + ((f + 1) & 1) * XSF));
+                    FC_STAMP(1, f, 1);
+                    if (f + 2 < nitems) load_slab();
+                    FC_STAMP(1, f, 2);
+                }
+                __syncthreads();                          // B(f+1)
+                FC_STAMP(1, f, 3);
+                if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
+                FC_STAMP(1, f, 4);
+            }
+            __syncthreads();                              // final (kept symmetric with the matrix role)
+            return;
+        }
+        const int total = p.CC * p.slabW;             // <= 256 * NU
+        const float divv = (MODE == 1 && p.div0) ? p.div0[b] : 1.f;
         // element e = rtid + 256*u of every chunk of every tile maps to the same (local channel cl, slab column tau):
         //   base0[u] = cl*Tin + tau      slot[u] = LDS float index | cl << 16
         // Per-element descriptors, all in BYTES and unpacked (every extraction / shift would be a VALU instruction per
@@ -320,32 +511,6 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             else write_slab_t(set_tag, Xd, std::false_type(), std::true_type());
         };
 
-        // GroupNorm partial of a finished tile: fixed-order fp64 reduction of the 256 per-lane fp32 partials the
-        // matrix waves left in LDS (done here because the staging waves idle at the barrier anyway)
-        auto flush_stats = [&](int tile) __attribute__((always_inline)) {
-            if (!p.partials || wid != 0) return;
-            const float2* r = red + (tile & 1) * 256;
-            double d1 = 0.0, d2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const float2 v = r[lane + 64 * j]; d1 += (double)v.x; d2 += (double)v.y; }
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                d1 += __shfl_xor(d1, o, 64);
-                d2 += __shfl_xor(d2, o, 64);
-            }
-            if (lane == 0) {
-                const int nblk = ntiles * gridDim.y;
-                const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
-                p.partials[slot_p] = d1;
-                p.partials[slot_p + 1] = d2;
-            }
-        };
-        // PLAIN staging (no prologue math) has time to spare: these waves then also stream the weight chunks (global ->
-        // LDS DMA); issuing a DMA piece between MFMAs costs the issuing wave 100+ cycles
-        if (STAGING_DMA) {
-            dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
-            if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
-        }
         using Set0 = std::integral_constant<int, 0>;
         using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
         int st_tile = t_begin, st_chunk = 0;
@@ -586,6 +751,9 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.slabW = (c.BN - 1) * c.stride + c.k;
     a.PL = ceil_div(a.slabW, c.stride);
     a.rowStride = a.PL * c.stride;
+    a.row = c.row;
+    if (c.row) { a.rowStride = (a.slabW + 3) & ~3; a.PL = a.rowStride; }   // 16-byte aligned rows
+    a.xsf = c.CC * a.rowStride + 4;
     a.xs_floats = ((c.CC * a.rowStride + 255) & ~255) + 4;   // whole 256-float DMA rounds + a dummy slot
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.zeros = c.zeros;
@@ -602,9 +770,10 @@ static ConvArgs make_args(const ConvLaunch& c) {
 
 // B-operand LDS offset (floats) of every k-step of a chunk: k-step ks covers kidx = 2*ks + {0,1} = kk*CC + 2*c2 + {0,1}
 // -> offset = 2*c2*rowStride + (kk % stride)*PL + kk / stride.  Padded to a multiple of 4 entries.
-std::vector<int> conv_koff_table(int k, int stride, int CC, int BN) {
+std::vector<int> conv_koff_table(int k, int stride, int CC, int BN, int row) {
     const int slabW = (BN - 1) * stride + k;
-    const int PL = ceil_div(slabW, stride), rowStride = PL * stride;
+    int PL = ceil_div(slabW, stride), rowStride = PL * stride;
+    if (row) { rowStride = (slabW + 3) & ~3; PL = rowStride; }
     const int nks = k * CC / 2, half_cc = CC / 2;
     std::vector<int> t(conv_koff_len(k, CC), 0);
     for (int ks = 0; ks < nks; ++ks) {
@@ -619,11 +788,21 @@ int conv_wbuf_floats(int k, int CC, int BM) { return ((((k * CC + 7) & ~7) * BM 
 
 int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM); }
 
-size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab) {
+// Row staging (stride 1): rows per round = 4 waves x (64 lanes / (BN/4) lanes per row); the kernel holds at most 8
+// rounds of one source (4 of two) in registers.
+bool conv_row_ok(int k, int stride, int CC, int BM, int BN, int Cin, bool dual) {
+    if (stride != 1 || (BN != 128 && BN != 256)) return false;
+    const int rpr = 4 * (64 / (BN / 4));
+    if (CC % rpr != 0 || Cin % CC != 0) return false;
+    if (CC / rpr > (dual ? 4 : 8)) return false;
+    return CC * (k - 1) <= 256 && (size_t)conv_wbuf_floats(k, CC, BM) <= 8192;
+}
+
+size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab, int row) {
     const int slabW = (BN - 1) * stride + k;
-    const int rowStride = ceil_div(slabW, stride) * stride;
+    const int rowStride = row ? ((slabW + 3) & ~3) : ceil_div(slabW, stride) * stride;
     const int img = CC * rowStride;
-    const int xs = (img <= 8 * 256 ? 8 : 16) * 256 + 4;            // XSF of the NU variant the launcher will pick
+    const int xs = row ? img + 4 : (img <= 8 * 256 ? 8 : 16) * 256 + 4;   // XSF of the variant the launcher will pick
     const size_t koff_bytes = (size_t)conv_koff_len(k, CC) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
            (size_t)BM * sizeof(float) + 2 * 256 * 8;
@@ -641,13 +820,13 @@ bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual) {
 
 size_t conv_lds_bytes(const ConvLaunch& c) {
     const int ntab = c.s1.ptr ? 2 : ((c.s0.aff || c.s0.div || c.elu) ? 1 : 0);
-    return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, ntab);
+    return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, ntab, c.row);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int NU>
+template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW>
 static hipError_t launch_conv_k(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     static bool attr_done = false;
-    auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE, NU>;
+    auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE, NU, ROW>;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
@@ -658,8 +837,9 @@ static hipError_t launch_conv_k(const ConvArgs& a, dim3 grid, size_t lds, hipStr
 
 template <int BM, int BN, int WM, int WN, int MODE>
 static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t lds, hipStream_t st) {
-    if (total <= 256 * 8) return launch_conv_k<BM, BN, WM, WN, MODE, 8>(a, grid, lds, st);
-    return launch_conv_k<BM, BN, WM, WN, MODE, 16>(a, grid, lds, st);
+    if (a.row) return launch_conv_k<BM, BN, WM, WN, MODE, 8, true>(a, grid, lds, st);
+    if (total <= 256 * 8) return launch_conv_k<BM, BN, WM, WN, MODE, 8, false>(a, grid, lds, st);
+    return launch_conv_k<BM, BN, WM, WN, MODE, 16, false>(a, grid, lds, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -673,9 +853,10 @@ static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 gri
 }
 
 // which template instantiation launch_conv() will pick (profiling labels)
-void conv_variant(const ConvLaunch& c, int* mode, int* nu) {
+void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row) {
     const ConvArgs a = make_args(c);
-    *nu = a.CC * a.rowStride <= 256 * 8 ? 8 : 16;
+    *row = a.row;
+    *nu = a.row || a.CC * a.rowStride <= 256 * 8 ? 8 : 16;
     if (c.s1.ptr) *mode = c.elu ? 4 : 3;
     else if (c.s0.aff || c.s0.div || c.elu) *mode = c.elu ? 2 : 1;
     else *mode = 0;
@@ -684,7 +865,12 @@ void conv_variant(const ConvLaunch& c, int* mode, int* nu) {
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
-    if (c.CC * (ceil_div((c.BN - 1) * c.stride + c.k, c.stride) * c.stride) > SLAB_PER_THREAD * 256 || lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
+    if (lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
+    if (c.row) {
+        if (!conv_row_ok(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr) || c.s0.div) return hipErrorInvalidValue;
+    } else if (c.CC * (ceil_div((c.BN - 1) * c.stride + c.k, c.stride) * c.stride) > SLAB_PER_THREAD * 256) {
+        return hipErrorInvalidValue;
+    }
     // one resident wave of workgroups (2 per CU): each takes a contiguous range of N tiles
     const int ntiles = ceil_div(c.Tout, c.BN), mtiles = ceil_div(c.M, c.BM);
     static const int target_env = getenv("FC_TARGET_WGS") ? atoi(getenv("FC_TARGET_WGS")) : 0;

@@ -43,7 +43,7 @@ us = sum(p["total_ms"] for p in prof if p["kernel"].startswith("conv")) * 1e3 / 
 print(f"ablate={os.environ.get('FC_ABLATE','0'):>3s} {prefix} T={T} elu={elu}: conv kernel {us:8.1f} us")
 
 tl = (C.c_ulonglong * (2 * 24 * 8))()
-if hasattr(eng.lib, "fc_debug_timeline") and eng.lib.fc_debug_timeline(tl) == 0 and any(tl):
+if eng.lib.fc_debug_timeline(C.cast(tl, C.c_void_p)) == 0 and any(tl):
     import numpy as np
     a = np.array(list(tl), dtype=np.int64).reshape(2, 24, 8)
     t0 = a[a > 0].min()
