@@ -94,7 +94,7 @@ struct Ctx {
 int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
 const char* kLstmClass = "lstm_wave_kernel (whole recurrence of one SLSTM block, incl. launch gaps)";
-const char* kRvqClass = "rvq_encode_kernel<128>";
+const char* kRvqClass = "rvq_encode_kernel<D, RS> (all stages of the residual quantiser)";
 
 }  // namespace
 
@@ -113,6 +113,7 @@ struct fc_engine {
     std::map<std::string, LstmBlock*> lstm_by_prefix;
     // quantiser
     float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
+    float* cb_frag = nullptr;                // the codebooks in MFMA B-fragment order (kernels.hip rvq_encode_kernel), or null
     float* zeros = nullptr;                  // 64 zero floats
     std::vector<void*> dev_allocs;
     // optional event timing
@@ -639,7 +640,7 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
         if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, emb, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
             return fail("combine launch failed");
         ProfSpan sp(e, cx, e->profiling ? e->prof_class(kRvqClass) : 0, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D, 0.0);
-        if (fc::launch_rvq_encode(emb, B * Tf, D, e->arch.codebook_size, n_q, e->cb, e->enorm, codes, quantized, qbdt,
+        if (fc::launch_rvq_encode(emb, B * Tf, D, e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quantized, qbdt,
                                   sub_quants, Tf, cx.st) != hipSuccess)
             return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256})");
     }
@@ -795,6 +796,18 @@ int fc_engine_finalize(fc_engine* e) {
     }
     if (upload(e, std::vector<float>(64, 0.f), &e->zeros)) return 1;
     if (upload(e, E, &e->cb)) return 1;
+    if (K % 16 == 0 && D % 16 == 0) {
+        // fragment order: [stage][16-code tile][q = d/16][g = (d%16)/4][code in tile][d%4]: lane (g, code) of a wave reads
+        // 16 contiguous bytes and a whole wave instruction reads 1 KiB contiguous (row-major rows give 64-byte pieces)
+        std::vector<float> F((size_t)nq * K * D);
+        for (int i = 0; i < nq; ++i)
+            for (int c = 0; c < K; ++c)
+                for (int d = 0; d < D; ++d) {
+                    const size_t tile = (size_t)i * (K / 16) + c / 16;
+                    F[((tile * (D / 16) + d / 16) * 4 + (d % 16) / 4) * 64 + (size_t)(c % 16) * 4 + d % 4] = E[((size_t)i * K + c) * D + d];
+                }
+        if (upload(e, F, &e->cb_frag)) return 1;
+    }
     if (upload(e, en, &e->enorm)) return 1;
     // opt in to the dynamic LDS the conv kernels ask for is not needed (<= 64 KiB); host copies are dropped
     e->host.clear();
@@ -890,7 +903,7 @@ int fc_rvq_encode(fc_engine* e, const float* x, int N, int n_q, int64_t* codes, 
     (void)workspace; (void)workspace_bytes;
     if (!x || !codes || N <= 0) return fail("bad argument");
     if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
-    HIP_TRY(fc::launch_rvq_encode(x, N, e->arch.dimension, e->arch.codebook_size, n_q, e->cb, e->enorm, codes, quantized,
+    HIP_TRY(fc::launch_rvq_encode(x, N, e->arch.dimension, e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quantized,
                                   nullptr, nullptr, N, (hipStream_t)stream));
     return 0;
 }

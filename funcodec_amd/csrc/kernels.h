@@ -63,7 +63,8 @@ hipError_t launch_volume(const float* wav, int B, int T, float* scale, hipStream
 hipError_t launch_transpose_btd(const float* in, int B, int T, int D, float* out, hipStream_t st);
 
 // Residual vector quantiser, all stages fused.  x [N][D] rows; cb [nq][K][D]; enorm [nq][K].
-hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* enorm,
+hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* cb_frag /* or null */,
+                             const float* enorm,
                              int64_t* codes /*[nq][N]*/, float* quant /*[N][D] or null*/,
                              float* quant_bdt /*[B][D][Tf] or null*/, float* subq /*[nq][B][D][Tf] or null*/,
                              int Tf, hipStream_t st);

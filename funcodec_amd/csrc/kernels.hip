@@ -1019,24 +1019,30 @@ hipError_t launch_transpose_btd(const float* in, int B, int T, int D, float* out
 //                d = 16q + 4g + j  for q = 0..D/16-1, j = 0..3, g = 0..3 (innermost);
 //      |e|^2   : precomputed at load time (engine.hip), sequential d = 0..D-1, squares rounded separately.
 // =================================================================================================
-template <int D>
+// RS = row sets of 16 rows per workgroup.  The stage is L2-bandwidth bound when one codebook load feeds only 16 rows
+// (every workgroup streams the whole 512 KiB stage codebook: 250 workgroups x 512 KiB = 128 MiB per stage at config B);
+// with RS = 2 the same registers feed two independent 16-row MFMA accumulators (same arithmetic per row).
+template <int D, int RS>
 __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict__ x, int N, int K, int nq,
-                                                         const float* __restrict__ cb, const float* __restrict__ enorm,
+                                                         const float* __restrict__ cb, const float* __restrict__ cbf,
+                                                         const float* __restrict__ enorm,
                                                          int64_t* __restrict__ codes, float* __restrict__ quant,
-                                                         float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf) {
+                                                         float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf,
+                                                         int ablate) {
     constexpr int NQ4 = D / 16;
-    __shared__ __attribute__((aligned(16))) float R[16][D];
-    __shared__ __attribute__((aligned(16))) float Q[16][D];
-    __shared__ float xn[16];
-    __shared__ float bestv[8][16];
-    __shared__ int besti[8][16];
-    __shared__ int sel[16];
+    constexpr int ROWS = 16 * RS;
+    __shared__ __attribute__((aligned(16))) float R[ROWS][D];
+    __shared__ __attribute__((aligned(16))) float Q[ROWS][D];
+    __shared__ float xn[ROWS];
+    __shared__ float bestv[8][ROWS];
+    __shared__ int besti[8][ROWS];
+    __shared__ int sel[ROWS];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = blockIdx.x * ROWS;
 
-    for (int e = tid; e < 16 * D; e += 512) {
+    for (int e = tid; e < ROWS * D; e += 512) {
         const int r = e / D, d = e - r * D;
         const int n = row0 + r;
         R[r][d] = n < N ? x[(size_t)n * D + d] : 0.f;
@@ -1045,11 +1051,13 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
     const int codes_per_wave = (K >> 3) < 16 ? 16 : (K >> 3);   // 8 waves: two per SIMD hide the codebook-row load latency
     const bool wactive = wid * codes_per_wave < K;            // small codebooks keep only K/16 waves busy
 
+    f32x4 b0[NQ4];                                               // first codebook fragment of the stage (requested one stage ahead)
     for (int i = 0; i < nq; ++i) {
         __syncthreads();
-        if (tid < 64) {   // |x|^2
+        if (tid < 4 * ROWS) {   // |x|^2
             const int r = tid >> 2, j = tid & 3;
             float s = 0.f;
+#pragma unroll 8
             for (int d = j * (D / 4); d < (j + 1) * (D / 4); ++d) {
                 const float v = R[r][d];
                 s = __fadd_rn(s, __fmul_rn(v, v));
@@ -1058,70 +1066,91 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
             const float s_all = __fadd_rn(s_pair, __shfl_xor(s_pair, 2, 64));  // (p0+p1)+(p2+p3)
             if (j == 0) xn[r] = s_all;
         }
-        f32x4 a4[NQ4];
+        f32x4 a4[RS][NQ4];
 #pragma unroll
-        for (int q = 0; q < NQ4; ++q) {
-            const f32x4 v = *(const f32x4*)&R[r16][16 * q + 4 * g];
-            a4[q] = v + v;   // 2*x, exact
-        }
+        for (int s2 = 0; s2 < RS; ++s2)
+#pragma unroll
+            for (int q = 0; q < NQ4; ++q) {
+                const f32x4 v = *(const f32x4*)&R[16 * s2 + r16][16 * q + 4 * g];
+                a4[s2][q] = v + v;   // 2*x, exact
+            }
         __syncthreads();
-        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int bidx[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-        float xr[4];
+        float best[RS][4];
+        int bidx[RS][4];
+        float xr[RS][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xr[r] = xn[4 * g + r];
+        for (int s2 = 0; s2 < RS; ++s2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { best[s2][r] = -INFINITY; bidx[s2][r] = 0x7fffffff; xr[s2][r] = xn[16 * s2 + 4 * g + r]; }
         const float* cbi = cb + (size_t)i * K * D;
-        // two code tiles per iteration: independent accumulators hide the 40-cycle dependent-MFMA latency and
-        // keep 2*NQ4 16-byte codebook loads in flight; each (row, code) chain keeps its own d order.
-        constexpr bool TWO = (D <= 128);
-        for (int nt = 0; wactive && nt < codes_per_wave; nt += (TWO ? 32 : 16)) {
-            const int codeA = wid * codes_per_wave + nt + r16;
-            const bool hasB = TWO && (nt + 16 < codes_per_wave);
-            const int codeB = hasB ? codeA + 16 : codeA;
-            const float* erowA = cbi + (size_t)codeA * D + 4 * g;
-            const float* erowB = cbi + (size_t)codeB * D + 4 * g;
-            f32x4 bA[NQ4], bB[TWO ? NQ4 : 1];
+        // One 16-code tile per trip, software pipelined: the codebook fragment of tile n+1 is requested before the 4*NQ4
+        // MFMAs of tile n are issued (two register buffers), so the L2 latency of the stream hides behind the matrix work;
+        // the second wave on the SIMD fills the dependent-MFMA bubbles.  Each (row, code) chain keeps its own d order.
+        const int ntile = wactive ? codes_per_wave >> 4 : 0;
+        const int code0 = wid * codes_per_wave;
+        auto frag_ptr = [&](int stage, int t) __attribute__((always_inline)) {
+            const int code = code0 + 16 * t;
+            return cbf ? cbf + ((size_t)stage * K + code) * D + lane * 4 : cb + ((size_t)stage * K + code + r16) * D + 4 * g;
+        };
+        const int qstep = cbf ? 256 : 16;
+        auto load_tile = [&](int stage, int t, f32x4 (&bq)[NQ4]) __attribute__((always_inline)) {
+            const float* e0 = frag_ptr(stage, t);
 #pragma unroll
-            for (int q = 0; q < NQ4; ++q) {
-                bA[q] = *(const f32x4*)(erowA + 16 * q);
-                if (TWO) bB[q] = *(const f32x4*)(erowB + 16 * q);
+            for (int q = 0; q < NQ4; ++q) bq[q] = (ablate & 2) ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(e0 + qstep * q);
+        };
+        auto do_tile = [&](int t, const f32x4 (&bq)[NQ4]) __attribute__((always_inline)) {
+            const int code = code0 + 16 * t + r16;
+            const float en = enorm[(size_t)i * K + code];
+            f32x4 acc[RS];
+#pragma unroll
+            for (int s2 = 0; s2 < RS; ++s2) acc[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (!(ablate & 1)) {
+#pragma unroll
+                for (int q = 0; q < NQ4; ++q)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int s2 = 0; s2 < RS; ++s2)
+                            acc[s2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s2][q][j], bq[q][j], acc[s2], 0, 0, 0);
             }
-            f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < NQ4; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], bA[q][j], accA, 0, 0, 0);
-                    if (TWO) accB = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], bB[q][j], accB, 0, 0, 0);
-                }
-            }
-            const float enA = enorm[(size_t)i * K + codeA];
-            const float enB = enorm[(size_t)i * K + codeB];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float dist = -__fadd_rn(__fsub_rn(xr[r], accA[r]), enA);
-                if (dist > best[r]) { best[r] = dist; bidx[r] = codeA; }
-            }
-            if (hasB) {
+            for (int s2 = 0; s2 < RS; ++s2)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dist = -__fadd_rn(__fsub_rn(xr[r], accB[r]), enB);
-                    if (dist > best[r]) { best[r] = dist; bidx[r] = codeB; }
+                    const float dist = -__fadd_rn(__fsub_rn(xr[s2][r], acc[s2][r]), en);
+                    if (dist > best[s2][r]) { best[s2][r] = dist; bidx[s2][r] = code; }
                 }
+        };
+        if (ntile > 0) {
+            f32x4 b1[NQ4];
+            if (i == 0) load_tile(0, 0, b0);
+            int t = 0;
+            for (; t + 2 <= ntile; t += 2) {
+                load_tile(i, t + 1, b1);
+                do_tile(t, b0);
+                if (t + 2 < ntile) load_tile(i, t + 2, b0);
+                do_tile(t + 1, b1);
             }
+            if (t < ntile) do_tile(t, b0);
+            // the next stage's first fragment does not depend on this stage's result: request it now, the arg-max /
+            // residual-update tail of this stage hides its latency
+            if (i + 1 < nq) load_tile(i + 1, 0, b0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int s2 = 0; s2 < RS; ++s2) {
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const float ov = __shfl_xor(best[r], o, 64);
-                const int oi = __shfl_xor(bidx[r], o, 64);
-                if (ov > best[r] || (ov == best[r] && oi < bidx[r])) { best[r] = ov; bidx[r] = oi; }
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const float ov = __shfl_xor(best[s2][r], o, 64);
+                    const int oi = __shfl_xor(bidx[s2][r], o, 64);
+                    if (ov > best[s2][r] || (ov == best[s2][r] && oi < bidx[s2][r])) { best[s2][r] = ov; bidx[s2][r] = oi; }
+                }
+                if (r16 == 0) { bestv[wid][16 * s2 + 4 * g + r] = best[s2][r]; besti[wid][16 * s2 + 4 * g + r] = bidx[s2][r]; }
             }
-            if (r16 == 0) { bestv[wid][4 * g + r] = best[r]; besti[wid][4 * g + r] = bidx[r]; }
         }
         __syncthreads();
-        if (tid < 16) {
+        if (tid < ROWS) {
             float bv = bestv[0][tid];
             int bi = besti[0][tid];
             for (int w = 1; w < 8; ++w) {
@@ -1134,13 +1163,13 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
             if (row0 + tid < N) codes[(size_t)i * N + row0 + tid] = (int64_t)bi;
         }
         __syncthreads();
-        for (int e = tid; e < 16 * D; e += 512) {
+        for (int e = tid; e < ROWS * D; e += 512) {
             const int r = e / D, d = e - r * D;
-            const float qv = cbi[(size_t)sel[r] * D + d];
+            const float qv = (ablate & 8) ? 0.001f : cbi[(size_t)sel[r] * D + d];
             R[r][d] = R[r][d] - qv;
             Q[r][d] = Q[r][d] + qv;
             const int n = row0 + r;
-            if (subq && n < N) {
+            if (subq && n < N && !(ablate & 4)) {
                 const int bb = n / Tf, t = n - bb * Tf;
                 const int Bn = N / Tf;
                 subq[(((size_t)i * Bn + bb) * D + d) * Tf + t] = qv;
@@ -1148,7 +1177,7 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    for (int e = tid; e < 16 * D; e += 512) {
+    for (int e = tid; e < ROWS * D; e += 512) {
         const int r = e / D, d = e - r * D;
         const int n = row0 + r;
         if (n >= N) continue;
@@ -1161,15 +1190,21 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
     }
 }
 
-hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* enorm,
-                             int64_t* codes, float* quant, float* quant_bdt, float* subq, int Tf, hipStream_t st) {
+hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* cb_frag,
+                             const float* enorm, int64_t* codes, float* quant, float* quant_bdt, float* subq, int Tf, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     if (K % 16 != 0 || (K > 128 && K % 128 != 0)) return hipErrorInvalidValue;
-    dim3 grid(ceil_div(N, 16)), block(512);
+    // two row sets per workgroup once there are enough rows to keep ~half the CUs busy that way (L2 traffic halves)
+    static const int ablate = getenv("FC_ABLATE_RVQ") ? atoi(getenv("FC_ABLATE_RVQ")) : 0;
+    static const int two_env = getenv("FC_RVQ_TWO") ? atoi(getenv("FC_RVQ_TWO")) : 0;
+    const bool two = two_env && N >= 2048 && D <= 128;
+    dim3 grid(ceil_div(N, two ? 32 : 16)), block(512);
 #define FC_RVQ_CASE(DD)                                                                                            \
     case DD:                                                                                                       \
-        hipLaunchKernelGGL(rvq_encode_kernel<DD>, grid, block, 0, st, x, N, K, nq, cb, enorm, codes, quant, quant_bdt, \
-                           subq, Tf);                                                                              \
+        if (two) hipLaunchKernelGGL((rvq_encode_kernel<(DD <= 128 ? DD : 16), 2>), grid, block, 0, st, x, N, K, nq, cb, cb_frag, enorm, codes, quant, \
+                                    quant_bdt, subq, Tf, ablate);                                                  \
+        else hipLaunchKernelGGL((rvq_encode_kernel<DD, 1>), grid, block, 0, st, x, N, K, nq, cb, cb_frag, enorm, codes, quant, quant_bdt, \
+                                subq, Tf, ablate);                                                                 \
         break;
     switch (D) {
         FC_RVQ_CASE(16)
@@ -1642,6 +1677,14 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             }
         }
         if (sync) lstm_barrier_wait(p.sync, (unsigned)(s + 1) * arrivals);
+    }
+    // a barrier that timed out (some workgroup was not resident) must not pass for a result: poison this workgroup's
+    // outputs so that the failure is loud downstream (the engine's per-step launch path is the supported fallback)
+    if (__hip_atomic_load(p.sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        for (int i = tid; i < 4 * B * T; i += 256) {
+            const int t = i % T, bu = i / T;
+            p.y[((size_t)(bu / 4) * H + (size_t)blk * 4 + (bu & 3)) * T + t] = __builtin_nanf("");
+        }
     }
 }
 
