@@ -59,6 +59,26 @@ def cpu_baseline(sample_utts: int = 4):
                       f"after a 1 s warm-up; best thread count reported"}
 
 
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in
+    separate rocprofv3 --pmc runs of this same benchmark).  Correction per MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950
+    (checked here on the 32->32 k=1 convs whose byte count is known: 0.320 GB reported for 0.656 GB read), WRITE_SIZE x 1
+    (0.641 GB reported for 0.656 GB written).  None if the committed profile has no entry for this instantiation."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_hbm_traffic_pmc.json")))
+    if not files:
+        return None
+    try:
+        for k in json.load(open(files[-1]))["per_kernel"]:
+            if k["kernel"] == kernel and k["launches"]:
+                return {"bytes_per_launch": round((2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0 / k["launches"]),
+                        "fetch_x2_gb": round(2.0 * k["fetch_kb"] * 1024.0 / 1e9, 3), "write_gb": round(k["write_kb"] * 1024.0 / 1e9, 3),
+                        "launches": k["launches"], "source": os.path.basename(files[-1])}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,7 +189,9 @@ def main():
             conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith("conv_mfma")) / args.steps
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(dom["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": None,
+                               "frac": round(dom["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": (pmc_traffic(dom["kernel"]) or {}).get("bytes_per_launch"),
+                               "traffic_detail": pmc_traffic(dom["kernel"]),
+                               "algorithmic_bytes_per_launch": round(dom["alg_gbs"] * 1e9 * dom["avg_us_per_launch"] * 1e-6) if dom["alg_gbs"] else None,
                                "avg_us_per_launch": dom["avg_us_per_launch"],
                                "launches_per_step": dom["launches_per_step"],
                                "hbm_alg_gbs": dom["alg_gbs"],
