@@ -53,6 +53,7 @@ struct ConvArgs {
     int CC, nchunk, Kc;
     int Wbuf;               // floats per packed weight chunk (multiple of 1024)
     int slabW, PL, rowStride, xs_floats;
+    int xcd_order;          // remap workgroup ids so that the M tiles of one slab share an XCD (FC_XCD_ORDER, default on)
     int row;                // stride-1 row staging (16-byte loads / LDS stores, one channel row per 32 or 64 lanes)
     int xsf;                // floats per slab buffer
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
@@ -124,7 +125,7 @@ __device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int t
 __device__ unsigned long long g_timeline[2][24][8];
 #define FC_STAMP(role_, f_, slot_)                                                                          \
     do {                                                                                                    \
-        if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && wid == 0 && lane == 0 && (f_) < 24)     \
+        if (bx == 1 && mt == 0 && b == 0 && wid == 0 && lane == 0 && (f_) < 24)                               \
             g_timeline[role_][f_][slot_] = (slot_) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
@@ -154,11 +155,26 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     const int tid = threadIdx.x;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 8);    // 0 matrix, 1 staging
     const int rtid = tid & 255, lane = tid & 63, wid = (tid >> 6) & 3;
-    const int b = blockIdx.z, mt = blockIdx.y;
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round robin by linear id, and each XCD has its own L2.
+    // All M tiles of one (utterance, N range) read the SAME input slab, so they are placed on the same XCD and next to
+    // each other in dispatch order: the slab crosses the fabric once per XCD instead of once per M tile (PMC: the
+    // dominant instantiation fetched 2.5x its algorithmic bytes with the plain (x, y, z) order).
+    int bx = blockIdx.x, mt = blockIdx.y, b = blockIdx.z;
+    {
+        const unsigned G = gridDim.x, MT = gridDim.y, groups = G * gridDim.z;
+        if (p.xcd_order && (groups & 7u) == 0u) {
+            const unsigned lin = bx + G * (mt + MT * b);
+            const unsigned xcd = lin & 7u, slot = lin >> 3;
+            const unsigned grp = (slot / MT) * 8u + xcd;      // < groups
+            mt = (int)(slot % MT);
+            bx = (int)(grp % G);
+            b = (int)(grp / G);
+        }
+    }
     const int m0 = mt * BM;
     const int ntiles = (p.Tout + BN - 1) / BN;
-    const int t_begin = (int)(((long long)ntiles * blockIdx.x) / gridDim.x);
-    const int t_end = (int)(((long long)ntiles * (blockIdx.x + 1)) / gridDim.x);
+    const int t_begin = (int)(((long long)ntiles * bx) / gridDim.x);
+    const int t_end = (int)(((long long)ntiles * (bx + 1)) / gridDim.x);
     if (t_begin >= t_end) return;
     const size_t rowbase = (size_t)b * p.Cin;
     const int nitems = (t_end - t_begin) * p.nchunk;  // flattened (tile, chunk) work items of this workgroup
@@ -764,6 +780,8 @@ static ConvArgs make_args(const ConvLaunch& c) {
     static const int skew = getenv("FC_SKEW") ? atoi(getenv("FC_SKEW")) : 0;
     static const int skew_div = getenv("FC_SKEW_DIV") ? atoi(getenv("FC_SKEW_DIV")) : 256;
     a.skew = skew; a.skew_div = skew_div;
+    static const int xcd_order = getenv("FC_XCD_ORDER") ? atoi(getenv("FC_XCD_ORDER")) : 1;
+    a.xcd_order = xcd_order;
     a.ablate = ablate;
     return a;
 }

@@ -157,6 +157,57 @@ def test_conv_padding_edge_lengths(T):
         assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-4, (p, T)
 
 
+@pytest.mark.parametrize("T", [769, 1024, 1291])
+def test_row_staging_interior_and_straddling_tiles(T):
+    """The stride-1 layers of the real recipe use row staging (16-byte loads, one channel row per 32 / 64 lanes, k-1 tail
+    columns per thread): lengths with interior tiles, a last tile that is exactly full, and one that straddles; k = 1, 3,
+    7 and the 2-tap transposed-conv GEMM; 32-, 64- and 128-row tiles."""
+    import torch_oracle as TO
+    m = engine_for("ds640", 0)
+    orc = oracle_for("ds640", 0)
+    gen = torch.Generator().manual_seed(T)
+    for p in ("encoder.model.1.shortcut.conv", "encoder.model.1.block.1.conv", "encoder.model.4.block.3.conv",
+              "decoder.model.13.block.1.conv", "decoder.model.18.conv", "decoder.model.10.shortcut.conv"):
+        w = orc.sd[p + ".conv.weight"]
+        x = torch.randn(2, w.shape[1], T, generator=gen)
+        for elu in (False, True):
+            ref = TO.sconv1d(F.elu(x) if elu else x, *orc._p(p), 1, orc.eps)
+            got = m.engine.layer_forward(p, x, apply_elu=elu).cpu()
+            assert got.shape == ref.shape and (got - ref).abs().max().item() < LAYER_ABS_TOL, (p, T, elu)
+    for p in ("decoder.model.15.convtr", "decoder.model.12.convtr"):
+        w = orc.sd[p + ".convtr.weight"]
+        x = torch.randn(2, w.shape[0], T // 2, generator=gen)
+        ref = TO.sconvtr1d(x, *orc._p(p), w.shape[2] // 2, orc.eps)
+        got = m.engine.layer_forward(p, x).cpu()
+        assert got.shape == ref.shape and (got - ref).abs().max().item() < LAYER_ABS_TOL, (p, T)
+
+
+def test_tile_order_and_staging_scheme_do_not_change_results():
+    """FC_XCD_ORDER only permutes which workgroup computes which tile: results must be bit-identical.  FC_ROW=0 (element
+    staging everywhere, other K chunking) changes the summation order across chunks: same codes, waveform within tolerance."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, torch, numpy as np\n"
+        "sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle'); sys.path.insert(0, '.')\n"
+        "from helpers import engine_for, audio\n"
+        "m = engine_for('ds320', 0)\n"
+        "r = m.engine.encode_decode(audio(3, 24000, 11, 'tones').cuda(), 32)\n"
+        "np.savez(sys.argv[1], codes=r['codes'].cpu().numpy(), recon=r['recon'].cpu().numpy())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("base", {}), ("noxcd", {"FC_XCD_ORDER": "0"}), ("norow", {"FC_ROW": "0"})):
+        path = os.path.join(root, "gpurun_out", f"_variant_{tag}.npz")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=dict(os.environ, **env), timeout=300)
+        outs[tag] = np.load(path)
+    assert np.array_equal(outs["base"]["codes"], outs["noxcd"]["codes"])
+    assert np.array_equal(outs["base"]["recon"], outs["noxcd"]["recon"])
+    assert np.array_equal(outs["base"]["codes"], outs["norow"]["codes"])
+    assert rms(outs["base"]["recon"], outs["norow"]["recon"]) < WAV_RMS_TOL
+
+
 @pytest.mark.parametrize("cfg_name,seed,B,T", [("tiny", 7, 3, 9), ("tiny", 7, 17, 4), ("ds640", 0, 2, 9), ("ds320", 0, 33, 3)])
 def test_lstm_against_torch_cpu(cfg_name, seed, B, T):
     m = engine_for(cfg_name, seed)
