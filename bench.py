@@ -184,9 +184,9 @@ def main():
                              "avg_us_per_launch": round(ms * 1e3 / p["launches"], 2),
                              "tflops": round(p["flops"] / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
                              "alg_gbs": round(p["bytes"] / (ms * 1e-3) / 1e9, 1) if ms > 0 and p["bytes"] else None})
-            dom = max((k for k in kern if k["kernel"].startswith("conv_mfma")), key=lambda k: k["ms_per_step"])
-            conv_ms = sum(k["ms_per_step"] for k in kern if k["kernel"].startswith("conv_mfma"))
-            conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith("conv_mfma")) / args.steps
+            dom = max((k for k in kern if k["kernel"].startswith("conv_")), key=lambda k: k["ms_per_step"])
+            conv_ms = sum(k["ms_per_step"] for k in kern if k["kernel"].startswith("conv_"))
+            conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith("conv_")) / args.steps
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(dom["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": (pmc_traffic(dom["kernel"]) or {}).get("bytes_per_launch"),

@@ -48,6 +48,8 @@ struct ConvLayer {
     int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
     int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
     bool row = false;       // stride-1 row staging (kernels.hip)
+    float* w_plain = nullptr;   // device [cin][k] when cout == 1 (FMA kernel instead of a 32-row MFMA tile)
+    float bias0 = 0.f;
     float *wt = nullptr, *bias = nullptr, *gamma = nullptr, *beta = nullptr;   // device
     int* koff = nullptr;                                                        // device
 };
@@ -366,6 +368,10 @@ int pack_conv(fc_engine* e, ConvLayer& L) {
     const auto& Bv = e->host[L.prefix + inner + ".bias"].data;
     if (!L.transposed) {
         if (pack_gemm(e, L, W, Bv)) return 1;
+        if (L.cout == 1 && L.stride == 1) {
+            if (upload(e, W, &L.w_plain)) return 1;       // [1][cin][k]
+            L.bias0 = Bv[0];
+        }
     } else {
         // ConvTranspose1d(k = 2r, stride = r) as a 2-tap GEMM over phases: row m = co*r + p,
         // tap 0 multiplies x[i-1] with w[ci][co][p + r], tap 1 multiplies x[i] with w[ci][co][p].
@@ -471,6 +477,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     c.B = cx.B; c.Cin = L.cin; c.Tin = Tin; c.M = L.M;
     c.k = L.gk; c.stride = L.gstride; c.padL = g.padL; c.padR = g.padR;
     c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
+    c.w_plain = L.w_plain; c.bias_host0 = L.bias0;
     Act out;
     out.C = L.cout; out.T = g.Tout;
     if (L.transposed) {
@@ -511,6 +518,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
             char nm[64];
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM == 128 ? 2 : 1,
                      L.BM == 128 ? 2 : 4, mode, nu, row ? "true" : "false");
+            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s>", c.k, c.s1.ptr ? "true" : "false");
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);

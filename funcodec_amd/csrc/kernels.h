@@ -34,9 +34,12 @@ struct ConvLaunch {
     double* partials = nullptr;   // [B][nblk][2] (sum, sumsq) or null
     int BM = 128, BN = 128, CC = 2, nchunk = 1;   // tiling chosen at pack time
     int row = 0;                  // stride-1 row staging (conv_row_ok() at pack time)
+    const float* w_plain = nullptr;   // [Cin][k] device copy for single-output-channel layers (FMA kernel), else null
+    float bias_host0 = 0.f;           // bias[0] of such a layer
 };
 
 int conv_nblk(const ConvLaunch& c);                         // stat partials per utterance
+bool conv_cout1_ok(const ConvLaunch& c);                    // launch_conv() will take the single-output-channel FMA kernel
 size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
 size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab, int row);

@@ -804,7 +804,11 @@ std::vector<int> conv_koff_table(int k, int stride, int CC, int BN, int row) {
 // K of a chunk is zero-padded to a multiple of 4 k-steps (8 k values): the main loop has no tail
 int conv_wbuf_floats(int k, int CC, int BM) { return ((((k * CC + 7) & ~7) * BM + 1023) / 1024) * 1024; }
 
-int conv_nblk(const ConvLaunch& c) { return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM); }
+bool conv_cout1_ok(const ConvLaunch& c);
+int conv_nblk(const ConvLaunch& c) {
+    if (conv_cout1_ok(c)) return ceil_div(c.Tout, 1024);     // single-output-channel kernel: one partial per 1024 samples
+    return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM);
+}
 
 // Row staging (stride 1): rows per round = 4 waves x (64 lanes / (BN/4) lanes per row); the kernel holds at most 8
 // rounds of one source (4 of two) in registers.
@@ -880,7 +884,9 @@ void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row) {
     else *mode = 0;
 }
 
+static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
+    if (conv_cout1_ok(c)) return launch_conv_cout1(c, st);
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
     if (lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
@@ -902,6 +908,177 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     if (c.BM == 32 && c.BN == 256) return launch_conv_t<32, 256, 1, 4>(c, a, grid, lds, st);
     if (c.BM == 32 && c.BN == 128) return launch_conv_t<32, 128, 1, 4>(c, a, grid, lds, st);
     return hipErrorInvalidValue;
+}
+
+// =================================================================================================
+// 1b. Single-output-channel stride-1 conv (the decoder's last layer, 32 -> 1, k = 7): HBM-bound, and a 32-row MFMA tile
+//     would do 32x the necessary matrix work -> plain FMAs.  One workgroup = 1024 output samples of one utterance;
+//     the (GroupNorm apply, residual add, ELU)'d input is staged 8 channels at a time into LDS ([8][1032], 16-byte
+//     loads and stores on interior tiles), every thread owns 4 consecutive outputs and reads its 4+k-1 slab columns
+//     with three 16-byte LDS loads per channel; the k weights of a channel come through scalar loads.  Same epilogue
+//     contract as the MFMA kernel: raw output + fp64 (sum, sum of squares) partial per tile.
+// =================================================================================================
+struct Cout1Args {
+    const float *src0, *aff0, *src1, *aff1;    // [B][Cin][T], per-(b,c) affine or null
+    const float* w;                            // [Cin][k]
+    float bias;
+    float* out;                                // [B][T]
+    double* partials;                          // [B][ntiles][2] or null
+    int Cin, T, k, padL, Leff, elu;
+    float alpha;
+};
+constexpr int C1_TN = 1024, C1_CH = 8, C1_ROW = 1032;
+
+template <int K, bool DUAL>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ __attribute__((aligned(16))) float Xs[C1_CH][C1_ROW];
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int t0 = tile * C1_TN, tbase = t0 - p.padL;
+    const bool interior = tbase >= 0 && tbase + C1_ROW <= p.T;
+    const float* s0 = p.src0 + (size_t)b * p.Cin * p.T;
+    const float* s1 = DUAL ? p.src1 + (size_t)b * p.Cin * p.T : s0;
+    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)b * p.Cin : nullptr;
+    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)b * p.Cin : nullptr;
+    // edge tiles: source index (reflect padding, conv.py:82-99) and validity of this thread's columns, once per tile
+    int esrc[5]; unsigned emask = 0;
+    if (!interior) {
+        const int refl = 2 * (p.Leff - 1);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int col = j < 4 ? 4 * tid + j : 1024 + tid;          // 4 main columns + (threads 0..7) one tail column
+            const int g = tbase + col;
+            int src = g < 0 ? -g : g;
+            src = src >= p.Leff ? refl - src : src;
+            const bool ok = (j < 4 || tid < 8) && g >= -p.padL && src >= 0 && src < p.T;
+            esrc[j] = ok ? src : 0;
+            emask |= (ok ? 1u : 0u) << j;
+        }
+    }
+    auto act = [&](float v, float w, float2 A, float2 A1) __attribute__((always_inline)) {
+        v = fmaf(v, A.x, A.y);
+        if (DUAL) v = v + fmaf(w, A1.x, A1.y);
+        if (p.elu) v = elu_f(v, p.alpha);
+        return v;
+    };
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < p.Cin; c0 += C1_CH) {
+        // ---- stage 8 channels
+#pragma unroll
+        for (int r = 0; r < C1_CH; ++r) {
+            const int c = c0 + r;
+            const bool cok = c < p.Cin;
+            const float* r0 = s0 + (size_t)(cok ? c : 0) * p.T;
+            const float* r1 = s1 + (size_t)(cok ? c : 0) * p.T;
+            const float2 A = a0 ? a0[cok ? c : 0] : make_float2(1.f, 0.f);
+            const float2 A1 = a1 ? a1[cok ? c : 0] : make_float2(1.f, 0.f);
+            f32x4 v;
+            if (interior) {
+                const f32x4 x0 = *(const f32x4u*)(r0 + tbase + 4 * tid);
+                const f32x4 x1 = DUAL ? (f32x4)(*(const f32x4u*)(r1 + tbase + 4 * tid)) : x0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = cok ? act(x0[j], x1[j], A, A1) : 0.f;
+                if (tid < 2) {                                         // tail columns 1024..1031
+                    const f32x4 y0 = *(const f32x4u*)(r0 + tbase + 1024 + 4 * tid);
+                    const f32x4 y1 = DUAL ? (f32x4)(*(const f32x4u*)(r1 + tbase + 1024 + 4 * tid)) : y0;
+                    f32x4 u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = cok ? act(y0[j], y1[j], A, A1) : 0.f;
+                    *(f32x4*)&Xs[r][1024 + 4 * tid] = u;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = r0[esrc[j]], x1 = DUAL ? r1[esrc[j]] : 0.f;
+                    v[j] = (cok && ((emask >> j) & 1u)) ? act(x0, x1, A, A1) : 0.f;
+                }
+                if (tid < 8) {
+                    const float x0 = r0[esrc[4]], x1 = DUAL ? r1[esrc[4]] : 0.f;
+                    Xs[r][1024 + tid] = (cok && ((emask >> 4) & 1u)) ? act(x0, x1, A, A1) : 0.f;
+                }
+            }
+            *(f32x4*)&Xs[r][4 * tid] = v;
+        }
+        __syncthreads();
+        // ---- 4 outputs per thread: out[n] += sum_c sum_kk w[c][kk] * x[c][n + kk]
+#pragma unroll
+        for (int r = 0; r < C1_CH; ++r) {
+            const int c = c0 + r;
+            if (c >= p.Cin) break;                                     // uniform
+            const f32x4 q0 = *(const f32x4*)&Xs[r][4 * tid];
+            const f32x4 q1 = *(const f32x4*)&Xs[r][4 * tid + 4];
+            const f32x4 q2 = *(const f32x4*)&Xs[r][4 * tid + 8];
+            const float x[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
+            const float* wr = p.w + (size_t)c * K;                     // uniform address: scalar loads
+#pragma unroll
+            for (int kk = 0; kk < K; ++kk) {
+                const float wv = wr[kk];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, x[j + kk], acc[j]);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: bias, store, statistics of the valid outputs
+    float s1v = 0.f, s2v = 0.f;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[j] = acc[j] + p.bias;
+        const int n = t0 + 4 * tid + j;
+        if (n < p.T) { s1v += o[j]; s2v = fmaf(o[j], o[j], s2v); }
+    }
+    float* orow = p.out + (size_t)b * p.T + t0 + 4 * tid;
+    if (t0 + 4 * tid + 3 < p.T) *(f32x4u*)orow = (f32x4){o[0], o[1], o[2], o[3]};
+    else
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (t0 + 4 * tid + j < p.T) orow[j] = o[j];
+    if (p.partials) {
+        double d1 = (double)s1v, d2 = (double)s2v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            d1 += __shfl_xor(d1, off, 64);
+            d2 += __shfl_xor(d2, off, 64);
+        }
+        if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t slot = ((size_t)b * gridDim.x + tile) * 2;
+            p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+    }
+}
+
+bool conv_cout1_ok(const ConvLaunch& c) {
+    return c.w_plain && c.M == 1 && c.stride == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
+           (c.k == 7 || c.k == 3 || c.k == 5) && c.padL + c.padR == c.k - 1;
+}
+
+static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
+    Cout1Args a;
+    a.src0 = c.s0.ptr; a.aff0 = c.s0.aff; a.src1 = c.s1.ptr; a.aff1 = c.s1.aff;
+    a.w = c.w_plain; a.bias = c.bias_host0; a.out = c.out; a.partials = c.partials;
+    a.Cin = c.Cin; a.T = c.Tin; a.k = c.k; a.padL = c.padL;
+    const int maxpad = c.padL > c.padR ? c.padL : c.padR;
+    a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
+    a.elu = c.elu; a.alpha = c.alpha;
+    dim3 grid(ceil_div(c.Tout, C1_TN), c.B), block(256);
+#define FC_C1(KK)                                                                                       \
+    case KK:                                                                                            \
+        if (c.s1.ptr) hipLaunchKernelGGL((conv_cout1_kernel<KK, true>), grid, block, 0, st, a);         \
+        else hipLaunchKernelGGL((conv_cout1_kernel<KK, false>), grid, block, 0, st, a);                 \
+        break;
+    switch (c.k) {
+        FC_C1(3)
+        FC_C1(5)
+        FC_C1(7)
+        default: return hipErrorInvalidValue;
+    }
+#undef FC_C1
+    return hipGetLastError();
 }
 
 // =================================================================================================
