@@ -1,11 +1,11 @@
 """Profiling aid (not a test): time one plan layer at benchmark shape under FC_ABLATE variants
 (HIP-event timing of the raw C-ABI call, 20 launches).
-usage: FC_ABLATE=<mask> python tests/ablate_layer.py <prefix> <T> [elu]"""
+usage: FC_ABLATE=<mask> python tools/ablate_layer.py <prefix> <T> [elu]"""
 import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from helpers import engine_for
 

@@ -1,10 +1,10 @@
 """Profiling aid (not a test): time the bottleneck LSTM at benchmark shape under FC_ABLATE_LSTM variants.
-usage: FC_ABLATE_LSTM=<mask> python tests/ablate_lstm.py [encoder|decoder] [T] [B]"""
+usage: FC_ABLATE_LSTM=<mask> python tools/ablate_lstm.py [encoder|decoder] [T] [B]"""
 import ctypes as C
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from helpers import engine_for
 

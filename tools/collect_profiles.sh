@@ -3,7 +3,7 @@
 #   bench.json               the official bench line (with cpu_baseline)
 #   bench_under_rocprof.json the same command under rocprofv3 --kernel-trace --stats
 #   kernel_stats.csv         rocprofv3 per-kernel statistics of that run
-#   last_step_per_launch.txt one line per launch of the last benchmark step (tests/trace_summary.py)
+#   last_step_per_launch.txt one line per launch of the last benchmark step (tools/trace_summary.py)
 #   pmc_fetch / pmc_write    FETCH_SIZE and WRITE_SIZE in SEPARATE passes (kernel-trace only), as the guide prescribes
 # Outputs go to gpurun_out/prof/; tools/profile_post.py turns them into profiles/rNN_*.
 set -u
@@ -15,7 +15,7 @@ python $R/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/rp -o out --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rp.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/pmc_write.err
-python $R/tests/trace_summary.py $(ls $OUT/rp/*kernel_trace.csv | head -1) > $OUT/last_step_per_launch.txt 2>&1
+python $R/tools/trace_summary.py $(ls $OUT/rp/*kernel_trace.csv | head -1) > $OUT/last_step_per_launch.txt 2>&1
 python $R/tools/profile_post.py $OUT
 ls -la $OUT | head -30
 # keep the merge-back small: raw traces are large

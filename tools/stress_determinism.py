@@ -1,9 +1,9 @@
 """Stress aid (not a test): repeat the same calls many times and report any run whose output differs from the first
-(a data race shows up as a non-deterministic result).  usage: python tests/stress_determinism.py [cfg] [B] [T] [iters]"""
+(a data race shows up as a non-deterministic result).  usage: python tools/stress_determinism.py [cfg] [B] [T] [iters]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from helpers import engine_for, audio
 
