@@ -53,7 +53,6 @@ struct ConvArgs {
     int CC, nchunk, Kc;
     int Wbuf;               // floats per packed weight chunk (multiple of 1024)
     int slabW, PL, rowStride, xs_floats;
-    int xcd_order;          // remap workgroup ids so that the M tiles of one slab share an XCD (FC_XCD_ORDER, default on)
     int row;                // stride-1 row staging (16-byte loads / LDS stores, one channel row per 32 or 64 lanes)
     int xsf;                // floats per slab buffer
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
@@ -155,22 +154,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     const int tid = threadIdx.x;
     const int role = __builtin_amdgcn_readfirstlane(tid >> 8);    // 0 matrix, 1 staging
     const int rtid = tid & 255, lane = tid & 63, wid = (tid >> 6) & 3;
-    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round robin by linear id, and each XCD has its own L2.
-    // All M tiles of one (utterance, N range) read the SAME input slab, so they are placed on the same XCD and next to
-    // each other in dispatch order: the slab crosses the fabric once per XCD instead of once per M tile (PMC: the
-    // dominant instantiation fetched 2.5x its algorithmic bytes with the plain (x, y, z) order).
-    int bx = blockIdx.x, mt = blockIdx.y, b = blockIdx.z;
-    {
-        const unsigned G = gridDim.x, MT = gridDim.y, groups = G * gridDim.z;
-        if (p.xcd_order && (groups & 7u) == 0u) {
-            const unsigned lin = bx + G * (mt + MT * b);
-            const unsigned xcd = lin & 7u, slot = lin >> 3;
-            const unsigned grp = (slot / MT) * 8u + xcd;      // < groups
-            mt = (int)(slot % MT);
-            bx = (int)(grp % G);
-            b = (int)(grp / G);
-        }
-    }
+    const int bx = blockIdx.x, mt = blockIdx.y, b = blockIdx.z;
     const int m0 = mt * BM;
     const int ntiles = (p.Tout + BN - 1) / BN;
     const int t_begin = (int)(((long long)ntiles * bx) / gridDim.x);
@@ -780,8 +764,6 @@ static ConvArgs make_args(const ConvLaunch& c) {
     static const int skew = getenv("FC_SKEW") ? atoi(getenv("FC_SKEW")) : 0;
     static const int skew_div = getenv("FC_SKEW_DIV") ? atoi(getenv("FC_SKEW_DIV")) : 256;
     a.skew = skew; a.skew_div = skew_div;
-    static const int xcd_order = getenv("FC_XCD_ORDER") ? atoi(getenv("FC_XCD_ORDER")) : 1;
-    a.xcd_order = xcd_order;
     a.ablate = ablate;
     return a;
 }

@@ -182,8 +182,8 @@ def test_row_staging_interior_and_straddling_tiles(T):
         assert got.shape == ref.shape and (got - ref).abs().max().item() < LAYER_ABS_TOL, (p, T)
 
 
-def test_tile_order_and_staging_scheme_do_not_change_results():
-    """FC_XCD_ORDER only permutes which workgroup computes which tile: results must be bit-identical.  FC_ROW=0 (element
+def test_staging_scheme_and_workgroup_count_do_not_change_results():
+    """FC_TARGET_WGS only changes how many N tiles a workgroup walks: results must be bit-identical.  FC_ROW=0 (element
     staging everywhere, other K chunking) changes the summation order across chunks: same codes, waveform within tolerance."""
     import os
     import subprocess
@@ -197,13 +197,13 @@ def test_tile_order_and_staging_scheme_do_not_change_results():
         "np.savez(sys.argv[1], codes=r['codes'].cpu().numpy(), recon=r['recon'].cpu().numpy())\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for tag, env in (("base", {}), ("noxcd", {"FC_XCD_ORDER": "0"}), ("norow", {"FC_ROW": "0"})):
+    for tag, env in (("base", {}), ("fewwg", {"FC_TARGET_WGS": "96"}), ("norow", {"FC_ROW": "0"})):
         path = os.path.join(root, "gpurun_out", f"_variant_{tag}.npz")
         os.makedirs(os.path.dirname(path), exist_ok=True)
         subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=dict(os.environ, **env), timeout=300)
         outs[tag] = np.load(path)
-    assert np.array_equal(outs["base"]["codes"], outs["noxcd"]["codes"])
-    assert np.array_equal(outs["base"]["recon"], outs["noxcd"]["recon"])
+    assert np.array_equal(outs["base"]["codes"], outs["fewwg"]["codes"])
+    assert np.array_equal(outs["base"]["recon"], outs["fewwg"]["recon"])
     assert np.array_equal(outs["base"]["codes"], outs["norow"]["codes"])
     assert rms(outs["base"]["recon"], outs["norow"]["recon"]) < WAV_RMS_TOL
 
