@@ -162,8 +162,8 @@ def inference_modelscope(
             if isinstance(raw_inputs, str):
                 uttid = os.path.basename(raw_inputs).rsplit(".")[0]
                 raw_inputs, sr = fio.read_wav(raw_inputs)
-                if sr != sampling_rate:
-                    raise NotImplementedError("resampling is not built yet (SURVEY.md §8f)")
+                if sr != sampling_rate:                                        # librosa.load(sr=...) in the reference (:240)
+                    raw_inputs = fio.resample(torch.from_numpy(raw_inputs), sr, sampling_rate).numpy()
             if isinstance(raw_inputs, torch.Tensor):
                 raw_inputs = raw_inputs.numpy()
             loader = [([uttid], dict(speech=torch.from_numpy(np.asarray(raw_inputs))[None, :],
@@ -173,8 +173,8 @@ def inference_modelscope(
         output_path = output_dir_v2 if output_dir_v2 is not None else output_dir
         if output_path is not None:
             os.makedirs(output_path, exist_ok=True)
-        if kwargs.get("file_sampling_rate") not in (None, sampling_rate):
-            raise NotImplementedError("file_sampling_rate != sampling_rate: resampling is not built yet (SURVEY.md §8f)")
+        file_sr = kwargs.get("file_sampling_rate")
+        should_resample = file_sr not in (None, sampling_rate)               # reference :270-273
         indices_writer, sub_quants_writer = None, None
         ark_indices = kwargs.get("indices_save_type") == "ark"
         if kwargs.get("need_indices"):
@@ -189,10 +189,14 @@ def inference_modelscope(
         run_mod = kwargs.get("run_mod", "inference")
         hop = my_model.model.quantizer.encoder_hop_length
         for keys, batch in loader:
+            if should_resample:                                                 # reference :318-322 (lengths stay in file samples)
+                batch["speech"] = fio.resample(batch["speech"], file_sr, sampling_rate)
             speech_length = batch.pop("speech_lengths")
             bw = param_dict["bit_width"] if param_dict is not None and "bit_width" in param_dict else bit_width
             token_id, token_emb, recon_speech, sub_quants = my_model(**batch, need_recon=True, bit_width=bw,
                                                                      use_scale=use_scale, run_mod=run_mod)
+            if should_resample and recon_speech is not None:                    # reference :352-356
+                recon_speech = fio.resample(recon_speech, sampling_rate, file_sr)
             for i, key in enumerate(keys):
                 if run_mod in ["decode", "decode_emb"]:
                     codec_len = int(speech_length[i])
@@ -206,7 +210,7 @@ def inference_modelscope(
                     continue
                 if recon_wav is not None:
                     save_audio(recon_wav, os.path.join(output_path, key + ".wav" if not key.endswith(".wav") else key),
-                               rescale=True, sample_rate=sampling_rate)
+                               rescale=True, sample_rate=file_sr if should_resample else sampling_rate)
                 if token_id is not None and indices_writer is not None:
                     if ark_indices:                                            # [T, n_q] float matrix (reference :292-294)
                         mats = [x[:, i, :codec_len].cpu().float().numpy().T for x in token_id]

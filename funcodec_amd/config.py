@@ -44,6 +44,18 @@ class ArchSpec:
     encoder_hop_length: int = 320
     quantizer_sampling_rate: int = 16000
     use_ddp: bool = True
+    # Encodec framing (codec_basic.py:288-298): None = one frame; else frames of segment_dur seconds, hop (1-overlap)*length
+    segment_dur: Optional[float] = None
+    overlap_ratio: float = 0.01
+
+    @property
+    def segment_length(self) -> Optional[int]:
+        return None if self.segment_dur is None else int(self.segment_dur * self.sample_rate)
+
+    @property
+    def segment_stride(self) -> Optional[int]:
+        sl = self.segment_length
+        return None if sl is None else max(1, int((1 - self.overlap_ratio) * sl))
 
     @property
     def hop_length(self) -> int:
@@ -135,8 +147,6 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     input_size = cfg.get("input_size", 1)
     if input_size != 1 or dec.get("channels", 1) != 1:
         raise _unsupported("input_size/channels", (input_size, dec.get("channels", 1)), "mono only")
-    if m.get("segment_dur", None) is not None:
-        raise _unsupported("model_conf.segment_dur", m["segment_dur"], "segmented overlap-add mode is §8f")
     if m.get("codec_domain", "time") not in ("time", None):
         raise _unsupported("model_conf.codec_domain", m["codec_domain"])
     if m.get("bypass_quantizer", False):
@@ -177,7 +187,11 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         encoder_hop_length=int(q.get("encoder_hop_length", 320)),
         quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
         use_ddp=bool(q.get("use_ddp", True)),
+        segment_dur=None if m.get("segment_dur", None) is None else float(m["segment_dur"]),
+        overlap_ratio=0.01 if m.get("overlap_ratio", None) is None else float(m["overlap_ratio"]),
     )
+    if arch.segment_dur is not None and not (arch.segment_dur > 0 and 0 <= arch.overlap_ratio < 1):
+        raise _unsupported("model_conf.segment_dur/overlap_ratio", (arch.segment_dur, arch.overlap_ratio))
     return arch
 
 
@@ -187,6 +201,11 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
 # class-default ratios of SEANetEncoder (seanet_encoder.py:92) for ds320.
 # ----------------------------------------------------------------------------------------------
 def recipe_config(name: str) -> Dict[str, Any]:
+    if name == "ds320seg":   # ds320 run in the segmented overlap-add mode (0.5 s frames, 10 % overlap)
+        cfg = recipe_config("ds320")
+        cfg["model_conf"]["segment_dur"] = 0.5
+        cfg["model_conf"]["overlap_ratio"] = 0.1
+        return cfg
     if name == "ds640":
         ratios, hop = [8, 5, 4, 2, 2], 640
     elif name == "ds320":

@@ -59,6 +59,43 @@ def save_audio(wav: torch.Tensor, path: str, sample_rate: int, rescale: bool = F
 
 
 # ------------------------------------------------------------------------------------------------
+# sample-rate conversion (reference: torchaudio.functional.resample, codec_inference.py:318-322,352-356)
+# ------------------------------------------------------------------------------------------------
+def resample(waveform: torch.Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6,
+             rolloff: float = 0.99) -> torch.Tensor:
+    """Band-limited sinc interpolation with a Hann window: the algorithm torchaudio publishes as
+    ``torchaudio.functional.resample(..., resampling_method="sinc_interp_hann")`` with its default width / roll-off
+    (torchaudio is not installed here, so this is a restatement of that algorithm, not a golden-pinned copy:
+    polyphase kernel bank [new/gcd, 1, 2*width + orig/gcd], conv1d with stride orig/gcd, output length
+    ceil(new * T / orig)).  Runs wherever `waveform` lives (torch ops: plumbing, not the hot path)."""
+    import math
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq <= 0 or new_freq <= 0:
+        raise ValueError("sample rates must be positive")
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(orig_freq, new_freq)
+    of, nf = orig_freq // g, new_freq // g
+    base = min(of, nf) * rolloff
+    width = math.ceil(lowpass_filter_width * of / base)
+    dt = torch.float64
+    idx = torch.arange(-width, width + of, dtype=dt)[None, None] / of
+    t = torch.arange(0, -nf, -1, dtype=dt)[:, None, None] / nf + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kern = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / of)
+    kern = kern.to(dtype=waveform.dtype, device=waveform.device)
+    shape = waveform.shape
+    x = waveform.reshape(-1, shape[-1])
+    n, length = x.shape
+    x = torch.nn.functional.pad(x, (width, width + of))
+    y = torch.nn.functional.conv1d(x[:, None], kern, stride=of).transpose(1, 2).reshape(n, -1)
+    target = int(math.ceil(nf * length / of))
+    return y[..., :target].reshape(shape[:-1] + (target,))
+
+
+# ------------------------------------------------------------------------------------------------
 # Kaldi ark / scp (binary float matrices only: what the reference writes with kaldiio "ark,scp,f:")
 # ------------------------------------------------------------------------------------------------
 class KaldiMatrixWriter:

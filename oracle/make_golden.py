@@ -76,12 +76,16 @@ def build_reference(cfg_name, seed, decay, tmp):
 
 
 def main():
+    # `python oracle/make_golden.py NAME...` regenerates only the named cases and merges them into MANIFEST.json
+    only = set(sys.argv[1:]) or None
     torch.manual_seed(0)
     os.makedirs(GOLD, exist_ok=True)
     manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "cases": {}}
     cache = {}
     with tempfile.TemporaryDirectory() as tmp:
         for name, cfg_name, wseed, decay, akind, aseed, B, T, bw in CASES:
+            if only is not None and name not in only:
+                continue
             key = (cfg_name, wseed, decay)
             if key not in cache:
                 cache[key] = build_reference(cfg_name, wseed, decay, tmp)
@@ -123,6 +127,34 @@ def main():
                                            audio_kind=akind, audio_seed=aseed, batch=B, samples=T,
                                            bit_width=bw, n_q=int(idx[0].shape[0]), frames=int(idx[0].shape[2]))
             print(f"[golden] {name}: idx{tuple(idx[0].shape)} recon{tuple(recon.shape)} oracle==reference OK")
+
+        # ---- segmented overlap-add mode (model_conf.segment_dur, codec_basic.py:334-359,382-396): 0.5 s frames, 10 % overlap
+        if only is None or "ds320seg_b2_t20000" in only:
+            name, cfg_name, wseed, akind, aseed, B, T = "ds320seg_b2_t20000", "ds320seg", 0, "tones", 41, 2, 20000
+            s2t, cfg, sd = build_reference(cfg_name, wseed, 1.0, tmp)
+            x = torch.from_numpy(synthetic_audio(B, T, aseed, akind))
+            idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=None, use_scale=True, run_mod="inference")
+            assert len(idx) == 3 and recon.shape[-1] == T
+            orc = Oracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
+            o = orc.inference(x, bit_width=None, use_scale=True)
+            for f in range(len(idx)):
+                assert torch.equal(o["code_indices"][f], idx[f]), f"{name}: frame {f} indices"
+                assert torch.equal(o["code_embeddings"][f][0], embs[f][0]) and torch.equal(o["code_embeddings"][f][1], embs[f][1])
+                assert torch.equal(o["sub_quants"][f], subs[f])
+            assert torch.equal(o["recon_speech"], recon), f"{name}: oracle recon != reference"
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), recon=recon.numpy(),
+                                **{f"indices_{f}": idx[f].numpy().astype(np.int16) for f in range(len(idx))},
+                                **{f"scale_{f}": embs[f][1].numpy() for f in range(len(idx))})
+            manifest["cases"][name] = dict(kind="segmented", config=cfg_name, weight_seed=wseed, codebook_decay=1.0,
+                                           audio_kind=akind, audio_seed=aseed, batch=B, samples=T, bit_width=None,
+                                           n_q=int(idx[0].shape[0]), frames=[int(i.shape[2]) for i in idx])
+            print(f"[golden] {name}: {len(idx)} frames {[tuple(i.shape) for i in idx]} oracle==reference OK")
+        if only is not None:
+            old = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
+            old["cases"].update(manifest["cases"])
+            with open(os.path.join(GOLD, "MANIFEST.json"), "wt") as f:
+                json.dump(old, f, indent=1, sort_keys=True)
+            return
 
         # ---- RVQ-only hard case: depth-decaying codebooks (exact-tie provoking) ----
         from funcodec.modules.quantization.ddp_core_vq import DistributedResidualVectorQuantization

@@ -72,6 +72,7 @@ class Oracle:
     """Functional model built from a config.yaml-shaped dict and a reference-format state_dict."""
 
     def __init__(self, config: Dict, state: Dict[str, torch.Tensor]):
+        self.cfg = config
         enc, dec = dict(config.get("encoder_conf", {})), dict(config.get("decoder_conf", {}))
         q, m = dict(config.get("quantizer_conf", {})), dict(config.get("model_conf", {}))
         assert enc.get("norm") == "time_group_norm" and not enc.get("causal", False)
@@ -224,9 +225,56 @@ class Oracle:
             scale = scale.view(-1, 1)
         return self.encoder(x), scale
 
+    @staticmethod
+    def linear_overlap_add(frames, stride):
+        """_linear_overlap_add codec_basic.py:77-116."""
+        total = stride * (len(frames) - 1) + frames[-1].shape[-1]
+        flen = frames[0].shape[-1]
+        t = torch.linspace(0, 1, flen + 2, dtype=frames[0].dtype)[1:-1]
+        weight = 0.5 - (t - 0.5).abs()
+        sum_w = torch.zeros(total, dtype=frames[0].dtype)
+        out = torch.zeros(*frames[0].shape[:-1], total, dtype=frames[0].dtype)
+        off = 0
+        for f in frames:
+            n = f.shape[-1]
+            out[..., off:off + n] += weight[:n] * f
+            sum_w[off:off + n] += weight[:n]
+            off += stride
+        return out / sum_w
+
+    @torch.no_grad()
+    def inference_segmented(self, speech: torch.Tensor, bit_width=None, use_scale=True, need_recon=True):
+        """Encodec.inference with model_conf.segment_dur set: _encode frames (codec_basic.py:334-359), per-frame RVQ, per-frame
+        _decode_frame, _linear_overlap_add (:382-396), trim to the input length (:711)."""
+        if speech.dim() == 2:
+            speech = speech.unsqueeze(1)
+        m = self.cfg.get("model_conf", {})
+        sr = int(m.get("target_sample_hz", self.cfg.get("sampling_rate", 16000)))
+        seg = int(m["segment_dur"] * sr)
+        ov = 0.01 if m.get("overlap_ratio", None) is None else m["overlap_ratio"]
+        stride = max(1, int((1 - ov) * seg))
+        T = speech.shape[-1]
+        idxs, embs, subs_all, recons, encs, scales = [], [], [], [], [], []
+        for off in range(0, T, stride):
+            frame = speech[:, :, off:off + seg]
+            emb, scale = self.encode_frame(frame)
+            quant, idx, subs = self.rvq_forward(emb, self.n_q_for(bit_width))
+            idxs.append(idx); embs.append((quant, scale if use_scale else None)); subs_all.append(subs)
+            encs.append(emb); scales.append(scale)
+            if need_recon:
+                r = self.decoder(quant)
+                if use_scale and scale is not None:
+                    r = r * scale.view(-1, 1, 1)
+                recons.append(r)
+        recon = self.linear_overlap_add(recons, stride)[:, :, :T] if need_recon else None
+        return dict(code_indices=idxs, code_embeddings=embs, recon_speech=recon, sub_quants=subs_all,
+                    encoder_out=encs, scale=scales)
+
     @torch.no_grad()
     def inference(self, speech: torch.Tensor, bit_width=None, use_scale=True, need_recon=True):
-        """Encodec.inference codec_basic.py:670-718 (one frame; segment_dur null)."""
+        """Encodec.inference codec_basic.py:670-718 (one frame when segment_dur is null)."""
+        if self.cfg.get("model_conf", {}).get("segment_dur", None) is not None:
+            return self.inference_segmented(speech, bit_width, use_scale, need_recon)
         if speech.dim() == 2:
             speech = speech.unsqueeze(1)
         emb, scale = self.encode_frame(speech)

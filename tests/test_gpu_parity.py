@@ -12,7 +12,8 @@ from helpers import (audio, engine_for, golden, index_report, manifest, oracle_f
 
 pytestmark = pytest.mark.gpu
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") != "rvq"]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "segmented")]
+SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 
 # tolerances (north_star): integer codec indices bit-exact; waveforms within 1e-4 RMS
 WAV_RMS_TOL = 1e-4
@@ -50,6 +51,30 @@ def test_e2e_against_reference_golden(name):
     assert rms(emb, g["quantized"]) == 0.0
     w3 = m.engine.decode_emb(torch.from_numpy(g["quantized"]))
     assert rms(w3, g["recon_from_codes"]) < WAV_RMS_TOL
+
+
+@pytest.mark.parametrize("name", SEG)
+def test_segmented_mode_against_reference_golden(name):
+    """model_conf.segment_dur / overlap_ratio: frames are extra batch rows for the engine, the
+    triangle overlap-add runs in the reference's operation order; golden = the real reference in segmented mode."""
+    from funcodec_amd.bin.codec_inference import Speech2Token   # noqa: F401  (drop-in surface is exercised elsewhere)
+    c = MAN["cases"][name]
+    m = engine_for(c["config"], c["weight_seed"], c["codebook_decay"])
+    assert m.arch.segment_length == 8000 and m.arch.segment_stride == 7200
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    g = golden(name)
+    r = m.inference(wav.unsqueeze(1), bit_width=c["bit_width"], use_scale=True)
+    assert len(r["code_indices"]) == len(c["frames"]) and len(r["sub_quants"]) == len(c["frames"])
+    for f, idx in enumerate(r["code_indices"]):
+        assert idx.shape == (c["n_q"], c["batch"], c["frames"][f])
+        rep = index_report(idx, g[f"indices_{f}"].astype(np.int64))
+        assert rep["mismatched_indices"] == 0, (f, rep)
+        assert np.allclose(r["code_embeddings"][f][1].cpu().numpy(), g[f"scale_{f}"], rtol=1e-5)
+    assert r["recon_speech"].shape == (c["batch"], 1, c["samples"])
+    assert rms(r["recon_speech"], g["recon"]) < WAV_RMS_TOL
+    # frames of one call are independent utterances: the first frame alone gives the same codes
+    one = m.engine.encode(wav[:, :8000], c["n_q"])
+    assert torch.equal(one["codes"], r["code_indices"][0])
 
 
 @pytest.mark.parametrize("name", ["rvq_flat", "rvq_decay08"])
@@ -468,6 +493,26 @@ def test_cli_encoding_decoding_pipeline(tmp_path):
             r = o["recon_speech"][i, 0, :n].numpy()
             r = r * min(0.99 / np.abs(r).max(), 1.0)                   # save_audio(rescale=True)
             assert np.abs(y - r).max() < 2.0 / 32768
+    # file_sampling_rate != model rate (reference :270-273,318-322,352-356): 8 kHz files are resampled in, the
+    # reconstruction is resampled back and written at the file rate; lengths stay in file samples
+    scp8 = tmp_path / "wav8k.scp"
+    p8 = str(tmp_path / "v0.wav")
+    x8 = fio.resample(wavs[0:1, :6400], 16000, 8000)
+    fio.save_audio(x8, p8, 8000, rescale=False)
+    with open(scp8, "wt") as f:
+        f.write(f"v0 {p8}\n")
+    out8 = str(tmp_path / "out8.1")
+    main(["--ngpu", "1", "--gpuid_list", "0", "--output_dir", out8, "--batch_size", "1", "--sampling_rate", "16000",
+          "--file_sampling_rate", "8000", "--config_file", cfg_path, "--model_file", pth_path, "--bit_width", "8000",
+          "--use_scale", "false", "--need_indices", "true", "--run_mod", "inference",
+          "--data_path_and_name_and_type", f"{scp8},speech,sound"])
+    y8, sr8 = fio.read_wav(os.path.join(out8, "v0.wav"))
+    assert sr8 == 8000 and y8.shape[0] == x8.shape[1]
+    x8q, _ = fio.read_wav(p8)
+    o8 = orc.inference(fio.resample(torch.from_numpy(x8q)[None], 8000, 16000), bit_width=8000, use_scale=False)
+    r8 = fio.resample(o8["recon_speech"], 16000, 8000)[0, 0, :y8.shape[0]].numpy()
+    r8 = r8 * min(0.99 / np.abs(r8).max(), 1.0)
+    assert np.abs(y8 - r8).max() < 3.0 / 32768
     # decode stage: codecs.txt -> wavs (run_mod=decode, data type codec_json), ark index dump on the way
     out2 = str(tmp_path / "dec.1")
     main(["--ngpu", "1", "--gpuid_list", "0", "--output_dir", out2, "--batch_size", "1", "--sampling_rate", "16000",

@@ -56,13 +56,16 @@ def test_arch_from_recipe_configs():
     b = arch_from_config(recipe_config("ds320"))
     assert b.hop_length == 320 and b.num_quantizers_for_bandwidth(8000) == 16
     assert a.frames_for(160000) == 250 and a.frames_for(160001) == 251 and a.frames_for(1) == 1
+    assert a.segment_length is None and a.segment_stride is None
+    s = arch_from_config(recipe_config("ds320seg"))       # codec_basic.py:288-298
+    assert s.segment_length == 8000 and s.segment_stride == 7200
 
 
 @pytest.mark.parametrize("mut", [
     lambda c: c["encoder_conf"].update(norm="weight_norm"),
     lambda c: c["encoder_conf"].update(causal=True),
     lambda c: c.update(model="freqcodec"),
-    lambda c: c["model_conf"].update(segment_dur=1.0),
+    lambda c: c["model_conf"].update(segment_dur=1.0, overlap_ratio=1.5),
     lambda c: c["quantizer_conf"].update(codec_dim=64),
     lambda c: c["decoder_conf"].update(ratios=[8, 5, 4]),
 ])

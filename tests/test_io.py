@@ -77,3 +77,28 @@ def test_cli_parser_has_the_reference_flags():
     ns = get_parser().parse_args(["--data_path_and_name_and_type", "a.scp,speech,sound", "--need_indices", "true"])
     assert ns.data_path_and_name_and_type == [("a.scp", "speech", "sound")] and ns.need_indices is True
     assert ns.bit_width == 16000 and ns.sampling_rate == 24000 and ns.run_mod == "inference"
+
+
+def test_resample_matches_the_published_sinc_hann_algorithm_properties():
+    """fio.resample restates torchaudio.functional.resample (sinc_interp_hann, width 6, rolloff 0.99); torchaudio is not
+    installed here, so the checks are the algorithm's properties: identity, output length ceil(new*T/orig), a band-limited
+    tone survives down- and up-sampling, agreement with scipy's polyphase resampler, batch dimensions kept."""
+    import math
+    from scipy.signal import resample_poly
+    x = torch.randn(3, 1001)
+    assert fio.resample(x, 16000, 16000) is x
+    for o, n in ((24000, 16000), (16000, 24000), (44100, 16000), (8000, 16000)):
+        y = fio.resample(x, o, n)
+        assert y.shape == (3, math.ceil(n * 1001 / o)) and torch.isfinite(y).all()
+    assert fio.resample(torch.randn(2, 1, 500), 16000, 8000).shape == (2, 1, 250)
+    t = torch.arange(24000, dtype=torch.float64) / 24000
+    tone = torch.sin(2 * math.pi * 440 * t).float()
+    down = fio.resample(tone, 24000, 16000)
+    ideal = torch.sin(2 * math.pi * 440 * torch.arange(16000, dtype=torch.float64) / 16000).float()
+    assert (down[100:-100] - ideal[100:-100]).abs().max() < 1e-3
+    assert np.abs(down.numpy()[200:-200] - resample_poly(tone.double().numpy(), 2, 3)[200:-200]).max() < 2e-3
+    up = fio.resample(down, 16000, 24000)
+    assert (up[300:-300] - tone[300:up.numel() - 300]).abs().max() < 2e-3
+    # a tone above the new Nyquist is removed (anti-aliasing), not folded back
+    hi = torch.sin(2 * math.pi * 11000 * t).float()
+    assert fio.resample(hi, 24000, 16000)[200:-200].abs().max() < 2e-2

@@ -7,7 +7,8 @@ import torch
 from helpers import audio, golden, index_report, manifest, oracle_for, rms
 
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") != "rvq"]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "segmented")]
+SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 SAME_BUILD = torch.__version__ == MAN["torch"]
 
 
@@ -32,6 +33,25 @@ def test_torch_oracle_matches_reference_golden(name):
     tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
     wav2, _ = orc.decode_codes(tok)
     assert rms(wav2, g["recon_from_codes"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", SEG)
+def test_torch_oracle_segmented_mode_matches_reference_golden(name):
+    """model_conf.segment_dur set: per-frame encode / RVQ / decode and the triangle overlap-add (codec_basic.py:334-396)."""
+    c = MAN["cases"][name]
+    orc = oracle_for(c["config"], c["weight_seed"], c["codebook_decay"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    g = golden(name)
+    o = orc.inference(wav, bit_width=c["bit_width"], use_scale=True)
+    assert [int(i.shape[2]) for i in o["code_indices"]] == c["frames"]
+    assert rms(o["recon_speech"], g["recon"]) < 1e-4
+    exact = SAME_BUILD and torch.get_num_threads() == MAN["threads"]
+    for f, idx in enumerate(o["code_indices"]):
+        rep = index_report(idx, g[f"indices_{f}"].astype(np.int64))
+        assert rep["mismatched_indices"] == 0 if exact else rep["frames_bad"] <= max(1, rep["frames"] // 50)
+        assert np.allclose(o["code_embeddings"][f][1].numpy(), g[f"scale_{f}"], rtol=1e-6)
+    if exact:
+        assert np.array_equal(o["recon_speech"].numpy(), g["recon"])
 
 
 @pytest.mark.parametrize("name", ["rvq_flat", "rvq_decay08"])
