@@ -118,6 +118,7 @@ def main():
     # global batch = 16 utterances per GPU; each rank takes its contiguous slice
     total_utts = UTTS_PER_GPU * world
     lo, hi = shard_range(total_utts, rank, world)
+    shard_sizes = [shard_range(total_utts, r, world)[1] - shard_range(total_utts, r, world)[0] for r in range(world)]
     wav_all = synthetic_audio(total_utts, SAMPLES, 1234) if total_utts <= 32 else None
     if wav_all is None:   # avoid generating 1 GB of noise per rank at large N: per-rank seeds
         wav = torch.from_numpy(synthetic_audio(hi - lo, SAMPLES, 1234 + rank)).cuda()
@@ -127,7 +128,7 @@ def main():
 
     def step():
         r = eng.encode_decode(wav, n_q, use_scale=True)
-        codes = gather_codes(r["codes"], dist) if world > 1 else r["codes"]
+        codes = gather_codes(r["codes"], dist, shard_sizes=shard_sizes) if world > 1 else r["codes"]
         return r, codes
 
     def fence():

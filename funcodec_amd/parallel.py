@@ -18,19 +18,25 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
-def gather_codes(codes: torch.Tensor, dist=None) -> torch.Tensor:
+def gather_codes(codes: torch.Tensor, dist=None, shard_sizes=None) -> torch.Tensor:
     """All-gather code indices [n_q, B_local, Tf] -> [n_q, B_global, Tf] in rank order.
 
     Ranks may hold different B_local (ragged shards): sizes are exchanged first and shards are padded to
-    the largest one, so a single `all_gather_into_tensor` (one RCCL ring over xGMI) moves the payload."""
+    the largest one, so a single `all_gather_into_tensor` (one RCCL ring over xGMI) moves the payload.
+    `shard_sizes` (every rank's B_local, e.g. from `shard_range`) skips the size exchange and with it the only
+    host synchronisation of the call, so the gather stays asynchronous on the stream."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return codes
     world = dist.get_world_size()
     n_q, b_local, tf = codes.shape
-    sizes = torch.tensor([b_local], dtype=torch.int64, device=codes.device)
-    all_sizes = torch.empty(world, dtype=torch.int64, device=codes.device)
-    dist.all_gather_into_tensor(all_sizes, sizes)
-    all_sizes = all_sizes.tolist()
+    if shard_sizes is not None:
+        all_sizes = [int(v) for v in shard_sizes]
+        assert len(all_sizes) == world and all_sizes[dist.get_rank()] == b_local
+    else:
+        sizes = torch.tensor([b_local], dtype=torch.int64, device=codes.device)
+        all_sizes = torch.empty(world, dtype=torch.int64, device=codes.device)
+        dist.all_gather_into_tensor(all_sizes, sizes)
+        all_sizes = all_sizes.tolist()
     b_max = max(all_sizes)
     send = codes.permute(1, 0, 2).contiguous()                 # [B_local, n_q, Tf]: batch-major for concatenation
     if b_local < b_max:

@@ -19,6 +19,9 @@ def _worker(rank, world, port, total, n_q, tf, out):
         u = torch.arange(lo, hi, dtype=torch.int64)
         codes = (u[None, :, None] * 1000 + torch.arange(n_q)[:, None, None] * 10 + torch.arange(tf)[None, None, :]).contiguous()
         full = gather_codes(codes, dist)
+        # the same with the shard sizes known up front (no size exchange, no host sync): what bench.py does
+        sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+        assert torch.equal(gather_codes(codes, dist, shard_sizes=sizes), full)
         exp_u = torch.arange(total, dtype=torch.int64)
         expect = exp_u[None, :, None] * 1000 + torch.arange(n_q)[:, None, None] * 10 + torch.arange(tf)[None, None, :]
         ok = torch.equal(full, expect)
