@@ -23,6 +23,20 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _on_device(fn):
+    """Run a method with the engine's GPU as the thread's current device (kernels are launched on that device's stream;
+    a caller whose current device is another GPU must not have to know)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        if not torch.cuda.is_available():          # GPU-less box: let the call reach the library's own loud error
+            return fn(self, *a, **kw)
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **kw)
+    return wrapper
+
+
 class CodecEngine:
     """One engine per (device, checkpoint).  Calls on one engine are serialised by the caller,
     like a torch module's forward."""
@@ -90,6 +104,7 @@ class CodecEngine:
         return out
 
     # -- checkpoint ----------------------------------------------------------------------------
+    @_on_device
     def load_state_dict(self, state: Dict[str, "torch.Tensor | np.ndarray"]) -> None:
         """Tolerant load, like the reference's filter_state_dict
         (funcodec/torch_utils/load_pretrained_model.py:12-43): unknown keys (discriminator.*,
@@ -153,6 +168,7 @@ class CodecEngine:
     def set_profiling(self, on: bool) -> None:
         self._check(self.lib.fc_engine_profile(self._h, int(on)))
 
+    @_on_device
     def read_profile(self):
         """Per-kernel-class totals since the last read (synchronises on the last recorded event)."""
         arr = (_lib.FcProf * _lib.FC_PROF_CLASSES)()
@@ -173,6 +189,7 @@ class CodecEngine:
             out[k] = None if vals[0] is None else torch.cat(vals, dim)
         return out
 
+    @_on_device
     def encode(self, wav: torch.Tensor, n_q: int, want_sub_quants: bool = True, want_enc_out: bool = False):
         """wav [B,T] -> dict(codes [n_q,B,Tf] i64, quantized [B,Tf,D], sub_quants [n_q,B,D,Tf], scale [B,1]|None)."""
         wav = self._dev(wav, torch.float32)
@@ -194,6 +211,7 @@ class CodecEngine:
         return dict(codes=codes, quantized=quant, sub_quants=subq,
                     scale=None if scale is None else scale.view(B, 1), enc_out=enc)
 
+    @_on_device
     def encode_decode(self, wav: torch.Tensor, n_q: int, use_scale: bool = True, want_sub_quants: bool = True):
         wav = self._dev(wav, torch.float32)
         B, T = wav.shape
@@ -214,6 +232,7 @@ class CodecEngine:
         return dict(codes=codes, quantized=quant, sub_quants=subq,
                     scale=None if scale is None else scale.view(B, 1), recon=recon)
 
+    @_on_device
     def decode_codes(self, tokens: torch.Tensor):
         """tokens [B,Tf,n_q] i64 -> (wav [B,1,Tf*hop], emb [B,Tf,D])."""
         tokens = self._dev(tokens, torch.int64)
@@ -229,6 +248,7 @@ class CodecEngine:
                                              self._stream()))
         return wav, emb
 
+    @_on_device
     def decode_emb(self, emb: torch.Tensor, scale: Optional[torch.Tensor] = None, out_len: Optional[int] = None):
         """emb [B,Tf,D] -> wav [B,1,out_len or Tf*hop]."""
         emb = self._dev(emb, torch.float32)
@@ -249,6 +269,7 @@ class CodecEngine:
         return wav
 
     # -- per-op entry points (tests) -----------------------------------------------------------
+    @_on_device
     def rvq_encode(self, x: torch.Tensor, n_q: int):
         x = self._dev(x, torch.float32)
         N, D = x.shape
@@ -257,6 +278,7 @@ class CodecEngine:
         self._check(self.lib.fc_rvq_encode(self._h, _ptr(x), N, n_q, _ptr(codes), _ptr(quant), None, 0, self._stream()))
         return codes, quant
 
+    @_on_device
     def layer_forward(self, prefix: str, x: torch.Tensor, apply_elu: bool = False) -> torch.Tensor:
         x = self._dev(x, torch.float32)
         B, Cin, T = x.shape
@@ -274,6 +296,7 @@ class CodecEngine:
                                               ws.numel(), self._stream()))
         return y
 
+    @_on_device
     def lstm_forward(self, prefix: str, x: torch.Tensor) -> torch.Tensor:
         x = self._dev(x, torch.float32)
         B, H, T = x.shape
