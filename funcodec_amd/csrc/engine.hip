@@ -116,7 +116,6 @@ struct fc_engine {
     // quantiser
     float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
     float* cb_frag = nullptr;                // the codebooks in MFMA B-fragment order (kernels.hip rvq_encode_kernel), or null
-    float* zeros = nullptr;                  // 64 zero floats
     std::vector<void*> dev_allocs;
     // optional event timing
     bool profiling = false;
@@ -473,7 +472,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     }
     fc::ConvLaunch c;
     c.s0 = s0; c.s1 = s1; c.elu = elu; c.alpha = e->arch.elu_alpha;
-    c.wt = L.wt; c.bias = L.bias; c.koff = L.koff; c.zeros = e->zeros;
+    c.wt = L.wt; c.bias = L.bias; c.koff = L.koff;
     c.B = cx.B; c.Cin = L.cin; c.Tin = Tin; c.M = L.M;
     c.k = L.gk; c.stride = L.gstride; c.padL = g.padL; c.padR = g.padR;
     c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
@@ -802,7 +801,6 @@ int fc_engine_finalize(fc_engine* e) {
         }
         en[r] = s;
     }
-    if (upload(e, std::vector<float>(64, 0.f), &e->zeros)) return 1;
     if (upload(e, E, &e->cb)) return 1;
     if (K % 16 == 0 && D % 16 == 0) {
         // fragment order: [stage][16-code tile][q = d/16][g = (d%16)/4][code in tile][d%4]: lane (g, code) of a wave reads

@@ -22,7 +22,6 @@ struct ConvLaunch {
     const float* wt = nullptr;    // packed weights [mtile][chunk][Wbuf]: [kk][cl][BM] + zero pad to 4 KiB
     const float* bias = nullptr;  // [Mpad]
     const int* koff = nullptr;    // device table from conv_koff_table()
-    const float* zeros = nullptr; // device buffer of zeros (DMA source for padding)
     float* out = nullptr;
     long long out_sB = 0, out_sM = 0, out_sT = 1;
     int B = 0, Cin = 0, Tin = 0;
@@ -74,12 +73,6 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
 // codes [B][Tf][nq] (i64) -> emb [B][Tf][D] and/or emb_bdt [B][D][Tf]
 hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D, int K, const float* cb,
                              float* emb, float* emb_bdt, hipStream_t st);
-
-// One LSTM time step for all batch rows.  wperm [4H][H] rows permuted to (blk, unit, gate);
-// xproj [T][B][4H] (permuted the same way, biases folded); h_prev/h_next [B][H]; c [B][H] in place;
-// y[b][u][t] (layout [B][H][T]) receives h_t.
-hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float* h_prev, float* h_next,
-                            float* c, float* y, int B, int H, int T, int t, hipStream_t st);
 
 #define FC_LSTM_MAX_LAYERS 4
 // Layer-wavefront step s (see kernels.hip): w[0] = W_hh0 perm [4H][H]; w[l>=1] = [W_ih_l | W_hh_l] perm [4H][2H];

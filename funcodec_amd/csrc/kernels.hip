@@ -35,10 +35,11 @@ static inline __host__ __device__ int ceil_div(int a, int b) { return (a + b - 1
 //
 //    LDS:  Ws[2][Kc][BM]   weight chunk, k-major so the A fragment (lane -> row) is conflict free; filled by
 //                          global_load_lds DMA, double buffered (chunk c+1 streams in while chunk c computes)
-//          Xs[CC][S][PL]   input slab, split by stride phase so the B fragment (lane -> column) is
-//                          conflict free for every stride (tau = n*S + kk -> [kk % S][n + kk / S]); the raw
-//                          values of chunk c+1 are prefetched into registers during the MFMA loop of chunk c
+//          Xs[2][CC][S][PL] input slab, double buffered, split by stride phase so the B fragment (lane -> column) is
+//                          conflict free for every stride (tau = n*S + kk -> [kk % S][n + kk / S]); stride-1 layers
+//                          use rows of BN + k - 1 columns padded to 16 bytes (ROW staging)
 //          tab[Cin]        the producers' GroupNorm affine for this utterance
+//          kofs, bias, red the k-step -> slab offset table, the tile's bias, per-lane GroupNorm partials of two tiles
 // =================================================================================================
 struct ConvArgs {
     const float *src0, *aff0, *div0, *src1, *aff1;
@@ -52,15 +53,13 @@ struct ConvArgs {
     int elu; float alpha;
     int CC, nchunk, Kc;
     int Wbuf;               // floats per packed weight chunk (multiple of 1024)
-    int slabW, PL, rowStride, xs_floats;
+    int slabW, PL, rowStride;
     int row;                // stride-1 row staging (16-byte loads / LDS stores, one channel row per 32 or 64 lanes)
     int xsf;                // floats per slab buffer
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
-    const float* zeros;     // >= 4 zero floats in HBM: DMA source of padding elements
     const int* koff;        // [koff_n] B-operand LDS float offset per k-step (padded, multiple of 4)
     int koff_n;
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
-    int skew, skew_div;     // phase skew between co-resident workgroups (units of 64*64 cycles), see kernel
     int ablate;             // profiling aid (FC_ABLATE env): 1 no MFMA, 2 no stores, 4 no slab loads, 16 no weight DMA,
                             // 128 no epilogue.  0 in production.
 };
@@ -78,7 +77,6 @@ __device__ __forceinline__ float elu_f(float v, float alpha) {
 }
 
 constexpr int SLAB_PER_THREAD = 16;          // register-staged slab elements per thread per chunk (NU = 8 or 16)
-constexpr int SLAB_MAX = SLAB_PER_THREAD * 256;
 
 // Direct global -> LDS copy of one packed weight chunk (contiguous, multiple of 4 KiB): each wave
 // instruction moves 1 KiB (64 lanes x 16 B) with no VGPR round trip.
@@ -92,19 +90,6 @@ __device__ __forceinline__ void dma_weights(const float* __restrict__ gsrc, floa
     }
 }
 
-// Resolve slab element e of the chunk starting at channel c0 to its source index; returns false when the
-// element is padding that evaluates to literal zero.
-__device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int tbase, int& cl, int& tau, int& src) {
-    cl = (int)__umulhi((unsigned)e, p.magic_slabW);
-    tau = e - cl * p.slabW;
-    const int g = tbase + tau;
-    src = g;
-    if (c0 + cl >= p.Cin || g < -p.padL || g >= p.Tin + p.padR) return false;
-    if (p.pad_zero) return g >= 0 && g < p.Tin;
-    if (src < 0) src = -src;
-    if (src >= p.Leff) src = 2 * (p.Leff - 1) - src;
-    return src < p.Tin;      // zero-extension of inputs shorter than the pad (conv.py:89-93)
-}
 
 // MODE 0: plain single source (already activated input, no prologue math)
 // MODE 1/2: single source with GroupNorm affine (optional /div), without / with ELU
@@ -112,9 +97,11 @@ __device__ __forceinline__ bool slab_src(const ConvArgs& p, int e, int c0, int t
 // NU: slab elements staged per staging thread per chunk (compile time)
 //
 // Workgroup = 8 waves with two ROLES (wave specialisation):
-//   waves 0-3 "matrix": weight DMA, LDS fragment reads, MFMAs, epilogue stores + GroupNorm partials;
-//   waves 4-7 "staging": global loads of the NEXT slab into registers, prologue math (affine / residual / ELU /
-//                        padding) and the write into the other half of a double-buffered LDS slab.
+//   waves 0-3 "matrix": LDS fragment reads, MFMAs, epilogue stores, per-lane GroupNorm partials (and the weight DMA of
+//                        layers with prologue math);
+//   waves 4-7 "staging": global loads of the NEXT slab(s) into registers, prologue math (affine / residual / ELU /
+//                        padding), the write into the other half of the double-buffered LDS slab, the weight DMA of PLAIN
+//                        layers, and the fixed-order reduction of a finished tile's GroupNorm partials.
 // Each SIMD hosts one matrix wave and one staging wave of a workgroup, so prologue VALU work and memory latency
 // overlap the matrix pipe by construction.  One barrier per K-chunk.  A workgroup owns one (utterance, M tile) and
 // a contiguous range of N tiles; the pipeline runs across chunk and tile boundaries.
@@ -754,16 +741,11 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.row = c.row;
     if (c.row) { a.rowStride = (a.slabW + 3) & ~3; a.PL = a.rowStride; }   // 16-byte aligned rows
     a.xsf = c.CC * a.rowStride + 4;
-    a.xs_floats = ((c.CC * a.rowStride + 255) & ~255) + 4;   // whole 256-float DMA rounds + a dummy slot
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
-    a.zeros = c.zeros;
     a.koff = c.koff;
     a.koff_n = conv_koff_len(c.k, c.CC);
     a.cin_tail = (c.Cin % c.CC) != 0;
     static const int ablate = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
-    static const int skew = getenv("FC_SKEW") ? atoi(getenv("FC_SKEW")) : 0;
-    static const int skew_div = getenv("FC_SKEW_DIV") ? atoi(getenv("FC_SKEW_DIV")) : 256;
-    a.skew = skew; a.skew_div = skew_div;
     a.ablate = ablate;
     return a;
 }
@@ -1423,10 +1405,9 @@ hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D,
 }
 
 // =================================================================================================
-// 5. LSTM time step (nn.LSTM inside SLSTM, lstm.py:12-28).  One launch per t; workgroup j owns the
-//    16 gate rows {i,f,g,o} x 4 hidden units (rows permuted at load time), split-K over its waves,
-//    gates + state update fused.  gates = (W_hh h_{t-1}) + xproj_t,  xproj = W_ih x_t + b_ih + b_hh
-//    computed for all t at once by the conv kernel (k = 1).
+// 5. LSTM (nn.LSTM inside SLSTM, lstm.py:12-28).  Workgroup j owns the 16 gate rows {i,f,g,o} x 4 hidden units (rows
+//    permuted at load time), split-K over its waves, gates + state update fused.
+//    gates = (W_hh h_{t-1}) + xproj_t,  xproj = W_ih x_t + b_ih + b_hh computed for all t at once by the conv kernel (k = 1).
 // =================================================================================================
 // Gate nonlinearities on the hardware exp2 / rcp (1 ulp each): sigmoid(v) = 1 / (1 + 2^(-v log2 e)), tanh(v) = 2 sigmoid(2v) - 1.
 // Absolute error <= ~2e-7 (the libm versions are ~40 and ~60 VALU instructions and sit on the recurrence's critical path);
@@ -1438,110 +1419,6 @@ __device__ __forceinline__ float sigmoid_f(float v) {
 __device__ __forceinline__ float tanh_f(float v) {
     const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * v);
     return fmaf(2.f, __builtin_amdgcn_rcpf(1.f + e), -1.f);
-}
-
-// NS = 16-wide k super-steps per wave (compile time, so that all W / h fragments are loaded up front and stay
-// in flight together); NS == 0 selects the generic runtime loop.
-template <int NS>
-__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ wperm, const float* __restrict__ xproj,
-                                                        const float* __restrict__ h_prev, float* __restrict__ h_next,
-                                                        float* __restrict__ c, float* __restrict__ y, int B, int H, int T,
-                                                        int t, int KS) {
-    __shared__ f32x4 red[4][64];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int g = lane >> 4, r16 = lane & 15;
-    const int blk = blockIdx.x;
-    const int kslice = H / KS;
-    const int nsteps = kslice >> 4;
-    const bool active = wid < KS;
-    const float* wrow = wperm + ((size_t)blk * 16 + r16) * H + (active ? wid : 0) * kslice + 4 * g;
-    constexpr int NA = NS > 0 ? NS : 1;
-    f32x4 a4[NA];
-    if (NS > 0) {
-#pragma unroll
-        for (int q = 0; q < NA; ++q) a4[q] = *(const f32x4*)(wrow + 16 * q);
-    }
-    const int nbt = (B + 15) >> 4;
-    for (int nb = 0; nb < nbt; ++nb) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int brow = nb * 16 + r16;
-        const bool bvalid = brow < B;
-        const float* hrow = h_prev + (size_t)(bvalid ? brow : 0) * H + (active ? wid : 0) * kslice + 4 * g;
-        // wave 0 finishes the step: fetch its x-projection and cell state now so the latency hides under the MFMAs
-        const size_t ci = (size_t)(bvalid ? brow : 0) * H + (size_t)blk * 4 + g;
-        f32x4 xp = {0.f, 0.f, 0.f, 0.f};
-        float cprev = 0.f;
-        if (wid == 0) {
-            xp = *(const f32x4*)(xproj + ((size_t)t * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
-            cprev = c[ci];
-        }
-        if (NS > 0) {
-            f32x4 b4[NA];
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                b4[q] = *(const f32x4*)(hrow + 16 * q);
-                if (!bvalid) b4[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (q & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[q][j], acc1, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[q][j], b4[q][j], acc, 0, 0, 0);
-                }
-            }
-            acc = acc + acc1;
-        } else if (active) {
-            for (int q = 0; q < nsteps; ++q) {
-                const f32x4 av = *(const f32x4*)(wrow + 16 * q);
-                f32x4 bv = *(const f32x4*)(hrow + 16 * q);
-                if (!bvalid) bv = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
-            }
-        }
-        if (!active) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        red[wid][lane] = acc;
-        __syncthreads();
-        if (wid == 0) {
-            f32x4 s = red[0][lane];
-            for (int w = 1; w < KS; ++w) s = s + red[w][lane];
-            if (bvalid) {
-                const float gi = sigmoid_f(s[0] + xp[0]);
-                const float gf = sigmoid_f(s[1] + xp[1]);
-                const float gg = tanh_f(s[2] + xp[2]);
-                const float go = sigmoid_f(s[3] + xp[3]);
-                const float cn = gf * cprev + gi * gg;
-                const float hn = go * tanh_f(cn);
-                c[ci] = cn;
-                h_next[ci] = hn;
-                y[ci * T + t] = hn;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-hipError_t launch_lstm_step(const float* wperm, const float* xproj, const float* h_prev, float* h_next, float* c,
-                            float* y, int B, int H, int T, int t, hipStream_t st) {
-    if (H % 16 != 0) return hipErrorInvalidValue;
-    int KS = 4;
-    while (KS > 1 && (H % (16 * KS)) != 0) KS >>= 1;
-    const int ns = H / (16 * KS);
-    dim3 grid(H / 4), block(256);
-#define FC_LSTM_CASE(NS) \
-    hipLaunchKernelGGL(lstm_step_kernel<NS>, grid, block, 0, st, wperm, xproj, h_prev, h_next, c, y, B, H, T, t, KS)
-    switch (ns) {
-        case 1: FC_LSTM_CASE(1); break;
-        case 2: FC_LSTM_CASE(2); break;
-        case 4: FC_LSTM_CASE(4); break;
-        case 8: FC_LSTM_CASE(8); break;
-        case 16: FC_LSTM_CASE(16); break;
-        default: FC_LSTM_CASE(0); break;
-    }
-#undef FC_LSTM_CASE
-    return hipGetLastError();
 }
 
 // -------------------------------------------------------------------------------------------------
