@@ -1126,8 +1126,17 @@ __global__ __launch_bounds__(1024) void volume_kernel(const float* __restrict__ 
     __shared__ double sh[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* x = wav + (size_t)b * T;
-    double s = 0.0;
-    for (int t = tid; t < T; t += 1024) { const float v = x[t]; s += (double)(v * v); }
+    // 16-byte loads (dword alignment only: T need not be a multiple of 4) and four independent fp64 chains per thread:
+    // one dependent add chain per element kept this 10 MB reduction at 70 us
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int T4 = T >> 2;
+    for (int q = tid; q < T4; q += 1024) {
+        const f32x4 v = *(const f32x4u*)(x + 4 * q);
+        s0 += (double)(v[0] * v[0]); s1 += (double)(v[1] * v[1]); s2 += (double)(v[2] * v[2]); s3 += (double)(v[3] * v[3]);
+    }
+    for (int t = 4 * T4 + tid; t < T; t += 1024) { const float v = x[t]; s0 += (double)(v * v); }
+    const double s = (s0 + s1) + (s2 + s3);
     sh[tid] = s;
     __syncthreads();
     for (int o = 512; o >= 1; o >>= 1) {
