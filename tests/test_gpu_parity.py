@@ -182,6 +182,41 @@ def test_conv_padding_edge_lengths(T):
         assert got.shape == ref.shape and (got - ref).abs().max().item() < 2e-4, (p, T)
 
 
+def test_conv_layers_random_shape_sweep():
+    """Seeded sweep over (layer, batch, length, ELU) of both real recipes: lengths around the tile widths (127..129,
+    255..257, 1023..1025), tiny lengths, primes; every staging scheme (element / row / single-output-channel kernel), edge-
+    only and interior tiles, strided and transposed layers.  Reference = the torch restatement of SConv1d / SConvTranspose1d."""
+    import torch_oracle as TO
+    rng = np.random.Generator(np.random.PCG64(2024))
+    lengths = [1, 2, 5, 17, 63, 127, 128, 129, 255, 256, 257, 511, 640, 1023, 1024, 1025, 1531, 2053]
+    for cfg_name in ("ds320", "ds640"):
+        m = engine_for(cfg_name, 0)
+        orc = oracle_for(cfg_name, 0)
+        layers = _layer_cases(cfg_name, 0)
+        for _ in range(36):
+            p = layers[int(rng.integers(len(layers)))]
+            tr = p.endswith("convtr")
+            w = orc.sd[p + (".convtr.weight" if tr else ".conv.weight")]
+            cin, k = (w.shape[0] if tr else w.shape[1]), w.shape[2]
+            T = lengths[int(rng.integers(len(lengths)))]
+            if cin >= 512:
+                T = min(T, 257)                      # keep the CPU reference cheap on the wide layers
+            B = int(rng.integers(1, 4))
+            elu = bool(rng.integers(2))
+            x = torch.from_numpy(rng.standard_normal((B, cin, T)).astype(np.float32))
+            xin = F.elu(x) if elu else x
+            if tr:
+                ref = TO.sconvtr1d(xin, *orc._p(p), k // 2, orc.eps)
+            else:
+                ref = TO.sconv1d(xin, *orc._p(p), (k // 2 if (k % 2 == 0 and k > 1) else 1), orc.eps)
+            got = m.engine.layer_forward(p, x, apply_elu=elu).cpu()
+            assert got.shape == ref.shape, (cfg_name, p, B, T, got.shape, ref.shape)
+            # GroupNorm over very few elements (short T) amplifies rounding: tolerance as in the padding edge test
+            tol = 2e-4 if ref.shape[-1] * ref.shape[1] < 4096 else LAYER_ABS_TOL
+            err = (got - ref).abs().max().item()
+            assert err < tol, (cfg_name, p, B, T, elu, err)
+
+
 @pytest.mark.parametrize("T", [769, 1024, 1291])
 def test_row_staging_interior_and_straddling_tiles(T):
     """The stride-1 layers of the real recipe use row staging (16-byte loads, one channel row per 32 / 64 lanes, k-1 tail
