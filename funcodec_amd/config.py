@@ -44,6 +44,10 @@ class ArchSpec:
     encoder_hop_length: int = 320
     quantizer_sampling_rate: int = 16000
     use_ddp: bool = True
+    # conv wrapper flavour (modules/normed_modules/conv.py): GroupNorm(1, C) after every conv, or weight-normalised convs /
+    # plain convs without an output norm; causal = all padding on the left, transposed convs trimmed on the right only
+    norm: str = "time_group_norm"
+    causal: bool = False
     # Encodec framing (codec_basic.py:288-298): None = one frame; else frames of segment_dur seconds, hop (1-overlap)*length
     segment_dur: Optional[float] = None
     overlap_ratio: float = 0.01
@@ -93,10 +97,12 @@ def _unsupported(key: str, value: Any, why: str = "") -> NotImplementedError:
 def _check_seanet_conf(conf: Dict[str, Any], which: str) -> Dict[str, Any]:
     conf = dict(conf or {})
     norm = conf.get("norm", "weight_norm")
-    if norm != "time_group_norm":
-        raise _unsupported(f"{which}.norm", norm, "only time_group_norm checkpoints are supported")
-    if conf.get("causal", False):
-        raise _unsupported(f"{which}.causal", True)
+    if norm not in ("time_group_norm", "weight_norm", "none"):
+        raise _unsupported(f"{which}.norm", norm, "time_group_norm, weight_norm and none are supported")
+    if conf.get("causal", False) and norm == "time_group_norm":
+        raise _unsupported(f"{which}.causal", True, "the reference refuses GroupNorm with causal=True (conv.py:46-47)")
+    if conf.get("trim_right_ratio", 1.0) != 1.0:
+        raise _unsupported(f"{which}.trim_right_ratio", conf["trim_right_ratio"])
     if conf.get("pad_mode", "reflect") != "reflect":
         raise _unsupported(f"{which}.pad_mode", conf["pad_mode"])
     if conf.get("activation", "ELU") != "ELU":
@@ -187,6 +193,8 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         encoder_hop_length=int(q.get("encoder_hop_length", 320)),
         quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
         use_ddp=bool(q.get("use_ddp", True)),
+        norm=str(shared("norm", "weight_norm")),
+        causal=bool(shared("causal", False)),
         segment_dur=None if m.get("segment_dur", None) is None else float(m["segment_dur"]),
         overlap_ratio=0.01 if m.get("overlap_ratio", None) is None else float(m["overlap_ratio"]),
     )
@@ -205,6 +213,13 @@ def recipe_config(name: str) -> Dict[str, Any]:
         cfg = recipe_config("ds320")
         cfg["model_conf"]["segment_dur"] = 0.5
         cfg["model_conf"]["overlap_ratio"] = 0.1
+        return cfg
+    if name in ("ds320wn", "tinywn"):   # weight-normalised, causal variants of the same nets (EnCodec-style streaming convs)
+        cfg = recipe_config("ds320" if name == "ds320wn" else "tiny")
+        for k in ("encoder_conf", "decoder_conf"):
+            cfg[k]["norm"] = "weight_norm"
+            cfg[k]["causal"] = True
+            cfg[k].pop("norm_params", None)
         return cfg
     if name == "ds640":
         ratios, hop = [8, 5, 4, 2, 2], 640

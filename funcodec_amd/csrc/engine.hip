@@ -41,7 +41,9 @@ struct ConvLayer {
     std::string prefix;     // e.g. "encoder.model.3.conv" / "decoder.model.3.convtr"
     bool transposed = false;
     int cin = 0, cout = 0, k = 1, stride = 1;
-    bool has_norm = true;
+    bool has_norm = true;   // GroupNorm(1, cout) after the conv
+    bool wnorm = false;     // checkpoint stores weight_g / weight_v (torch.nn.utils.weight_norm)
+    bool causal = false;
     bool dual = false;      // the plan feeds it two summed sources (residual sum / LSTM skip)
     bool small_n = false;   // runs at the bottleneck frame rate: few columns per utterance
     // GEMM view
@@ -160,13 +162,18 @@ struct ProfSpan {   // RAII: records start now, stop at scope exit
 // ---- plan construction (mirrors nn.Sequential indices: seanet_encoder.py:109-160, seanet_decoder.py:111-164)
 void add_conv_expect(fc_engine* e, ConvLayer& L) {
     const std::string inner = L.transposed ? ".convtr" : ".conv";
-    if (L.transposed)
-        e->expected.push_back({L.prefix + inner + ".weight", {L.cin, L.cout, L.k}});
-    else
-        e->expected.push_back({L.prefix + inner + ".weight", {L.cout, L.cin, L.k}});
+    const int d0 = L.transposed ? L.cin : L.cout, d1 = L.transposed ? L.cout : L.cin;
+    if (L.wnorm) {
+        e->expected.push_back({L.prefix + inner + ".weight_g", {d0, 1, 1}});
+        e->expected.push_back({L.prefix + inner + ".weight_v", {d0, d1, L.k}});
+    } else {
+        e->expected.push_back({L.prefix + inner + ".weight", {d0, d1, L.k}});
+    }
     e->expected.push_back({L.prefix + inner + ".bias", {L.cout}});
-    e->expected.push_back({L.prefix + ".norm.weight", {L.cout}});
-    e->expected.push_back({L.prefix + ".norm.bias", {L.cout}});
+    if (L.has_norm) {
+        e->expected.push_back({L.prefix + ".norm.weight", {L.cout}});
+        e->expected.push_back({L.prefix + ".norm.bias", {L.cout}});
+    }
     e->by_prefix[L.prefix] = &L;
 }
 
@@ -251,6 +258,17 @@ void build_plan(fc_engine* e) {
     idx++;
     e->dec_last = mk_conv(name("decoder", idx, ".conv"), nf, 1, a.last_kernel_size, 1, false, true);
 
+    // ---- conv wrapper flavour of every SConv1d / SConvTranspose1d of the nets (conv.py:20-56)
+    {
+        std::vector<ConvLayer*> all = {&e->enc_first, &e->enc_last, &e->dec_first, &e->dec_last};
+        for (auto& S : e->enc_stages) { all.push_back(&S.shortcut); all.push_back(&S.block1); all.push_back(&S.block3); all.push_back(&S.resample); }
+        for (auto& S : e->dec_stages) { all.push_back(&S.shortcut); all.push_back(&S.block1); all.push_back(&S.block3); all.push_back(&S.resample); }
+        for (ConvLayer* L : all) {
+            L->has_norm = a.norm_type == 0;
+            L->wnorm = a.norm_type == 1;
+            L->causal = a.causal != 0;
+        }
+    }
     // ---- checkpoint contract, in execution order
     add_conv_expect(e, e->enc_first);
     for (auto& S : e->enc_stages) {
@@ -293,7 +311,7 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     // channels per K-chunk: as many as fit (a) the register-staged slab, (b) K-chunk <= 64, (c) half of the LDS
     // (two workgroups per CU).  Layers with >= 3 M tiles get their input materialised (run_conv) and therefore
     // always run the PLAIN variant: no affine tables, and the 16-element staging variant has no register pressure.
-    const bool plain = ceil_div_i(L.M, L.BM) >= 3 || !L.has_norm;
+    const bool plain = ceil_div_i(L.M, L.BM) >= 3;
     const bool dual_eff = L.dual && !plain;
     int cin_p2 = 2;
     while (cin_p2 < L.cin) cin_p2 *= 2;
@@ -363,7 +381,23 @@ int pack_gemm(fc_engine* e, ConvLayer& L, const std::vector<float>& wg /*[M][cin
 
 int pack_conv(fc_engine* e, ConvLayer& L) {
     const std::string inner = L.transposed ? ".convtr" : ".conv";
-    const auto& W = e->host[L.prefix + inner + ".weight"].data;
+    std::vector<float> folded;
+    if (L.wnorm) {
+        // torch.nn.utils.weight_norm (conv.py:24-25): weight = v * (g / ||v||), the 2-norm taken over every dim but 0
+        // (dim 0 = out channels of Conv1d, IN channels of ConvTranspose1d)
+        const auto& V = e->host[L.prefix + inner + ".weight_v"].data;
+        const auto& G = e->host[L.prefix + inner + ".weight_g"].data;
+        const size_t d0 = L.transposed ? L.cin : L.cout, inner_n = V.size() / d0;
+        folded.resize(V.size());
+        for (size_t r = 0; r < d0; ++r) {
+            double ss = 0.0;
+            for (size_t j = 0; j < inner_n; ++j) ss += (double)V[r * inner_n + j] * (double)V[r * inner_n + j];
+            const float nrm = (float)sqrt(ss);
+            const float sc = G[r] / nrm;
+            for (size_t j = 0; j < inner_n; ++j) folded[r * inner_n + j] = V[r * inner_n + j] * sc;
+        }
+    }
+    const auto& W = L.wnorm ? folded : e->host[L.prefix + inner + ".weight"].data;
     const auto& Bv = e->host[L.prefix + inner + ".bias"].data;
     if (!L.transposed) {
         if (pack_gemm(e, L, W, Bv)) return 1;
@@ -388,8 +422,10 @@ int pack_conv(fc_engine* e, ConvLayer& L) {
             }
         if (pack_gemm(e, L, wg, bg)) return 1;
     }
-    if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
-    if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
+    if (L.has_norm) {
+        if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
+        if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
+    }
     return 0;
 }
 
@@ -440,8 +476,8 @@ ConvGeom conv_geom(const ConvLayer& L, int T) {
         const int nfr = num >= 0 ? ceil_div_i(num, L.stride) : -((-num) / L.stride);   // ceil(n_frames) - 1
         const int ideal = nfr * L.stride + (L.k - pt);
         const int extra = ideal - T;
-        g.padR = pt / 2 + extra;
-        g.padL = pt - pt / 2;
+        if (L.causal) { g.padL = pt; g.padR = extra; }          // all fixed padding on the left (conv.py:249-251)
+        else { g.padR = pt / 2 + extra; g.padL = pt - pt / 2; }
         g.Tout = nfr + 1;
         g.count_T = g.Tout;
     } else {
@@ -481,7 +517,8 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     out.C = L.cout; out.T = g.Tout;
     if (L.transposed) {
         c.Tout = Tin + 1; c.pad_zero = 1;
-        c.up_r = L.stride; c.trimL = L.stride - L.stride / 2; c.Tfinal = g.Tout;
+        // unpad1d: non-causal trims left = r - r/2, right = r/2; causal (trim_right_ratio 1) trims everything on the right
+        c.up_r = L.stride; c.trimL = L.causal ? 0 : L.stride - L.stride / 2; c.Tfinal = g.Tout;
     } else {
         c.Tout = g.Tout;
     }
@@ -690,6 +727,8 @@ const char* fc_last_error(void) { return g_err.c_str(); }
 int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (!arch || !out) return fail("null argument");
     if (arch->abi_version != FC_ABI_VERSION) return fail("fc_arch.abi_version mismatch");
+    if (arch->norm_type < 0 || arch->norm_type > 2) return fail("fc_arch.norm_type must be 0 (GroupNorm), 1 (weight_norm) or 2 (none)");
+    if (arch->norm_type == 0 && arch->causal) return fail("GroupNorm convs cannot be causal (the reference refuses it too, conv.py:46-47)");
     if (arch->n_ratios < 1 || arch->n_ratios > FC_MAX_RATIOS) return fail("n_ratios out of range");
     if (arch->compress < 1 || arch->n_filters < 2 || (arch->n_filters % arch->compress) != 0) return fail("bad n_filters/compress");
     if (arch->n_filters % 2) return fail("n_filters must be even");

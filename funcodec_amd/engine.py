@@ -74,6 +74,8 @@ class CodecEngine:
         a.gn_eps = arch.gn_eps
         a.codebook_size = arch.codebook_size
         a.num_quantizers = arch.num_quantizers
+        a.norm_type = {"time_group_norm": 0, "weight_norm": 1, "none": 2}[arch.norm]
+        a.causal = int(arch.causal)
         h = C.c_void_p()
         self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
         self._h = h
@@ -285,7 +287,8 @@ class CodecEngine:
         Tout = self.lib.fc_layer_out_len(self._h, prefix.encode(), T)
         if Tout < 0:
             raise EngineError(f"unknown layer {prefix}")
-        cout = self.expected_tensors()[prefix + ".norm.weight"][0]
+        inner = ".convtr.bias" if prefix.endswith("convtr") else ".conv.bias"
+        cout = self.expected_tensors()[prefix + inner][0]
         y = torch.empty((B, cout, Tout), dtype=torch.float32, device=self.device)
         ws = self._workspace(B, max(T, Tout) * 4 + 4096)
         need = (B * cout * (Tout + 64) * 4) * 2 + (1 << 20)

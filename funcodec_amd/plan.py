@@ -83,17 +83,21 @@ def decoder_plan(a: ArchSpec) -> List[ConvOp]:
 def expected_tensors(a: ArchSpec) -> Dict[str, Tuple[int, ...]]:
     """Every checkpoint tensor the hot path consumes: key -> shape (reference layout)."""
     out: Dict[str, Tuple[int, ...]] = {}
+    gn = a.norm == "time_group_norm"
+    wn = a.norm == "weight_norm"      # torch.nn.utils.weight_norm: weight = weight_v * (weight_g / ||weight_v||), norm over dims != 0
     for op in encoder_plan(a) + decoder_plan(a):
-        if op.kind == "conv":
-            out[f"{op.key}.conv.weight"] = (op.cout, op.cin, op.k)
-            out[f"{op.key}.conv.bias"] = (op.cout,)
-            out[f"{op.key}.norm.weight"] = (op.cout,)
-            out[f"{op.key}.norm.bias"] = (op.cout,)
-        elif op.kind == "convtr":
-            out[f"{op.key}.convtr.weight"] = (op.cin, op.cout, op.k)
-            out[f"{op.key}.convtr.bias"] = (op.cout,)
-            out[f"{op.key}.norm.weight"] = (op.cout,)
-            out[f"{op.key}.norm.bias"] = (op.cout,)
+        if op.kind in ("conv", "convtr"):
+            inner = op.kind
+            wshape = (op.cout, op.cin, op.k) if op.kind == "conv" else (op.cin, op.cout, op.k)
+            if wn:
+                out[f"{op.key}.{inner}.weight_g"] = (wshape[0], 1, 1)
+                out[f"{op.key}.{inner}.weight_v"] = wshape
+            else:
+                out[f"{op.key}.{inner}.weight"] = wshape
+            out[f"{op.key}.{inner}.bias"] = (op.cout,)
+            if gn:
+                out[f"{op.key}.norm.weight"] = (op.cout,)
+                out[f"{op.key}.norm.bias"] = (op.cout,)
         else:
             h = op.cin
             for l in range(a.lstm_layers):

@@ -39,10 +39,18 @@ def make_state_dict(arch: ArchSpec, seed: int = 0, codebook_sigma_decay: float =
             wshape = (op.cout, op.cin, op.k) if op.kind == "conv" else (op.cin, op.cout, op.k)
             fan_in = op.cin * op.k if op.kind == "conv" else op.cout * op.k  # torch's fan_in for ConvTranspose
             bound = 1.0 / np.sqrt(fan_in)
-            sd[f"{op.key}.{inner}.weight"] = uni(wshape, bound)
+            if arch.norm == "weight_norm":
+                # a trained checkpoint has g != ||v||: randomise g around the norm so that a loader which ignores g fails
+                v = uni(wshape, bound)
+                nrm = np.sqrt((v.astype(np.float64) ** 2).sum(axis=(1, 2), keepdims=True))
+                sd[f"{op.key}.{inner}.weight_v"] = v
+                sd[f"{op.key}.{inner}.weight_g"] = (nrm * (1.0 + 0.2 * rng.standard_normal(nrm.shape))).astype(np.float32)
+            else:
+                sd[f"{op.key}.{inner}.weight"] = uni(wshape, bound)
             sd[f"{op.key}.{inner}.bias"] = uni((op.cout,), bound)
-            sd[f"{op.key}.norm.weight"] = (1.0 + 0.1 * rng.standard_normal(op.cout)).astype(np.float32)
-            sd[f"{op.key}.norm.bias"] = (0.1 * rng.standard_normal(op.cout)).astype(np.float32)
+            if arch.norm == "time_group_norm":
+                sd[f"{op.key}.norm.weight"] = (1.0 + 0.1 * rng.standard_normal(op.cout)).astype(np.float32)
+                sd[f"{op.key}.norm.bias"] = (0.1 * rng.standard_normal(op.cout)).astype(np.float32)
         else:
             h = op.cin
             bound = 1.0 / np.sqrt(h)

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define FC_MAX_RATIOS 8
-#define FC_ABI_VERSION 1
+#define FC_ABI_VERSION 2
 
 typedef struct fc_engine fc_engine;
 
@@ -53,6 +53,10 @@ typedef struct fc_arch {
     float   gn_eps;                 /* 1e-5 */
     int32_t codebook_size;          /* 1024 */
     int32_t num_quantizers;         /* 32 */
+    /* conv wrapper flavour (funcodec/modules/normed_modules/conv.py:20-56,205-305), ABI version 2: */
+    int32_t norm_type;              /* 0 = GroupNorm(1,C) after every conv ("time_group_norm"); 1 = weight_norm (checkpoint holds
+                                       weight_g / weight_v, no output norm); 2 = none (plain weight, no output norm) */
+    int32_t causal;                 /* 1: all conv padding on the left, transposed convs trimmed on the right only */
 } fc_arch;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

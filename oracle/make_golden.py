@@ -40,6 +40,9 @@ CASES = [
     ("ds320_b1_t16000", "ds320", 0, 1.0, "noise", 1234, 1, 16000, None),
     ("ds640_b2_t16000", "ds640", 0, 1.0, "tones", 21, 2, 16000, None),
     ("ds640_b1_t9999_bw4000", "ds640", 0, 1.0, "noise", 22, 1, 9999, 4000),
+    # weight-normalised causal convs (norm: weight_norm, causal: true; conv.py:20-56,243-305)
+    ("tinywn_b2_t777", "tinywn", 9, 1.0, "tones", 51, 2, 777, None),
+    ("ds320wn_b1_t12000", "ds320wn", 0, 1.0, "noise", 52, 1, 12000, None),
 ]
 
 

@@ -45,27 +45,42 @@ def pad1d_reflect(x: torch.Tensor, paddings: Tuple[int, int]) -> torch.Tensor:
     return padded[..., :end]
 
 
-def sconv1d(x, w, b, gamma, beta, stride: int, eps: float):
-    """SConv1d.forward conv.py:243-261 (non-causal) -> NormConv1d.forward :155-164 -> GroupNorm(1,C) :45-52."""
+def sconv1d(x, w, b, gamma, beta, stride: int, eps: float, causal: bool = False):
+    """SConv1d.forward conv.py:243-261 -> NormConv1d.forward :155-164 -> GroupNorm(1,C) :45-52 (gamma None: no output
+    norm, i.e. norm = weight_norm / none)."""
     k = w.shape[-1]
     padding_total = (k - 1) - (stride - 1)
     extra = get_extra_padding_for_conv1d(x.shape[-1], k, stride, padding_total)
-    pr = padding_total // 2
-    pl = padding_total - pr
-    x = pad1d_reflect(x, (pl, pr + extra))
+    if causal:
+        x = pad1d_reflect(x, (padding_total, extra))              # :249-251
+    else:
+        pr = padding_total // 2
+        pl = padding_total - pr
+        x = pad1d_reflect(x, (pl, pr + extra))
     y = F.conv1d(x, w, b, stride=stride)
-    return F.group_norm(y, 1, gamma, beta, eps)
+    return y if gamma is None else F.group_norm(y, 1, gamma, beta, eps)
 
 
-def sconvtr1d(x, w, b, gamma, beta, stride: int, eps: float):
-    """SConvTranspose1d.forward conv.py:281-305: ConvTranspose1d -> GroupNorm on the UNTRIMMED output -> unpad1d."""
+def sconvtr1d(x, w, b, gamma, beta, stride: int, eps: float, causal: bool = False):
+    """SConvTranspose1d.forward conv.py:281-305: ConvTranspose1d -> GroupNorm on the UNTRIMMED output -> unpad1d
+    (causal, trim_right_ratio = 1: everything trimmed on the right :292-297)."""
     k = w.shape[-1]
     y = F.conv_transpose1d(x, w, b, stride=stride)
-    y = F.group_norm(y, 1, gamma, beta, eps)
+    if gamma is not None:
+        y = F.group_norm(y, 1, gamma, beta, eps)
     padding_total = k - stride
-    pr = padding_total // 2
-    pl = padding_total - pr
+    if causal:
+        pr = math.ceil(padding_total * 1.0)
+        pl = padding_total - pr
+    else:
+        pr = padding_total // 2
+        pl = padding_total - pr
     return y[..., pl: y.shape[-1] - pr]
+
+
+def weight_norm_fold(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """torch.nn.utils.weight_norm (dim = 0): the weight the module computes in its forward pre-hook."""
+    return torch._weight_norm(v, g, 0)
 
 
 class Oracle:
@@ -75,7 +90,10 @@ class Oracle:
         self.cfg = config
         enc, dec = dict(config.get("encoder_conf", {})), dict(config.get("decoder_conf", {}))
         q, m = dict(config.get("quantizer_conf", {})), dict(config.get("model_conf", {}))
-        assert enc.get("norm") == "time_group_norm" and not enc.get("causal", False)
+        self.norm = enc.get("norm", "weight_norm")
+        self.causal = bool(enc.get("causal", False))
+        assert self.norm in ("time_group_norm", "weight_norm", "none") and dec.get("norm", "weight_norm") == self.norm
+        assert bool(dec.get("causal", False)) == self.causal
         self.ratios: List[int] = list(enc.get("ratios", [8, 5, 4, 2]))
         assert list(dec.get("ratios", [8, 5, 4, 2])) == self.ratios
         self.n_filters = enc.get("n_filters", 32)
@@ -100,12 +118,17 @@ class Oracle:
     # -- small helpers -------------------------------------------------------------------------
     def _p(self, prefix):
         inner = "convtr" if prefix.endswith("convtr") else "conv"
-        return (self.sd[f"{prefix}.{inner}.weight"], self.sd[f"{prefix}.{inner}.bias"],
-                self.sd[f"{prefix}.norm.weight"], self.sd[f"{prefix}.norm.bias"])
+        if self.norm == "weight_norm":
+            w = weight_norm_fold(self.sd[f"{prefix}.{inner}.weight_v"], self.sd[f"{prefix}.{inner}.weight_g"])
+        else:
+            w = self.sd[f"{prefix}.{inner}.weight"]
+        if self.norm == "time_group_norm":
+            return w, self.sd[f"{prefix}.{inner}.bias"], self.sd[f"{prefix}.norm.weight"], self.sd[f"{prefix}.norm.bias"]
+        return w, self.sd[f"{prefix}.{inner}.bias"], None, None
 
     def _conv(self, x, prefix, stride=1):
         w, b, g, be = self._p(prefix)
-        return sconv1d(x, w, b, g, be, stride, self.eps)
+        return sconv1d(x, w, b, g, be, stride, self.eps, self.causal)
 
     def _elu(self, x):
         return F.elu(x, self.alpha)                                  # activations.py:24-30
@@ -162,7 +185,7 @@ class Oracle:
         for ratio in self.ratios:
             idx += 1
             w, b, g, be = self._p(f"decoder.model.{idx}.convtr")
-            x = sconvtr1d(self._elu(x), w, b, g, be, ratio, self.eps)
+            x = sconvtr1d(self._elu(x), w, b, g, be, ratio, self.eps, self.causal)
             idx += 1
             x = self._resblock(x, f"decoder.model.{idx}")
             idx += 1

@@ -125,9 +125,10 @@ def _layer_cases(cfg_name, seed):
     cfg, arch, sd = state_for(cfg_name, seed)
     out = []
     for k in sd:
-        if k.endswith(".norm.weight"):
-            out.append(k[: -len(".norm.weight")])
-    return sorted(out)
+        for suffix in (".conv.bias", ".convtr.bias"):
+            if k.endswith(suffix) and k.startswith(("encoder.", "decoder.")):
+                out.append(k[: -len(suffix)])
+    return sorted(set(out))
 
 
 @pytest.mark.parametrize("cfg_name,seed,B,T0", [("tiny", 7, 3, 203), ("ds640", 0, 2, 3200)])
@@ -189,14 +190,14 @@ def test_conv_layers_random_shape_sweep():
     import torch_oracle as TO
     rng = np.random.Generator(np.random.PCG64(2024))
     lengths = [1, 2, 5, 17, 63, 127, 128, 129, 255, 256, 257, 511, 640, 1023, 1024, 1025, 1531, 2053]
-    for cfg_name in ("ds320", "ds640"):
+    for cfg_name in ("ds320", "ds640", "ds320wn"):
         m = engine_for(cfg_name, 0)
         orc = oracle_for(cfg_name, 0)
         layers = _layer_cases(cfg_name, 0)
         for _ in range(36):
             p = layers[int(rng.integers(len(layers)))]
             tr = p.endswith("convtr")
-            w = orc.sd[p + (".convtr.weight" if tr else ".conv.weight")]
+            w = orc._p(p)[0]                         # (folded) weight: [Cout,Cin,k] or [Cin,Cout,k]
             cin, k = (w.shape[0] if tr else w.shape[1]), w.shape[2]
             T = lengths[int(rng.integers(len(lengths)))]
             if cin >= 512:
@@ -206,9 +207,9 @@ def test_conv_layers_random_shape_sweep():
             x = torch.from_numpy(rng.standard_normal((B, cin, T)).astype(np.float32))
             xin = F.elu(x) if elu else x
             if tr:
-                ref = TO.sconvtr1d(xin, *orc._p(p), k // 2, orc.eps)
+                ref = TO.sconvtr1d(xin, *orc._p(p), k // 2, orc.eps, orc.causal)
             else:
-                ref = TO.sconv1d(xin, *orc._p(p), (k // 2 if (k % 2 == 0 and k > 1) else 1), orc.eps)
+                ref = TO.sconv1d(xin, *orc._p(p), (k // 2 if (k % 2 == 0 and k > 1) else 1), orc.eps, orc.causal)
             got = m.engine.layer_forward(p, x, apply_elu=elu).cpu()
             assert got.shape == ref.shape, (cfg_name, p, B, T, got.shape, ref.shape)
             # GroupNorm over very few elements (short T) amplifies rounding: tolerance as in the padding edge test

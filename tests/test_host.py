@@ -59,11 +59,19 @@ def test_arch_from_recipe_configs():
     assert a.segment_length is None and a.segment_stride is None
     s = arch_from_config(recipe_config("ds320seg"))       # codec_basic.py:288-298
     assert s.segment_length == 8000 and s.segment_stride == 7200
+    w = arch_from_config(recipe_config("ds320wn"))        # weight-normalised causal convs (conv.py:20-56,243-305)
+    assert w.norm == "weight_norm" and w.causal and a.norm == "time_group_norm" and not a.causal
+    from funcodec_amd.plan import expected_tensors
+    keys = expected_tensors(w)
+    assert keys["encoder.model.3.conv.conv.weight_g"] == (64, 1, 1) and keys["encoder.model.3.conv.conv.weight_v"] == (64, 32, 4)
+    assert keys["decoder.model.3.convtr.convtr.weight_g"] == (512, 1, 1)       # dim 0 of a ConvTranspose1d weight = IN channels
+    assert not any(k.endswith((".norm.weight", ".conv.weight", ".convtr.weight")) for k in keys)
 
 
 @pytest.mark.parametrize("mut", [
-    lambda c: c["encoder_conf"].update(norm="weight_norm"),
-    lambda c: c["encoder_conf"].update(causal=True),
+    lambda c: c["encoder_conf"].update(norm="weight_norm"),                     # encoder / decoder flavours differ
+    lambda c: (c["encoder_conf"].update(causal=True), c["decoder_conf"].update(causal=True)),   # GroupNorm + causal (conv.py:46-47)
+    lambda c: (c["encoder_conf"].update(norm="layer_norm"), c["decoder_conf"].update(norm="layer_norm")),
     lambda c: c.update(model="freqcodec"),
     lambda c: c["model_conf"].update(segment_dur=1.0, overlap_ratio=1.5),
     lambda c: c["quantizer_conf"].update(codec_dim=64),
