@@ -19,7 +19,7 @@ class FcArch(C.Structure):
         ("compress", C.c_int32), ("lstm_layers", C.c_int32), ("lstm_skip", C.c_int32),
         ("elu_alpha", C.c_float), ("gn_eps", C.c_float),
         ("codebook_size", C.c_int32), ("num_quantizers", C.c_int32),
-        ("norm_type", C.c_int32), ("causal", C.c_int32),
+        ("norm_type", C.c_int32), ("causal", C.c_int32), ("n_residual_layers", C.c_int32), ("dilation_base", C.c_int32),
     ]
 
 

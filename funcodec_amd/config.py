@@ -118,9 +118,8 @@ def _check_seanet_conf(conf: Dict[str, Any], which: str) -> Dict[str, Any]:
     seq_model = conf.get("seq_model", "lstm")
     if seq_model not in ("lstm", None, "none", "None"):
         raise _unsupported(f"{which}.seq_model", seq_model)
-    if conf.get("n_residual_layers", 1) != 1:
-        raise _unsupported(f"{which}.n_residual_layers", conf["n_residual_layers"],
-                           "dilated residual stacks are not built yet")
+    if not 1 <= int(conf.get("n_residual_layers", 1)) <= 8:
+        raise _unsupported(f"{which}.n_residual_layers", conf["n_residual_layers"])
     nk = dict(conf.get("norm_params", {}) or {})
     if nk.get("num_groups", 1) != 1:
         raise _unsupported(f"{which}.norm_params.num_groups", nk["num_groups"])
@@ -180,7 +179,7 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         kernel_size=int(shared("kernel_size", 7)),
         last_kernel_size=int(shared("last_kernel_size", 7)),
         residual_kernel_size=int(shared("residual_kernel_size", 3)),
-        n_residual_layers=1,
+        n_residual_layers=int(shared("n_residual_layers", 1)),
         dilation_base=int(shared("dilation_base", 2)),
         compress=int(shared("compress", 2)),
         lstm_layers=int(shared("seq_layer_num", 2)) if seq_model == "lstm" else 0,
@@ -213,6 +212,15 @@ def recipe_config(name: str) -> Dict[str, Any]:
         cfg = recipe_config("ds320")
         cfg["model_conf"]["segment_dur"] = 0.5
         cfg["model_conf"]["overlap_ratio"] = 0.1
+        return cfg
+    if name in ("ss320", "tinyss"):
+        # egs/LibriTTS/codec/conf/soundstream_16k_n32_600k_step.yaml:11-38: weight-normalised causal convs, three residual
+        # blocks per stage with dilations 1, 2, 4, no sequence model, 512-dim codebooks ("tinyss": the same shape, small)
+        cfg = recipe_config("ds320wn" if name == "ss320" else "tinywn")
+        for k in ("encoder_conf", "decoder_conf"):
+            cfg[k]["n_residual_layers"] = 3
+            cfg[k]["seq_model"] = "none"
+        cfg["encoder_conf"]["dimension"] = 512 if name == "ss320" else 32
         return cfg
     if name in ("ds320wn", "tinywn"):   # weight-normalised, causal variants of the same nets (EnCodec-style streaming convs)
         cfg = recipe_config("ds320" if name == "ds320wn" else "tiny")

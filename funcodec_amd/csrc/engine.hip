@@ -40,7 +40,7 @@ struct DevBuf {
 struct ConvLayer {
     std::string prefix;     // e.g. "encoder.model.3.conv" / "decoder.model.3.convtr"
     bool transposed = false;
-    int cin = 0, cout = 0, k = 1, stride = 1;
+    int cin = 0, cout = 0, k = 1, stride = 1, dil = 1;
     bool has_norm = true;   // GroupNorm(1, cout) after the conv
     bool wnorm = false;     // checkpoint stores weight_g / weight_v (torch.nn.utils.weight_norm)
     bool causal = false;
@@ -110,7 +110,8 @@ struct fc_engine {
     std::map<std::string, HostTensor> host;
     // plan
     ConvLayer enc_first, enc_last, dec_first, dec_last;
-    struct Stage { ConvLayer shortcut, block1, block3, resample; };       // resample = down (enc) / up (dec)
+    struct ResBlock { ConvLayer shortcut, block1, block3; };              // SEANetResnetBlock: shortcut(x) + block(x)
+    struct Stage { std::vector<ResBlock> res; ConvLayer resample; };      // n_residual_layers blocks; resample = down (enc) / up (dec)
     std::vector<Stage> enc_stages, dec_stages;
     LstmBlock enc_lstm, dec_lstm;
     std::map<std::string, ConvLayer*> by_prefix;
@@ -180,18 +181,18 @@ void add_conv_expect(fc_engine* e, ConvLayer& L) {
 void choose_tiling(ConvLayer& L);
 
 ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed = false,
-                  bool dual = false, bool small_n = false);
-ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n);
-ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n) {
-    ConvLayer L = mk_conv_(prefix, cin, cout, k, stride, transposed, dual, small_n);
+                  bool dual = false, bool small_n = false, int dil = 1);
+ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n, int dil);
+ConvLayer mk_conv(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n, int dil) {
+    ConvLayer L = mk_conv_(prefix, cin, cout, k, stride, transposed, dual, small_n, dil);
     if (getenv("FC_DUMP_PLAN"))     // tuning aid: the tiling every layer gets
         fprintf(stderr, "plan %-36s cin=%4d M=%4d k=%2d s=%d  tile %3dx%3d CC=%2d nchunk=%3d %s\n", L.prefix.c_str(), L.cin, L.M,
                 L.gk, L.gstride, L.BM, L.BN, L.CC, L.nchunk, L.row ? "row" : "");
     return L;
 }
-ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n) {
+ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stride, bool transposed, bool dual, bool small_n, int dil) {
     ConvLayer L;
-    L.prefix = prefix; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.transposed = transposed;
+    L.prefix = prefix; L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.transposed = transposed; L.dil = dil;
     L.dual = dual; L.small_n = small_n;
     if (!transposed) { L.M = cout; L.gk = k; L.gstride = stride; }
     else { L.M = cout * stride; L.gk = 2; L.gstride = 1; }   // 2-tap GEMM over the r output phases
@@ -201,7 +202,7 @@ ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stri
 
 void build_plan(fc_engine* e) {
     const fc_arch& a = e->arch;
-    const int nf = a.n_filters;
+    const int nf = a.n_filters, nres = a.n_residual_layers;
     auto name = [](const char* side, int idx, const char* suffix) {
         return std::string(side) + ".model." + std::to_string(idx) + suffix;
     };
@@ -214,10 +215,15 @@ void build_plan(fc_engine* e) {
         const int ratio = a.ratios[a.n_ratios - 1 - s];
         const int c = mult * nf, hid = c / a.compress;
         auto& S = e->enc_stages[s];
-        S.shortcut = mk_conv(name("encoder", idx, ".shortcut.conv"), c, c, 1, 1);
-        S.block1 = mk_conv(name("encoder", idx, ".block.1.conv"), c, hid, a.residual_kernel_size, 1);
-        S.block3 = mk_conv(name("encoder", idx, ".block.3.conv"), hid, c, 1, 1);
-        idx += 2;
+        S.res.resize(nres);
+        for (int j = 0, dil = 1; j < nres; ++j, dil *= a.dilation_base) {      // dilations [dilation_base**j, 1] (seanet_encoder.py:127-133)
+            auto& R = S.res[j];
+            R.shortcut = mk_conv(name("encoder", idx, ".shortcut.conv"), c, c, 1, 1, false, j > 0);
+            R.block1 = mk_conv(name("encoder", idx, ".block.1.conv"), c, hid, a.residual_kernel_size, 1, false, j > 0, false, dil);
+            R.block3 = mk_conv(name("encoder", idx, ".block.3.conv"), hid, c, 1, 1);
+            idx++;
+        }
+        idx++;                                                                    // ELU
         S.resample = mk_conv(name("encoder", idx, ".conv"), c, 2 * c, 2 * ratio, ratio, false, true);
         idx++;
         mult *= 2;
@@ -249,10 +255,14 @@ void build_plan(fc_engine* e) {
         idx++;
         S.resample = mk_conv(name("decoder", idx, ".convtr"), c, c2, 2 * ratio, ratio, true, s > 0 || skip_dual, s == 0);
         idx++;
-        S.shortcut = mk_conv(name("decoder", idx, ".shortcut.conv"), c2, c2, 1, 1);
-        S.block1 = mk_conv(name("decoder", idx, ".block.1.conv"), c2, hid, a.residual_kernel_size, 1);
-        S.block3 = mk_conv(name("decoder", idx, ".block.3.conv"), hid, c2, 1, 1);
-        idx++;
+        S.res.resize(nres);
+        for (int j = 0, dil = 1; j < nres; ++j, dil *= a.dilation_base) {
+            auto& R = S.res[j];
+            R.shortcut = mk_conv(name("decoder", idx, ".shortcut.conv"), c2, c2, 1, 1, false, j > 0);
+            R.block1 = mk_conv(name("decoder", idx, ".block.1.conv"), c2, hid, a.residual_kernel_size, 1, false, j > 0, false, dil);
+            R.block3 = mk_conv(name("decoder", idx, ".block.3.conv"), hid, c2, 1, 1);
+            idx++;
+        }
         mult /= 2;
     }
     idx++;
@@ -261,8 +271,11 @@ void build_plan(fc_engine* e) {
     // ---- conv wrapper flavour of every SConv1d / SConvTranspose1d of the nets (conv.py:20-56)
     {
         std::vector<ConvLayer*> all = {&e->enc_first, &e->enc_last, &e->dec_first, &e->dec_last};
-        for (auto& S : e->enc_stages) { all.push_back(&S.shortcut); all.push_back(&S.block1); all.push_back(&S.block3); all.push_back(&S.resample); }
-        for (auto& S : e->dec_stages) { all.push_back(&S.shortcut); all.push_back(&S.block1); all.push_back(&S.block3); all.push_back(&S.resample); }
+        for (auto* st : {&e->enc_stages, &e->dec_stages})
+            for (auto& S : *st) {
+                for (auto& R : S.res) { all.push_back(&R.shortcut); all.push_back(&R.block1); all.push_back(&R.block3); }
+                all.push_back(&S.resample);
+            }
         for (ConvLayer* L : all) {
             L->has_norm = a.norm_type == 0;
             L->wnorm = a.norm_type == 1;
@@ -272,7 +285,7 @@ void build_plan(fc_engine* e) {
     // ---- checkpoint contract, in execution order
     add_conv_expect(e, e->enc_first);
     for (auto& S : e->enc_stages) {
-        add_conv_expect(e, S.shortcut); add_conv_expect(e, S.block1); add_conv_expect(e, S.block3);
+        for (auto& R : S.res) { add_conv_expect(e, R.shortcut); add_conv_expect(e, R.block1); add_conv_expect(e, R.block3); }
         add_conv_expect(e, S.resample);
     }
     auto add_lstm = [&](LstmBlock& lb) {
@@ -295,7 +308,7 @@ void build_plan(fc_engine* e) {
     add_lstm(e->dec_lstm);
     for (auto& S : e->dec_stages) {
         add_conv_expect(e, S.resample);
-        add_conv_expect(e, S.shortcut); add_conv_expect(e, S.block1); add_conv_expect(e, S.block3);
+        for (auto& R : S.res) { add_conv_expect(e, R.shortcut); add_conv_expect(e, R.block1); add_conv_expect(e, R.block3); }
     }
     add_conv_expect(e, e->dec_last);
     e->expected.push_back({"quantizer.rq.model.embed", {a.num_quantizers, a.codebook_size, a.dimension}});
@@ -319,8 +332,8 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     for (;;) {
         const int n = cc * 2;
         if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
-        if (!fc::conv_slab_fits(L.gk, L.gstride, n, L.BN, L.BM, dual_eff)) break;
-        if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 0) >
+        if (!fc::conv_slab_fits(L.gk, L.gstride, L.dil, n, L.BN, L.BM, dual_eff)) break;
+        if (fc::conv_lds_bytes_for(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 0) >
             (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) break;
         cc = n;
     }
@@ -331,8 +344,8 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     if (row_env && L.gstride == 1) {
         int best = 0;
         for (int n = 4; n <= 64 && n <= L.cin; n *= 2) {
-            if (!fc::conv_row_ok(L.gk, L.gstride, n, L.BM, L.BN, L.cin, dual_eff)) continue;
-            if (fc::conv_lds_bytes_for(L.gk, L.gstride, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 1) >
+            if (!fc::conv_row_ok(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, dual_eff)) continue;
+            if (fc::conv_lds_bytes_for(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 1) >
                 (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) continue;
             best = n;
         }
@@ -375,7 +388,7 @@ int pack_gemm(fc_engine* e, ConvLayer& L, const std::vector<float>& wg /*[M][cin
     for (int m = 0; m < L.M; ++m) bpad[m] = bg[m];
     if (upload(e, packed, &L.wt)) return 1;
     if (upload(e, bpad, &L.bias)) return 1;
-    if (upload(e, fc::conv_koff_table(L.gk, L.gstride, L.CC, L.BN, L.row ? 1 : 0), &L.koff)) return 1;
+    if (upload(e, fc::conv_koff_table(L.gk, L.gstride, L.dil, L.CC, L.BN, L.row ? 1 : 0), &L.koff)) return 1;
     return 0;
 }
 
@@ -471,14 +484,16 @@ struct ConvGeom { int Tout, padL, padR, count_T; };
 ConvGeom conv_geom(const ConvLayer& L, int T) {
     ConvGeom g;
     if (!L.transposed) {
-        const int pt = (L.k - 1) - (L.stride - 1);
+        const int pt = (L.k - 1) * L.dil - (L.stride - 1);      // padding_total (conv.py:247)
         const int num = T - L.k + pt;
         const int nfr = num >= 0 ? ceil_div_i(num, L.stride) : -((-num) / L.stride);   // ceil(n_frames) - 1
         const int ideal = nfr * L.stride + (L.k - pt);
         const int extra = ideal - T;
         if (L.causal) { g.padL = pt; g.padR = extra; }          // all fixed padding on the left (conv.py:249-251)
         else { g.padR = pt / 2 + extra; g.padL = pt - pt / 2; }
-        g.Tout = nfr + 1;
+        // what nn.Conv1d then produces on the padded input (the reference's frame formula above ignores dilation; with
+        // dilation 1 this equals nfr + 1)
+        g.Tout = (T + g.padL + g.padR - ((L.k - 1) * L.dil + 1)) / L.stride + 1;
         g.count_T = g.Tout;
     } else {
         g.padL = 1; g.padR = 1;
@@ -510,7 +525,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     c.s0 = s0; c.s1 = s1; c.elu = elu; c.alpha = e->arch.elu_alpha;
     c.wt = L.wt; c.bias = L.bias; c.koff = L.koff;
     c.B = cx.B; c.Cin = L.cin; c.Tin = Tin; c.M = L.M;
-    c.k = L.gk; c.stride = L.gstride; c.padL = g.padL; c.padR = g.padR;
+    c.k = L.gk; c.stride = L.gstride; c.dil = L.dil; c.padL = g.padL; c.padR = g.padR;
     c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
     c.w_plain = L.w_plain; c.bias_host0 = L.bias0;
     Act out;
@@ -606,10 +621,14 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
 }
 
 // SEANetResnetBlock (seanet_encoder.py:16-61): returns the two raw branches whose GroupNorm'd sum is the output
-void run_resblock(fc_engine* e, Ctx& cx, const fc_engine::Stage& S, const Act& x, Act* sc, Act* b3) {
-    *sc = run_conv(e, cx, S.shortcut, src_of(x), fc::Src(), 0, x.T);
-    Act b1 = run_conv(e, cx, S.block1, src_of(x), fc::Src(), 1, x.T);
-    *b3 = run_conv(e, cx, S.block3, src_of(b1), fc::Src(), 1, b1.T);
+// The block's input is one tensor (first block of a stage) or the pending sum of the previous block's two branches.
+void run_resblocks(fc_engine* e, Ctx& cx, const fc_engine::Stage& S, fc::Src a0, fc::Src a1, int T, Act* sc, Act* b3) {
+    for (const auto& R : S.res) {
+        *sc = run_conv(e, cx, R.shortcut, a0, a1, 0, T);
+        Act b1 = run_conv(e, cx, R.block1, a0, a1, 1, T);
+        *b3 = run_conv(e, cx, R.block3, src_of(b1), fc::Src(), 1, b1.T);
+        a0 = src_of(*sc); a1 = src_of(*b3);
+    }
 }
 
 // SEANetEncoder.forward: wav [B][T] (optionally divided by scale[b]) -> last conv (raw + affine), T -> Tf
@@ -618,7 +637,7 @@ Act run_encoder(fc_engine* e, Ctx& cx, const float* wav, int T, const float* sca
     Act x = run_conv(e, cx, e->enc_first, s, fc::Src(), 0, T);
     for (auto& S : e->enc_stages) {
         Act sc, b3;
-        run_resblock(e, cx, S, x, &sc, &b3);
+        run_resblocks(e, cx, S, src_of(x), fc::Src(), x.T, &sc, &b3);
         x = run_conv(e, cx, S.resample, src_of(sc), src_of(b3), 1, sc.T);
     }
     if (e->enc_lstm.H) {
@@ -643,7 +662,7 @@ Act run_decoder(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf) {
     for (auto& S : e->dec_stages) {
         Act up = run_conv(e, cx, S.resample, a0, a1, 1, T);
         Act sc, b3;
-        run_resblock(e, cx, S, up, &sc, &b3);
+        run_resblocks(e, cx, S, src_of(up), fc::Src(), up.T, &sc, &b3);
         a0 = src_of(sc); a1 = src_of(b3);
         T = up.T;
     }
@@ -686,7 +705,7 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
         ProfSpan sp(e, cx, e->profiling ? e->prof_class(kRvqClass) : 0, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D, 0.0);
         if (fc::launch_rvq_encode(emb, B * Tf, D, e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quantized, qbdt,
                                   sub_quants, Tf, cx.st) != hipSuccess)
-            return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256})");
+            return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256,512})");
     }
     if (quant_bdt_out) *quant_bdt_out = qbdt;
     return cx.err;
@@ -727,13 +746,15 @@ const char* fc_last_error(void) { return g_err.c_str(); }
 int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (!arch || !out) return fail("null argument");
     if (arch->abi_version != FC_ABI_VERSION) return fail("fc_arch.abi_version mismatch");
+    if (arch->n_residual_layers < 1 || arch->n_residual_layers > 8 || arch->dilation_base < 1)
+        return fail("fc_arch.n_residual_layers must be in 1..8 and dilation_base >= 1");
     if (arch->norm_type < 0 || arch->norm_type > 2) return fail("fc_arch.norm_type must be 0 (GroupNorm), 1 (weight_norm) or 2 (none)");
     if (arch->norm_type == 0 && arch->causal) return fail("GroupNorm convs cannot be causal (the reference refuses it too, conv.py:46-47)");
     if (arch->n_ratios < 1 || arch->n_ratios > FC_MAX_RATIOS) return fail("n_ratios out of range");
     if (arch->compress < 1 || arch->n_filters < 2 || (arch->n_filters % arch->compress) != 0) return fail("bad n_filters/compress");
     if (arch->n_filters % 2) return fail("n_filters must be even");
     const int D = arch->dimension;
-    if (!(D == 16 || D == 32 || D == 64 || D == 128 || D == 256)) return fail("dimension must be one of 16/32/64/128/256");
+    if (!(D == 16 || D == 32 || D == 64 || D == 128 || D == 256 || D == 512)) return fail("dimension must be one of 16/32/64/128/256/512");
     if (arch->codebook_size % 64) return fail("codebook_size must be a multiple of 64");
     if (arch->lstm_layers > 0 && ((arch->n_filters << arch->n_ratios) % 16)) return fail("LSTM width must be a multiple of 16");
     if (arch->lstm_layers > FC_LSTM_MAX_LAYERS) return fail("too many LSTM layers");
@@ -822,8 +843,11 @@ int fc_engine_finalize(fc_engine* e) {
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         return fail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     std::vector<ConvLayer*> convs = {&e->enc_first, &e->enc_last, &e->dec_first, &e->dec_last};
-    for (auto& S : e->enc_stages) { convs.push_back(&S.shortcut); convs.push_back(&S.block1); convs.push_back(&S.block3); convs.push_back(&S.resample); }
-    for (auto& S : e->dec_stages) { convs.push_back(&S.shortcut); convs.push_back(&S.block1); convs.push_back(&S.block3); convs.push_back(&S.resample); }
+    for (auto* st : {&e->enc_stages, &e->dec_stages})
+        for (auto& S : *st) {
+            for (auto& R : S.res) { convs.push_back(&R.shortcut); convs.push_back(&R.block1); convs.push_back(&R.block3); }
+            convs.push_back(&S.resample);
+        }
     for (ConvLayer* L : convs)
         if (pack_conv(e, *L)) return 1;
     if (pack_lstm(e, e->enc_lstm)) return 1;

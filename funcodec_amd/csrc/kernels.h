@@ -28,6 +28,7 @@ struct ConvLaunch {
     int M = 0;                    // real GEMM rows (Cout, or Cout*r for transposed conv)
     int Tout = 0;                 // GEMM columns per utterance
     int k = 1, stride = 1, padL = 0, padR = 0;   // padR includes the reference's "extra" padding
+    int dil = 1;                  // tap spacing (dilated residual convs; 1 elsewhere)
     int pad_zero = 0;             // 0 reflect (pad1d), 1 zeros
     int up_r = 0, trimL = 0, Tfinal = 0;          // transposed-conv scatter epilogue when up_r > 0
     double* partials = nullptr;   // [B][nblk][2] (sum, sumsq) or null
@@ -41,11 +42,11 @@ int conv_nblk(const ConvLaunch& c);                         // stat partials per
 bool conv_cout1_ok(const ConvLaunch& c);                    // launch_conv() will take the single-output-channel FMA kernel
 size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
-size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab, int row);
-bool conv_row_ok(int k, int stride, int CC, int BM, int BN, int Cin, bool dual);   // row staging usable with this chunking?
-bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual);
+size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row);
+bool conv_row_ok(int k, int stride, int dil, int CC, int BM, int BN, int Cin, bool dual);   // row staging usable with this chunking?
+bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dual);
 int conv_wgs_per_cu(int BM);
-std::vector<int> conv_koff_table(int k, int stride, int CC, int BN, int row);
+std::vector<int> conv_koff_table(int k, int stride, int dil, int CC, int BN, int row);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
 void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row);    // template instantiation launch_conv() picks
 

@@ -48,6 +48,7 @@ struct ConvArgs {
     double* partials;
     long long out_sB, out_sM, out_sT;
     int B, Cin, Tin, M, Tout, k, stride, padL, padR, pad_zero, Leff;
+    int dil;                // tap spacing: tap kk reads slab column n*stride + kk*dil
     int up_r, trimL, Tfinal;
     unsigned magic_r;       // ceil(2^32 / up_r)
     int elu; float alpha;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             const unsigned slot0 = 4u * (unsigned)(rsub * p.rowStride + 4 * c4);
             const unsigned lds_round = 4u * (unsigned)(RPR * p.rowStride);
             const size_t src_round = (size_t)RPR * p.Tin;  // floats between the rows of consecutive rounds
-            const int km1 = p.k - 1;
+            const int km1 = p.slabW - BN;                  // tail columns of a row: (k - 1) * dilation
             const bool has_tail = rtid < p.CC * km1;
             const int t_cl = has_tail ? rtid / km1 : 0, t_j = has_tail ? rtid - t_cl * km1 : 0;
             const unsigned t_slot = 4u * (unsigned)(t_cl * p.rowStride + BN + t_j);
@@ -728,6 +729,7 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.out_sB = c.out_sB; a.out_sM = c.out_sM; a.out_sT = c.out_sT;
     a.B = c.B; a.Cin = c.Cin; a.Tin = c.Tin; a.M = c.M; a.Tout = c.Tout;
     a.k = c.k; a.stride = c.stride; a.padL = c.padL; a.padR = c.padR; a.pad_zero = c.pad_zero;
+    a.dil = c.dil;
     const int maxpad = c.padL > c.padR ? c.padL : c.padR;
     a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
     a.up_r = c.up_r; a.trimL = c.trimL; a.Tfinal = c.Tfinal;
@@ -735,7 +737,7 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.elu = c.elu; a.alpha = c.alpha;
     a.CC = c.CC; a.nchunk = c.nchunk; a.Kc = c.k * c.CC;
     a.Wbuf = conv_wbuf_floats(c.k, c.CC, c.BM);
-    a.slabW = (c.BN - 1) * c.stride + c.k;
+    a.slabW = (c.BN - 1) * c.stride + (c.k - 1) * c.dil + 1;
     a.PL = ceil_div(a.slabW, c.stride);
     a.rowStride = a.PL * c.stride;
     a.row = c.row;
@@ -752,15 +754,15 @@ static ConvArgs make_args(const ConvLaunch& c) {
 
 // B-operand LDS offset (floats) of every k-step of a chunk: k-step ks covers kidx = 2*ks + {0,1} = kk*CC + 2*c2 + {0,1}
 // -> offset = 2*c2*rowStride + (kk % stride)*PL + kk / stride.  Padded to a multiple of 4 entries.
-std::vector<int> conv_koff_table(int k, int stride, int CC, int BN, int row) {
-    const int slabW = (BN - 1) * stride + k;
+std::vector<int> conv_koff_table(int k, int stride, int dil, int CC, int BN, int row) {
+    const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     int PL = ceil_div(slabW, stride), rowStride = PL * stride;
     if (row) { rowStride = (slabW + 3) & ~3; PL = rowStride; }
     const int nks = k * CC / 2, half_cc = CC / 2;
     std::vector<int> t(conv_koff_len(k, CC), 0);
     for (int ks = 0; ks < nks; ++ks) {
-        const int kk = ks / half_cc, c2 = ks % half_cc;
-        t[ks] = 2 * c2 * rowStride + (kk % stride) * PL + kk / stride;
+        const int kk = ks / half_cc, c2 = ks % half_cc, pos = kk * dil;   // slab column of tap kk relative to the output column
+        t[ks] = 2 * c2 * rowStride + (pos % stride) * PL + pos / stride;
     }
     return t;
 }
@@ -776,16 +778,16 @@ int conv_nblk(const ConvLaunch& c) {
 
 // Row staging (stride 1): rows per round = 4 waves x (64 lanes / (BN/4) lanes per row); the kernel holds at most 8
 // rounds of one source (4 of two) in registers.
-bool conv_row_ok(int k, int stride, int CC, int BM, int BN, int Cin, bool dual) {
+bool conv_row_ok(int k, int stride, int dil, int CC, int BM, int BN, int Cin, bool dual) {
     if (stride != 1 || (BN != 128 && BN != 256)) return false;
     const int rpr = 4 * (64 / (BN / 4));
     if (CC % rpr != 0 || Cin % CC != 0) return false;
     if (CC / rpr > (dual ? 4 : 8)) return false;
-    return CC * (k - 1) <= 256 && (size_t)conv_wbuf_floats(k, CC, BM) <= 8192;
+    return CC * (k - 1) * dil <= 256 && (size_t)conv_wbuf_floats(k, CC, BM) <= 8192;
 }
 
-size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, int ntab, int row) {
-    const int slabW = (BN - 1) * stride + k;
+size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row) {
+    const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int rowStride = row ? ((slabW + 3) & ~3) : ceil_div(slabW, stride) * stride;
     const int img = CC * rowStride;
     const int xs = row ? img + 4 : (img <= 8 * 256 ? 8 : 16) * 256 + 4;   // XSF of the variant the launcher will pick
@@ -797,8 +799,8 @@ size_t conv_lds_bytes_for(int k, int stride, int CC, int BM, int BN, int Cin, in
 // Every tiling runs two 512-thread workgroups per CU (128 VGPRs per wave).  Three workgroups of the 32-row tiles at 80
 // VGPRs forced the 8-element staging variant and therefore 4x smaller K chunks: measured slower (per-item overheads).
 int conv_wgs_per_cu(int) { return 2; }
-bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual) {
-    const int slabW = (BN - 1) * stride + k;
+bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dual) {
+    const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int img = CC * ceil_div(slabW, stride) * stride;
     if (dual && CC > 2) return img <= 8 * 256;      // two-source prologue: keep the low-register (NU = 8) variant
     return img <= SLAB_PER_THREAD * 256;
@@ -806,7 +808,7 @@ bool conv_slab_fits(int k, int stride, int CC, int BN, int BM, bool dual) {
 
 size_t conv_lds_bytes(const ConvLaunch& c) {
     const int ntab = c.s1.ptr ? 2 : ((c.s0.aff || c.s0.div || c.elu) ? 1 : 0);
-    return conv_lds_bytes_for(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, ntab, c.row);
+    return conv_lds_bytes_for(c.k, c.stride, c.dil, c.CC, c.BM, c.BN, c.Cin, ntab, c.row);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW>
@@ -855,8 +857,8 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const size_t lds = conv_lds_bytes(c);
     if (lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
     if (c.row) {
-        if (!conv_row_ok(c.k, c.stride, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr) || c.s0.div) return hipErrorInvalidValue;
-    } else if (c.CC * (ceil_div((c.BN - 1) * c.stride + c.k, c.stride) * c.stride) > SLAB_PER_THREAD * 256) {
+        if (!conv_row_ok(c.k, c.stride, c.dil, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr) || c.s0.div) return hipErrorInvalidValue;
+    } else if (c.CC * (ceil_div((c.BN - 1) * c.stride + (c.k - 1) * c.dil + 1, c.stride) * c.stride) > SLAB_PER_THREAD * 256) {
         return hipErrorInvalidValue;
     }
     // one resident wave of workgroups (2 per CU): each takes a contiguous range of N tiles
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
 }
 
 bool conv_cout1_ok(const ConvLaunch& c) {
-    return c.w_plain && c.M == 1 && c.stride == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
+    return c.w_plain && c.M == 1 && c.stride == 1 && c.dil == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
            (c.k == 7 || c.k == 3 || c.k == 5) && c.padL + c.padR == c.k - 1;
 }
 
@@ -1358,10 +1360,153 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
     }
 }
 
+// Wide codebooks (D = 512, the SoundStream recipe): same arithmetic and the same argmax / update flow as rvq_encode_kernel,
+// but a (row, code) chain is fed in chunks of 256 dims -- the 2x fragment of the row (re-read from LDS per chunk) and the two
+// in-flight codebook fragments then fit the register file -- and the running quantised sum lives in registers instead of LDS.
+template <int D>
+__global__ __launch_bounds__(512) void rvq_encode_wide_kernel(const float* __restrict__ x, int N, int K, int nq,
+                                                              const float* __restrict__ cb, const float* __restrict__ cbf,
+                                                              const float* __restrict__ enorm,
+                                                              int64_t* __restrict__ codes, float* __restrict__ quant,
+                                                              float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf) {
+    static_assert(D % 256 == 0, "chunks of 256 dims");
+    constexpr int NC = D / 256, CQ = 16, NEL = 16 * D / 512;
+    __shared__ __attribute__((aligned(16))) float R[16][D];
+    __shared__ float xn[16];
+    __shared__ float bestv[8][16];
+    __shared__ int besti[8][16];
+    __shared__ int sel[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, r16 = lane & 15;
+    const int row0 = blockIdx.x * 16;
+    float qreg[NEL];                                     // running sum of the selected code rows, element e = tid + 512*i
+#pragma unroll
+    for (int i2 = 0; i2 < NEL; ++i2) {
+        const int e = tid + 512 * i2, r = e / D, d = e - r * D, n = row0 + r;
+        R[r][d] = n < N ? x[(size_t)n * D + d] : 0.f;
+        qreg[i2] = 0.f;
+    }
+    const int codes_per_wave = (K >> 3) < 16 ? 16 : (K >> 3);
+    const bool wactive = wid * codes_per_wave < K;
+    const int ntile = wactive ? codes_per_wave >> 4 : 0, nunit = ntile * NC;
+    const int code0 = wid * codes_per_wave;
+    for (int i = 0; i < nq; ++i) {
+        __syncthreads();
+        if (tid < 64) {   // |x|^2, same chains as the narrow kernel
+            const int r = tid >> 2, j = tid & 3;
+            float s = 0.f;
+#pragma unroll 8
+            for (int d = j * (D / 4); d < (j + 1) * (D / 4); ++d) {
+                const float v = R[r][d];
+                s = __fadd_rn(s, __fmul_rn(v, v));
+            }
+            const float s_pair = __fadd_rn(s, __shfl_xor(s, 1, 64));
+            const float s_all = __fadd_rn(s_pair, __shfl_xor(s_pair, 2, 64));
+            if (j == 0) xn[r] = s_all;
+        }
+        __syncthreads();
+        float best[4], xr[4];
+        int bidx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { best[r] = -INFINITY; bidx[r] = 0x7fffffff; xr[r] = xn[4 * g + r]; }
+        const float* cbi = cb + (size_t)i * K * D;
+        auto load_unit = [&](int u, f32x4 (&bq)[CQ]) __attribute__((always_inline)) {
+            const int t = u / NC, c = u - t * NC, code = code0 + 16 * t;
+            const float* e0 = cbf ? cbf + ((size_t)i * K + code) * D + (size_t)c * CQ * 256 + lane * 4
+                                  : cbi + (size_t)(code + r16) * D + 256 * c + 4 * g;
+            const int qstep = cbf ? 256 : 16;
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) bq[q] = *(const f32x4*)(e0 + qstep * q);
+        };
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        auto do_unit = [&](int u, const f32x4 (&bq)[CQ]) __attribute__((always_inline)) {
+            const int t = u / NC, c = u - t * NC, code = code0 + 16 * t + r16;
+            if (c == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < CQ; ++q) {
+                const f32x4 v = *(const f32x4*)&R[r16][256 * c + 16 * q + 4 * g];
+                const f32x4 a = v + v;                                  // 2*x, exact
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bq[q][j], acc, 0, 0, 0);
+            }
+            if (c == NC - 1) {
+                const float en = enorm[(size_t)i * K + code];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dist = -__fadd_rn(__fsub_rn(xr[r], acc[r]), en);
+                    if (dist > best[r]) { best[r] = dist; bidx[r] = code; }
+                }
+            }
+        };
+        if (nunit > 0) {
+            f32x4 b0[CQ], b1[CQ];
+            load_unit(0, b0);
+            int u = 0;
+            for (; u + 2 <= nunit; u += 2) {
+                load_unit(u + 1, b1);
+                do_unit(u, b0);
+                if (u + 2 < nunit) load_unit(u + 2, b0);
+                do_unit(u + 1, b1);
+            }
+            if (u < nunit) do_unit(u, b0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const float ov = __shfl_xor(best[r], o, 64);
+                const int oi = __shfl_xor(bidx[r], o, 64);
+                if (ov > best[r] || (ov == best[r] && oi < bidx[r])) { best[r] = ov; bidx[r] = oi; }
+            }
+            if (r16 == 0) { bestv[wid][4 * g + r] = best[r]; besti[wid][4 * g + r] = bidx[r]; }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            float bv = bestv[0][tid];
+            int bi = besti[0][tid];
+            for (int w = 1; w < 8; ++w) {
+                const float ov = bestv[w][tid];
+                const int oi = besti[w][tid];
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (bi < 0 || bi >= K) bi = 0;
+            sel[tid] = bi;
+            if (row0 + tid < N) codes[(size_t)i * N + row0 + tid] = (int64_t)bi;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i2 = 0; i2 < NEL; ++i2) {
+            const int e = tid + 512 * i2, r = e / D, d = e - r * D, n = row0 + r;
+            const float qv = cbi[(size_t)sel[r] * D + d];
+            R[r][d] = R[r][d] - qv;
+            qreg[i2] = qreg[i2] + qv;
+            if (subq && n < N) {
+                const int bb = n / Tf, t = n - bb * Tf, Bn = N / Tf;
+                subq[(((size_t)i * Bn + bb) * D + d) * Tf + t] = qv;
+            }
+        }
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < NEL; ++i2) {
+        const int e = tid + 512 * i2, r = e / D, d = e - r * D, n = row0 + r;
+        if (n >= N) continue;
+        if (quant) quant[(size_t)n * D + d] = qreg[i2];
+        if (quant_bdt) {
+            const int bb = n / Tf, t = n - bb * Tf;
+            quant_bdt[((size_t)bb * D + d) * Tf + t] = qreg[i2];
+        }
+    }
+}
+
 hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* cb_frag,
                              const float* enorm, int64_t* codes, float* quant, float* quant_bdt, float* subq, int Tf, hipStream_t st) {
     if (N <= 0) return hipSuccess;
     if (K % 16 != 0 || (K > 128 && K % 128 != 0)) return hipErrorInvalidValue;
+    if (D == 512) {
+        hipLaunchKernelGGL((rvq_encode_wide_kernel<512>), dim3(ceil_div(N, 16)), dim3(512), 0, st, x, N, K, nq, cb, cb_frag, enorm, codes,
+                           quant, quant_bdt, subq, Tf);
+        return hipGetLastError();
+    }
     // two row sets per workgroup once there are enough rows to keep ~half the CUs busy that way (L2 traffic halves)
     static const int ablate = getenv("FC_ABLATE_RVQ") ? atoi(getenv("FC_ABLATE_RVQ")) : 0;
     static const int two_env = getenv("FC_RVQ_TWO") ? atoi(getenv("FC_RVQ_TWO")) : 0;

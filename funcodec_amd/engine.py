@@ -76,6 +76,8 @@ class CodecEngine:
         a.num_quantizers = arch.num_quantizers
         a.norm_type = {"time_group_norm": 0, "weight_norm": 1, "none": 2}[arch.norm]
         a.causal = int(arch.causal)
+        a.n_residual_layers = arch.n_residual_layers
+        a.dilation_base = arch.dilation_base
         h = C.c_void_p()
         self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
         self._h = h

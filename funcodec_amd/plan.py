@@ -23,6 +23,7 @@ class ConvOp:
     k: int = 1
     stride: int = 1
     role: str = ""       # "first" | "shortcut" | "block1" | "block3" | "down" | "up" | "last" | "lstm"
+    dilation: int = 1
 
 
 def encoder_plan(a: ArchSpec) -> List[ConvOp]:
@@ -34,11 +35,12 @@ def encoder_plan(a: ArchSpec) -> List[ConvOp]:
     for ratio in reversed(a.ratios):
         c = mult * a.n_filters
         hid = c // a.compress
-        p = f"encoder.model.{idx}"
-        ops.append(ConvOp("conv", f"{p}.shortcut.conv", c, c, 1, 1, "shortcut"))
-        ops.append(ConvOp("conv", f"{p}.block.1.conv", c, hid, a.residual_kernel_size, 1, "block1"))
-        ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c, 1, 1, "block3"))
-        idx += 1          # resblock
+        for j in range(a.n_residual_layers):          # dilations [dilation_base**j, 1] (seanet_encoder.py:127-133)
+            p = f"encoder.model.{idx}"
+            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c, c, 1, 1, "shortcut"))
+            ops.append(ConvOp("conv", f"{p}.block.1.conv", c, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j))
+            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c, 1, 1, "block3"))
+            idx += 1      # resblock
         idx += 1          # ELU
         ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", c, 2 * c, 2 * ratio, ratio, "down"))
         idx += 1
@@ -69,11 +71,12 @@ def decoder_plan(a: ArchSpec) -> List[ConvOp]:
         idx += 1
         c2 = c // 2
         hid = c2 // a.compress
-        p = f"decoder.model.{idx}"
-        ops.append(ConvOp("conv", f"{p}.shortcut.conv", c2, c2, 1, 1, "shortcut"))
-        ops.append(ConvOp("conv", f"{p}.block.1.conv", c2, hid, a.residual_kernel_size, 1, "block1"))
-        ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c2, 1, 1, "block3"))
-        idx += 1
+        for j in range(a.n_residual_layers):
+            p = f"decoder.model.{idx}"
+            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c2, c2, 1, 1, "shortcut"))
+            ops.append(ConvOp("conv", f"{p}.block.1.conv", c2, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j))
+            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c2, 1, 1, "block3"))
+            idx += 1
         mult //= 2
     idx += 1              # ELU
     ops.append(ConvOp("conv", f"decoder.model.{idx}.conv", a.n_filters, a.input_channels, a.last_kernel_size, 1, "last"))

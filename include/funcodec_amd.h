@@ -57,6 +57,8 @@ typedef struct fc_arch {
     int32_t norm_type;              /* 0 = GroupNorm(1,C) after every conv ("time_group_norm"); 1 = weight_norm (checkpoint holds
                                        weight_g / weight_v, no output norm); 2 = none (plain weight, no output norm) */
     int32_t causal;                 /* 1: all conv padding on the left, transposed convs trimmed on the right only */
+    int32_t n_residual_layers;      /* residual blocks per stage (1 in the encodec recipes, 3 in the SoundStream recipe) */
+    int32_t dilation_base;          /* block j of a stage dilates its k=3 conv by dilation_base**j (seanet_encoder.py:127-133) */
 } fc_arch;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

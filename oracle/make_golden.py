@@ -43,6 +43,9 @@ CASES = [
     # weight-normalised causal convs (norm: weight_norm, causal: true; conv.py:20-56,243-305)
     ("tinywn_b2_t777", "tinywn", 9, 1.0, "tones", 51, 2, 777, None),
     ("ds320wn_b1_t12000", "ds320wn", 0, 1.0, "noise", 52, 1, 12000, None),
+    # the SoundStream recipe shape: + three residual blocks per stage (dilations 1, 2, 4), no LSTM, 512-dim codebooks
+    ("tinyss_b2_t600", "tinyss", 5, 1.0, "tones", 61, 2, 600, None),
+    ("ss320_b1_t8000", "ss320", 0, 1.0, "noise", 62, 1, 8000, None),
 ]
 
 

@@ -45,11 +45,11 @@ def pad1d_reflect(x: torch.Tensor, paddings: Tuple[int, int]) -> torch.Tensor:
     return padded[..., :end]
 
 
-def sconv1d(x, w, b, gamma, beta, stride: int, eps: float, causal: bool = False):
+def sconv1d(x, w, b, gamma, beta, stride: int, eps: float, causal: bool = False, dilation: int = 1):
     """SConv1d.forward conv.py:243-261 -> NormConv1d.forward :155-164 -> GroupNorm(1,C) :45-52 (gamma None: no output
     norm, i.e. norm = weight_norm / none)."""
     k = w.shape[-1]
-    padding_total = (k - 1) - (stride - 1)
+    padding_total = (k - 1) * dilation - (stride - 1)             # :247
     extra = get_extra_padding_for_conv1d(x.shape[-1], k, stride, padding_total)
     if causal:
         x = pad1d_reflect(x, (padding_total, extra))              # :249-251
@@ -57,7 +57,7 @@ def sconv1d(x, w, b, gamma, beta, stride: int, eps: float, causal: bool = False)
         pr = padding_total // 2
         pl = padding_total - pr
         x = pad1d_reflect(x, (pl, pr + extra))
-    y = F.conv1d(x, w, b, stride=stride)
+    y = F.conv1d(x, w, b, stride=stride, dilation=dilation)
     return y if gamma is None else F.group_norm(y, 1, gamma, beta, eps)
 
 
@@ -102,6 +102,8 @@ class Oracle:
         self.last_ksize = enc.get("last_kernel_size", 7)
         self.res_ksize = enc.get("residual_kernel_size", 3)
         self.compress = enc.get("compress", 2)
+        self.n_res = enc.get("n_residual_layers", 1)
+        self.dil_base = enc.get("dilation_base", 2)
         self.lstm_layers = enc.get("seq_layer_num", 2) if enc.get("seq_model", "lstm") == "lstm" else 0
         self.alpha = (enc.get("activation_params") or {"alpha": 1.0}).get("alpha", 1.0)
         self.eps = (enc.get("norm_params") or {}).get("eps", 1e-5)
@@ -126,16 +128,16 @@ class Oracle:
             return w, self.sd[f"{prefix}.{inner}.bias"], self.sd[f"{prefix}.norm.weight"], self.sd[f"{prefix}.norm.bias"]
         return w, self.sd[f"{prefix}.{inner}.bias"], None, None
 
-    def _conv(self, x, prefix, stride=1):
+    def _conv(self, x, prefix, stride=1, dilation=1):
         w, b, g, be = self._p(prefix)
-        return sconv1d(x, w, b, g, be, stride, self.eps, self.causal)
+        return sconv1d(x, w, b, g, be, stride, self.eps, self.causal, dilation)
 
     def _elu(self, x):
         return F.elu(x, self.alpha)                                  # activations.py:24-30
 
-    def _resblock(self, x, prefix):
+    def _resblock(self, x, prefix, dilation=1):
         """SEANetResnetBlock.forward seanet_encoder.py:60-61: shortcut(x) + block(x)."""
-        y = self._conv(self._elu(x), f"{prefix}.block.1.conv")
+        y = self._conv(self._elu(x), f"{prefix}.block.1.conv", dilation=dilation)
         y = self._conv(self._elu(y), f"{prefix}.block.3.conv")
         return self._conv(x, f"{prefix}.shortcut.conv") + y
 
@@ -161,8 +163,10 @@ class Oracle:
         x = self._conv(x, f"encoder.model.{idx}.conv")
         idx += 1
         for ratio in reversed(self.ratios):
-            x = self._resblock(x, f"encoder.model.{idx}")
-            idx += 2
+            for j in range(self.n_res):
+                x = self._resblock(x, f"encoder.model.{idx}", self.dil_base ** j)
+                idx += 1
+            idx += 1
             x = self._conv(self._elu(x), f"encoder.model.{idx}.conv", stride=ratio)
             idx += 1
         if self.lstm_layers > 0:
@@ -187,8 +191,9 @@ class Oracle:
             w, b, g, be = self._p(f"decoder.model.{idx}.convtr")
             x = sconvtr1d(self._elu(x), w, b, g, be, ratio, self.eps, self.causal)
             idx += 1
-            x = self._resblock(x, f"decoder.model.{idx}")
-            idx += 1
+            for j in range(self.n_res):
+                x = self._resblock(x, f"decoder.model.{idx}", self.dil_base ** j)
+                idx += 1
         idx += 1
         return self._conv(self._elu(x), f"decoder.model.{idx}.conv")
 

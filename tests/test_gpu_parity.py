@@ -184,16 +184,18 @@ def test_conv_padding_edge_lengths(T):
 
 
 def test_conv_layers_random_shape_sweep():
-    """Seeded sweep over (layer, batch, length, ELU) of both real recipes: lengths around the tile widths (127..129,
+    """Seeded sweep over (layer, batch, length, ELU) of the real recipes (GroupNorm, weight-norm causal, SoundStream shape): lengths around the tile widths (127..129,
     255..257, 1023..1025), tiny lengths, primes; every staging scheme (element / row / single-output-channel kernel), edge-
     only and interior tiles, strided and transposed layers.  Reference = the torch restatement of SConv1d / SConvTranspose1d."""
     import torch_oracle as TO
     rng = np.random.Generator(np.random.PCG64(2024))
     lengths = [1, 2, 5, 17, 63, 127, 128, 129, 255, 256, 257, 511, 640, 1023, 1024, 1025, 1531, 2053]
-    for cfg_name in ("ds320", "ds640", "ds320wn"):
+    from funcodec_amd.plan import decoder_plan, encoder_plan
+    for cfg_name in ("ds320", "ds640", "ds320wn", "ss320"):
         m = engine_for(cfg_name, 0)
         orc = oracle_for(cfg_name, 0)
         layers = _layer_cases(cfg_name, 0)
+        dil = {op.key: op.dilation for op in encoder_plan(m.arch) + decoder_plan(m.arch)}
         for _ in range(36):
             p = layers[int(rng.integers(len(layers)))]
             tr = p.endswith("convtr")
@@ -209,7 +211,7 @@ def test_conv_layers_random_shape_sweep():
             if tr:
                 ref = TO.sconvtr1d(xin, *orc._p(p), k // 2, orc.eps, orc.causal)
             else:
-                ref = TO.sconv1d(xin, *orc._p(p), (k // 2 if (k % 2 == 0 and k > 1) else 1), orc.eps, orc.causal)
+                ref = TO.sconv1d(xin, *orc._p(p), (k // 2 if (k % 2 == 0 and k > 1) else 1), orc.eps, orc.causal, dil[p])
             got = m.engine.layer_forward(p, x, apply_elu=elu).cpu()
             assert got.shape == ref.shape, (cfg_name, p, B, T, got.shape, ref.shape)
             # GroupNorm over very few elements (short T) amplifies rounding: tolerance as in the padding edge test
