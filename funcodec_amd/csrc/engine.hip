@@ -575,7 +575,8 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
         ProfSpan sp(e, cx, cls, fl, by);
         er = fc::launch_conv(c, cx.st);
     }
-    if (er != hipSuccess) { cx.err = 1; g_err = "conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); return out; }
+    if (er != hipSuccess) { cx.err = 1; g_err = "conv launch failed (" + L.prefix + "): " + hipGetErrorString(er) +
+                " (invalid value = tiling / LDS limits, or an utterance longer than 2^32 / (4 * channels per chunk) samples)"; return out; }
     if (L.has_norm) {
         er = fc::launch_gn_finalize(c.partials, nblk, (double)L.cout * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps,
                                     cx.B, out.aff, cx.st);

@@ -856,6 +856,8 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     const ConvArgs a = make_args(c);
     const size_t lds = conv_lds_bytes(c);
     if (lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
+    // the staging waves address a chunk's rows with 32-bit byte offsets from a per-chunk base
+    if ((unsigned long long)c.CC * (unsigned long long)c.Tin * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
     if (c.row) {
         if (!conv_row_ok(c.k, c.stride, c.dil, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr) || c.s0.div) return hipErrorInvalidValue;
     } else if (c.CC * (ceil_div((c.BN - 1) * c.stride + (c.k - 1) * c.dil + 1, c.stride) * c.stride) > SLAB_PER_THREAD * 256) {
