@@ -160,3 +160,18 @@ def test_shard_range_partitions_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_fc_arch_layout_is_the_same_in_header_binding_and_integration_doc():
+    """ABI drift guard: the field list of struct fc_arch in include/funcodec_amd.h, the ctypes mirror in
+    funcodec_amd/_lib.py and the stub shown to reference maintainers in INTEGRATION.md must agree name for name."""
+    hdr = open(os.path.join(ROOT, "include", "funcodec_amd.h")).read()
+    body = hdr[hdr.index("typedef struct fc_arch {"):hdr.index("} fc_arch;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = re.findall(r"\b(?:int32_t|float)\s+([a-z_0-9]+)\s*(?:\[[A-Z_]+\])?\s*;", body)
+    py_fields = [f[0] for f in _lib.FcArch._fields_]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    doc_struct = doc[doc.index("class FcArch(C.Structure)"):doc.index("lib = C.CDLL")]
+    doc_fields = re.findall(r'\("([a-z_0-9]+)",\s*C\.', doc_struct)
+    assert c_fields == py_fields == doc_fields, (c_fields, py_fields, doc_fields)
+    assert f"abi_version={_lib.FC_ABI_VERSION}" in doc and f"#define FC_ABI_VERSION {_lib.FC_ABI_VERSION}" in hdr
