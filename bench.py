@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 UTTS_PER_GPU = 16
 SAMPLES = 160000
-CONFIG = "ds640"
+CONFIG = os.environ.get("FC_BENCH_CONFIG", "ds640")   # the contract metric is ds640; other recipes only for side measurements
 PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix (= vector) peak
 PEAK_HBM_TBS = 8.0
 
@@ -158,7 +158,8 @@ def main():
         audio_s = total_utts * SAMPLES / 16000.0 * args.steps
         work = eng.work(UTTS_PER_GPU, SAMPLES, n_q)
         out = {
-            "metric": "audio-seconds encoded+decoded per wall-sec, 16k-nq32ds640",
+            "metric": "audio-seconds encoded+decoded per wall-sec, 16k-nq32ds640" if CONFIG == "ds640" else
+                      f"audio-seconds encoded+decoded per wall-sec, recipe {CONFIG} (side measurement, not the contract metric)",
             "value": round(audio_s / dt, 2), "unit": "audio-s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
