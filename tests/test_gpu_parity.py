@@ -562,3 +562,44 @@ def test_cli_encoding_decoding_pipeline(tmp_path):
         ref = orc.decode_codes(tok)[0][0, 0].numpy()
         ref = ref * min(0.99 / np.abs(ref).max(), 1.0)
         assert y.shape == ref.shape and np.abs(y - ref).max() < 2.0 / 32768
+
+
+def test_boundary_error_behaviour():
+    """The reference raises Python exceptions / asserts at its boundary (assert x.dim() == 3, channels <= 2, codec_basic.py:
+    342-344); the C ABI reports a status + fc_last_error() and never corrupts: bad sizes, n_q out of range, a workspace that
+    is too small, an engine that was never given its weights, out-of-range code indices on the decode path (clamped)."""
+    import ctypes as C
+    from funcodec_amd.engine import CodecEngine, EngineError
+    from funcodec_amd.config import arch_from_config, recipe_config
+    m = engine_for("ds320", 0)
+    eng = m.engine
+    wav = audio(2, 6400, 3, "tones").cuda()
+    with pytest.raises(EngineError, match="n_q out of range"):
+        eng.encode_decode(wav, 33)
+    with pytest.raises(EngineError, match="n_q out of range|bad argument"):   # an empty codes tensor is a null pointer
+        eng.encode_decode(wav, 0)
+    with pytest.raises(EngineError, match="bad argument"):
+        eng.encode_decode(wav[:, :0], 32)
+    with pytest.raises((AssertionError, NotImplementedError)):
+        m.inference(torch.zeros(1, 3, 100))                            # > 2 channels (codec_basic.py:344)
+    # workspace one byte short of what the engine asks for
+    need = eng.lib.fc_engine_workspace_bytes(eng._h, 2, 6400)
+    ws = torch.empty(need // 2, dtype=torch.uint8, device="cuda")
+    codes = torch.empty((32, 2, 20), dtype=torch.int64, device="cuda")
+    recon = torch.empty((2, 1, 6400), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = eng.lib.fc_encode_decode(eng._h, p(wav), 2, 6400, 32, 1, p(codes), None, None, None, p(recon), p(ws), ws.numel(),
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0 and b"workspace too small" in eng.lib.fc_last_error()
+    good = eng.encode_decode(wav, 32)                                  # and the engine is still usable afterwards
+    assert torch.isfinite(good["recon"]).all()
+    # an engine without weights refuses to run
+    raw = CodecEngine(arch_from_config(recipe_config("tiny")), "cuda:0")
+    with pytest.raises(EngineError, match="finalize|not finalized|weights"):
+        raw.encode_decode(wav, 2)
+    # decode of out-of-range indices: clamped like an index into the codebook must be, never an out-of-bounds read
+    tok = good["codes"].permute(1, 2, 0).contiguous().clone()
+    tok[0, 0, 0] = 99999
+    tok[0, 1, 1] = -5
+    w, _ = eng.decode_codes(tok)
+    assert torch.isfinite(w).all()
