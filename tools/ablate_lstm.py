@@ -11,7 +11,7 @@ from helpers import engine_for
 which = sys.argv[1] if len(sys.argv) > 1 else "encoder"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
-m = engine_for("ds640", 0)
+m = engine_for(os.environ.get("FC_CFG", "ds640"), 0)
 eng = m.engine
 H = eng.expected_tensors()[which + ".weight_hh_l0"][1]
 x = torch.randn(B, H, T, device="cuda")
