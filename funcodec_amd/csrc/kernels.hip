@@ -1100,6 +1100,47 @@ __global__ __launch_bounds__(256) void combine_kernel(Src s0, Src s1, int elu, f
     if (s0.aff) a0 = ((const float2*)s0.aff)[row];
     if (s1.ptr && s1.aff) a1 = ((const float2*)s1.aff)[row];
     const float m = mul ? mul[b] : 1.f;
+    if (o_sT == 1 && !s0.div) {
+        // contiguous output rows (every materialisation inside the engine): 4 samples per thread, 16-byte loads / stores
+        // (dword alignment only: rows start at row * Tsrc floats)
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        float* orow = out + (size_t)b * o_sB + (size_t)c * o_sC;
+        const float* r0 = s0.ptr + row * Tsrc;
+        const float* r1 = s1.ptr ? s1.ptr + row * Tsrc : r0;
+        const int T4 = Tcopy >> 2;
+        for (int q = blockIdx.x * 256 + threadIdx.x; q < T4; q += gridDim.x * 256) {
+            const f32x4 x0 = *(const f32x4u*)(r0 + 4 * q);
+            const f32x4 x1 = s1.ptr ? (f32x4)(*(const f32x4u*)(r1 + 4 * q)) : x0;
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = x0[j];
+                if (s0.aff) v = fmaf(v, a0.x, a0.y);
+                if (s1.ptr) {
+                    float w = x1[j];
+                    if (s1.aff) w = fmaf(w, a1.x, a1.y);
+                    v = v + w;
+                }
+                if (elu) v = elu_f(v, alpha);
+                if (mul) v = v * m;
+                y[j] = v;
+            }
+            *(f32x4u*)(orow + 4 * q) = y;
+        }
+        for (int t = 4 * T4 + blockIdx.x * 256 + threadIdx.x; t < Tcopy; t += gridDim.x * 256) {
+            float v = r0[t];
+            if (s0.aff) v = fmaf(v, a0.x, a0.y);
+            if (s1.ptr) {
+                float w = r1[t];
+                if (s1.aff) w = fmaf(w, a1.x, a1.y);
+                v = v + w;
+            }
+            if (elu) v = elu_f(v, alpha);
+            if (mul) v = v * m;
+            orow[t] = v;
+        }
+        return;
+    }
     for (int t = blockIdx.x * 256 + threadIdx.x; t < Tcopy; t += gridDim.x * 256) {
         float v = s0.ptr[row * Tsrc + t];
         if (s0.div) v = v / s0.div[b];
