@@ -7,7 +7,7 @@ import os
 from . import build as _build
 
 FC_MAX_RATIOS = 8
-FC_ABI_VERSION = 2
+FC_ABI_VERSION = 3
 
 
 class FcArch(C.Structure):
@@ -62,6 +62,8 @@ SYMBOLS = {
     "fc_engine_profile": (C.c_int, [_P, C.c_int]),
     "fc_engine_profile_read": (C.c_int, [_P, C.POINTER(FcProf)]),
     "fc_debug_timeline": (C.c_int, [_P]),
+    "fc_overlap_add": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "fc_engine_status": (C.c_int, [_P, C.POINTER(C.c_uint)]),
 }
 
 _lib = None

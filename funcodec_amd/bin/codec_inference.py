@@ -195,6 +195,9 @@ def inference_modelscope(
             bw = param_dict["bit_width"] if param_dict is not None and "bit_width" in param_dict else bit_width
             token_id, token_emb, recon_speech, sub_quants = my_model(**batch, need_recon=True, bit_width=bw,
                                                                      use_scale=use_scale, run_mod=run_mod)
+            # device-side failures cannot raise in-line like the reference's F.embedding / asserts do: synchronise and ask the
+            # engine before anything of this batch is written (corrupt token files, LSTM barrier timeout)
+            my_model.model.engine.check_status(sync=True)
             if should_resample and recon_speech is not None:                    # reference :352-356
                 recon_speech = fio.resample(recon_speech, sampling_rate, file_sr)
             for i, key in enumerate(keys):

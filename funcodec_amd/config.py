@@ -165,14 +165,19 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         raise _unsupported("quantizer_conf.codec_range", q["codec_range"])
     if q.get("q0_ds_ratio", 1) != 1:
         raise _unsupported("quantizer_conf.q0_ds_ratio", q["q0_ds_ratio"])
-    act_params = dict(enc.get("activation_params", {"alpha": 1.0}) or {})
-    norm_params = dict(enc.get("norm_params", {}) or {})
-    seq_model = enc.get("seq_model", "lstm")
+    # decoder_conf values that differ from encoder_conf are refused (shared()), never silently ignored
+    act_params = dict(shared("activation_params", {"alpha": 1.0}) or {})
+    norm_params = dict(shared("norm_params", {}) or {})
+    seq_model = shared("seq_model", "lstm")
+    # Encodec.__init__ defaults for keys an ESPnet-style config.yaml may omit (codec_basic.py:132-141):
+    # target_sample_hz=24000, audio_normalize=True, segment_dur=1.0, overlap_ratio=0.01.  An explicit null is kept.
+    segment_dur = m["segment_dur"] if "segment_dur" in m else 1.0
+    overlap_ratio = m["overlap_ratio"] if "overlap_ratio" in m else 0.01
     ratios = tuple(int(r) for r in shared("ratios", [8, 5, 4, 2]))
     arch = ArchSpec(
-        sample_rate=int(m.get("target_sample_hz", cfg.get("sampling_rate", 16000))),
+        sample_rate=int(m.get("target_sample_hz", 24000)),
         input_channels=1,
-        audio_normalize=bool(m.get("audio_normalize", False)),
+        audio_normalize=bool(m.get("audio_normalize", True)),
         n_filters=int(shared("n_filters", 32)),
         dimension=int(enc.get("dimension", 128)),
         ratios=ratios,
@@ -194,8 +199,8 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         use_ddp=bool(q.get("use_ddp", True)),
         norm=str(shared("norm", "weight_norm")),
         causal=bool(shared("causal", False)),
-        segment_dur=None if m.get("segment_dur", None) is None else float(m["segment_dur"]),
-        overlap_ratio=0.01 if m.get("overlap_ratio", None) is None else float(m["overlap_ratio"]),
+        segment_dur=None if segment_dur is None else float(segment_dur),
+        overlap_ratio=0.01 if overlap_ratio is None else float(overlap_ratio),
     )
     if arch.segment_dur is not None and not (arch.segment_dur > 0 and 0 <= arch.overlap_ratio < 1):
         raise _unsupported("model_conf.segment_dur/overlap_ratio", (arch.segment_dur, arch.overlap_ratio))
@@ -212,6 +217,22 @@ def recipe_config(name: str) -> Dict[str, Any]:
         cfg = recipe_config("ds320")
         cfg["model_conf"]["segment_dur"] = 0.5
         cfg["model_conf"]["overlap_ratio"] = 0.1
+        return cfg
+    if name == "ds640seg":   # segment length NOT a multiple of the hop (8000 % 640 = 320): frames decode to 13 * 640 = 8320 samples
+        cfg = recipe_config("ds640")
+        cfg["model_conf"]["segment_dur"] = 0.5
+        cfg["model_conf"]["overlap_ratio"] = 0.1
+        return cfg
+    if name in ("ss320nc", "tinyssnc"):
+        # egs/LibriTTS/codec/conf/soundstream_noncausal_16k_n32_600k_step.yaml:11-38: GroupNorm, non-causal, three residual
+        # blocks per stage (dilations 1, 2, 4 -> the two-source GroupNorm chain across consecutive blocks), no sequence
+        # model, 512-dim codebooks ("tinyssnc": the same shape, small)
+        cfg = recipe_config("ds320" if name == "ss320nc" else "tiny")
+        for k in ("encoder_conf", "decoder_conf"):
+            cfg[k]["n_residual_layers"] = 3
+            cfg[k]["seq_model"] = "none"
+        cfg["encoder_conf"]["dimension"] = 512 if name == "ss320nc" else 32
+        cfg["model_conf"]["odim"] = cfg["encoder_conf"]["dimension"]
         return cfg
     if name in ("ss320", "tinyss"):
         # egs/LibriTTS/codec/conf/soundstream_16k_n32_600k_step.yaml:11-38: weight-normalised causal convs, three residual

@@ -97,7 +97,8 @@ struct Ctx {
 
 int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
-const char* kLstmClass = "lstm_wave_kernel (whole recurrence of one SLSTM block, incl. launch gaps)";
+const char* kLstmPersistClass = "lstm_persist_kernel<NS, NBT> (whole recurrence of one SLSTM block, one launch)";
+const char* kLstmWaveClass = "lstm_wave_kernel<NS> (whole recurrence of one SLSTM block: T + L - 1 launches incl. gaps)";
 const char* kRvqClass = "rvq_encode_kernel<D, RS> (all stages of the residual quantiser)";
 
 }  // namespace
@@ -120,6 +121,11 @@ struct fc_engine {
     float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
     float* cb_frag = nullptr;                // the codebooks in MFMA B-fragment order (kernels.hip rvq_encode_kernel), or null
     std::vector<void*> dev_allocs;
+    // status words written by kernels (host-pinned, device-mapped; kernels.h FC_STATUS_*), read at the next call without a sync
+    volatile unsigned* status_host = nullptr;
+    unsigned* status_dev = nullptr;
+    bool lstm_persist_ok = true;             // cleared after a grid-barrier timeout: later calls take the per-step launch path
+    int persist_checked_B = -1; bool persist_checked_val = false;
     // optional event timing
     bool profiling = false;
     struct Span { hipEvent_t a, b; int cls; double flops, bytes; };
@@ -595,7 +601,12 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
     float* xproj = cx.alloc<float>((size_t)T * B * 4 * H);
     run_conv(e, cx, lb.layers[0].inproj, src_of(in), fc::Src(), 0, T, xproj, (long long)4 * H, 1, (long long)B * 4 * H);
     static const int persist_env = getenv("FC_LSTM_PERSIST") ? atoi(getenv("FC_LSTM_PERSIST")) : 1;
-    const bool persist = persist_env && fc::lstm_persist_supported(B, H, L, e->device);
+    bool persist = false;
+    if (persist_env && e->lstm_persist_ok) {
+        const int key = B * 4096 + H;            // the occupancy query is cached per (B, H)
+        if (e->persist_checked_B != key) { e->persist_checked_val = fc::lstm_persist_supported(B, H, L, e->device); e->persist_checked_B = key; }
+        persist = e->persist_checked_val;
+    }
     // persistent kernel: barrier words + hidden-state history; per-step launches: h [L][2][B][H], c [L][B][H]
     float* state = cx.alloc<float>(persist ? fc::lstm_persist_state_floats(B, H, T) : (size_t)3 * L * B * H);
     Act y;
@@ -604,13 +615,13 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
     cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H * (2 * L - 1);
     cx.launches += persist ? 2 : T + L;
     if (!cx.dry && !cx.err) {
-        ProfSpan sp(e, cx, e->profiling ? e->prof_class(kLstmClass) : 0, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
+        ProfSpan sp(e, cx, e->profiling ? e->prof_class(persist ? kLstmPersistClass : kLstmWaveClass) : 0, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
         hipError_t er = hipMemsetAsync(state, 0, (persist ? fc::lstm_persist_clear_floats(B, H) : (size_t)3 * L * B * H) * sizeof(float), cx.st);
         const float* w[FC_LSTM_MAX_LAYERS] = {nullptr};
         const float* bias[FC_LSTM_MAX_LAYERS] = {nullptr};
         for (int l = 0; l < L; ++l) { w[l] = l == 0 ? lb.layers[0].whh : lb.layers[l].wcat; bias[l] = lb.layers[l].bperm; }
         if (persist) {
-            if (er == hipSuccess) er = fc::launch_lstm_persist(w[0], w[1], bias[1], xproj, state, y.raw, B, H, T, cx.st);
+            if (er == hipSuccess) er = fc::launch_lstm_persist(w[0], w[1], bias[1], xproj, state, y.raw, B, H, T, e->status_dev, cx.st);
         } else {
             float *h = state, *c = state + (size_t)2 * L * B * H;
             for (int s = 0; s < T + L - 1 && er == hipSuccess; ++s)
@@ -724,10 +735,28 @@ int do_decode(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf, const float* sc
     return cx.err;
 }
 
+// Deferred device-side failures of EARLIER calls (kernels cannot return a status): reported once, then cleared.
+int consume_status(fc_engine* e) {
+    if (!e->status_host) return 0;
+    if (e->status_host[FC_STATUS_LSTM_TIMEOUT]) {
+        e->status_host[FC_STATUS_LSTM_TIMEOUT] = 0;
+        e->lstm_persist_ok = false;
+        return fail("a previous call's persistent LSTM kernel timed out at its grid barrier (its workgroups were not all co-resident: "
+                    "GPU shared with another process / stream, or CUs masked); that call's outputs were NaN-poisoned and are invalid. "
+                    "This engine now uses the per-step LSTM launches (same results); set FC_LSTM_PERSIST=0 for shared-GPU deployments");
+    }
+    if (e->status_host[FC_STATUS_BAD_CODE]) {
+        e->status_host[FC_STATUS_BAD_CODE] = 0;
+        return fail("a previous decode call was given code indices outside [0, codebook_size) (the reference's F.embedding raises, "
+                    "ddp_core_vq.py:191); they were clamped, the decoded audio of that call is not meaningful");
+    }
+    return 0;
+}
+
 int check_ready(fc_engine* e) {
     if (!e) return fail("null engine");
     if (!e->finalized) return fail("engine not finalized");
-    return 0;
+    return consume_status(e);
 }
 
 Ctx make_ctx(int B, void* ws, size_t ws_bytes, void* stream) {
@@ -756,7 +785,8 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (arch->n_filters % 2) return fail("n_filters must be even");
     const int D = arch->dimension;
     if (!(D == 16 || D == 32 || D == 64 || D == 128 || D == 256 || D == 512)) return fail("dimension must be one of 16/32/64/128/256/512");
-    if (arch->codebook_size % 64) return fail("codebook_size must be a multiple of 64");
+    if (arch->codebook_size % 64 || (arch->codebook_size > 128 && arch->codebook_size % 128))
+        return fail("codebook_size must be a multiple of 64, and of 128 above 128 (8 waves x 16-code tiles)");
     if (arch->lstm_layers > 0 && ((arch->n_filters << arch->n_ratios) % 16)) return fail("LSTM width must be a multiple of 16");
     if (arch->lstm_layers > FC_LSTM_MAX_LAYERS) return fail("too many LSTM layers");
     for (int i = 0; i < arch->n_ratios; ++i)
@@ -796,6 +826,7 @@ void fc_engine_destroy(fc_engine* e) {
     if (!e) return;
     for (hipEvent_t ev : e->event_pool) (void)hipEventDestroy(ev);
     for (void* p : e->dev_allocs) (void)hipFree(p);
+    if (e->status_host) (void)hipHostFree((void*)e->status_host);
     delete e;
 }
 
@@ -879,8 +910,16 @@ int fc_engine_finalize(fc_engine* e) {
         if (upload(e, F, &e->cb_frag)) return 1;
     }
     if (upload(e, en, &e->enorm)) return 1;
-    // opt in to the dynamic LDS the conv kernels ask for is not needed (<= 64 KiB); host copies are dropped
-    e->host.clear();
+    {   // status words: pinned host memory the kernels write to directly (error paths only)
+        void* hp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, FC_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped));
+        memset(hp, 0, FC_STATUS_WORDS * sizeof(unsigned));
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, hp, 0));
+        e->status_host = (volatile unsigned*)hp;
+        e->status_dev = (unsigned*)dp;
+    }
+    e->host.clear();                                  // host copies of the checkpoint are dropped
     HIP_TRY(hipDeviceSynchronize());
     e->finalized = true;
     return 0;
@@ -949,7 +988,7 @@ int fc_decode_codes(fc_engine* e, const int64_t* codes, int B, int Tf, int n_q, 
     const int D = e->arch.dimension;
     float* z = cx.alloc<float>((size_t)B * D * Tf);
     if (cx.err) return 1;
-    HIP_TRY(fc::launch_rvq_decode(codes, B, Tf, n_q, D, e->arch.codebook_size, e->cb, emb_out, z, cx.st));
+    HIP_TRY(fc::launch_rvq_decode(codes, B, Tf, n_q, D, e->arch.codebook_size, e->cb, emb_out, z, e->status_dev, cx.st));
     return do_decode(e, cx, z, Tf, nullptr, out_len, wav);
 }
 
@@ -1012,6 +1051,25 @@ int fc_lstm_forward(fc_engine* e, const char* prefix, const float* x, int B, int
     fc::Src s1;
     if (e->arch.lstm_skip) s1 = src_of(in);
     HIP_TRY(fc::launch_combine(src_of(o), s1, 0, 1.f, nullptr, B, o.C, T, T, y, (long long)o.C * T, T, 1, cx.st));
+    return 0;
+}
+
+int fc_engine_status(fc_engine* e, unsigned* flags) {
+    if (!e) return fail("null engine");
+    unsigned f = 0;
+    if (e->status_host) {
+        if (e->status_host[FC_STATUS_LSTM_TIMEOUT]) f |= FC_STATUS_FLAG_LSTM_TIMEOUT;
+        if (e->status_host[FC_STATUS_BAD_CODE]) f |= FC_STATUS_FLAG_BAD_CODE;
+    }
+    if (flags) *flags = f;
+    if (!e->finalized) return 0;
+    return consume_status(e);
+}
+
+int fc_overlap_add(const float* const* frames, const int* lens, int n_frames, int B, int frame0_len, int stride, int out_len,
+                   float* out, void* stream) {
+    if (!frames || !lens || !out || n_frames <= 0 || B <= 0 || frame0_len <= 0 || stride <= 0 || out_len <= 0) return fail("bad argument");
+    HIP_TRY(fc::launch_overlap_add(frames, lens, n_frames, B, frame0_len, stride, out_len, out, (hipStream_t)stream));
     return 0;
 }
 

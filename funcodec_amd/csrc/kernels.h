@@ -72,8 +72,14 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
                              float* quant_bdt /*[B][D][Tf] or null*/, float* subq /*[nq][B][D][Tf] or null*/,
                              int Tf, hipStream_t st);
 // codes [B][Tf][nq] (i64) -> emb [B][Tf][D] and/or emb_bdt [B][D][Tf]
+// status: host-visible engine status words (FC_STATUS_*), or null; an index outside [0, K) sets FC_STATUS_BAD_CODE
 hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D, int K, const float* cb,
-                             float* emb, float* emb_bdt, hipStream_t st);
+                             float* emb, float* emb_bdt, unsigned* status, hipStream_t st);
+
+// engine status words (host-pinned, device-mapped): written by kernels with plain stores, read by the host without a sync
+#define FC_STATUS_LSTM_TIMEOUT 0   // persistent LSTM: the grid barrier timed out (workgroups not co-resident); outputs poisoned
+#define FC_STATUS_BAD_CODE 1       // decode: a code index outside [0, codebook_size) was clamped
+#define FC_STATUS_WORDS 16
 
 #define FC_LSTM_MAX_LAYERS 4
 // Layer-wavefront step s (see kernels.hip): w[0] = W_hh0 perm [4H][H]; w[l>=1] = [W_ih_l | W_hh_l] perm [4H][2H];
@@ -83,7 +89,11 @@ hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, con
 
 // Persistent 2-layer recurrence (one launch); sync = 2 zeroed words; h [2][2][B][H] zeroed by the caller.
 hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* state, float* y,
-                               int B, int H, int T, hipStream_t st);
+                               int B, int H, int T, unsigned* status, hipStream_t st);
+// _linear_overlap_add (codec_basic.py:77-116): frames = DEVICE array of n_frames device pointers ([B][lens[f]] each), lens = DEVICE
+// array; L0 = length of frame 0 (sizes the triangle window); out [B][out_len] = the first out_len samples of the sum
+hipError_t launch_overlap_add(const float* const* frames, const int* lens, int n_frames, int B, int L0, int stride, int out_len,
+                              float* out, hipStream_t st);
 hipError_t debug_timeline(unsigned long long* dst);      // [2 roles][24 items][8 slots], profiling builds only
 size_t lstm_persist_state_floats(int B, int H, int T);   // barrier words + zero slot + hidden-state history of both layers
 size_t lstm_persist_clear_floats(int B, int H);

@@ -6,6 +6,7 @@
 // traded.  Wavefront = 64 lanes throughout.
 #include "kernels.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -813,11 +814,17 @@ size_t conv_lds_bytes(const ConvLaunch& c) {
 
 template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW>
 static hipError_t launch_conv_k(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    static bool attr_done = false;
+    // the opt-in to > 64 KiB of dynamic LDS is per (kernel, device): one bit per device, set idempotently (two threads
+    // racing here both set the attribute, which is harmless)
+    static std::atomic<unsigned long long> attr_done{0ull};
     auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE, NU, ROW>;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        hipError_t ea = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kfn, grid, dim3(512), lds, st, a);
     return hipGetLastError();
@@ -1577,15 +1584,19 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
 // DRVQ.decode (ddp_core_vq.py:442-453): out = ((0 + E_0[i0]) + E_1[i1]) + ...
 __global__ __launch_bounds__(256) void rvq_decode_kernel(const int64_t* __restrict__ codes, int Tf, int nq, int D, int K,
                                                          const float* __restrict__ cb, float* __restrict__ emb,
-                                                         float* __restrict__ emb_bdt) {
+                                                         float* __restrict__ emb_bdt, unsigned* __restrict__ status) {
     const int n = blockIdx.x;   // row = b*Tf + t
     const int b = n / Tf, t = n - b * Tf;
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
         float s = 0.f;
         for (int i = 0; i < nq; ++i) {
             long long idx = codes[(size_t)n * nq + i];
-            if (idx < 0) idx = 0;
-            if (idx >= K) idx = K - 1;
+            // F.embedding raises on an index outside [0, K) (ddp_core_vq.py:191): never read out of bounds, but make the
+            // corrupt token loud -- the engine status word reports it (fc_engine_status)
+            if (idx < 0 || idx >= K) {
+                if (status && threadIdx.x == 0) *(volatile unsigned*)(status + FC_STATUS_BAD_CODE) = 1u;
+                idx = idx < 0 ? 0 : K - 1;
+            }
             s = s + cb[((size_t)i * K + idx) * D + d];
         }
         if (emb) emb[(size_t)n * D + d] = s;
@@ -1594,10 +1605,10 @@ __global__ __launch_bounds__(256) void rvq_decode_kernel(const int64_t* __restri
 }
 
 hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D, int K, const float* cb, float* emb,
-                             float* emb_bdt, hipStream_t st) {
+                             float* emb_bdt, unsigned* status, hipStream_t st) {
     if (B * Tf <= 0) return hipSuccess;
     const int threads = D >= 256 ? 256 : (D >= 128 ? 128 : 64);
-    hipLaunchKernelGGL(rvq_decode_kernel, dim3(B * Tf), dim3(threads), 0, st, codes, Tf, nq, D, K, cb, emb, emb_bdt);
+    hipLaunchKernelGGL(rvq_decode_kernel, dim3(B * Tf), dim3(threads), 0, st, codes, Tf, nq, D, K, cb, emb, emb_bdt, status);
     return hipGetLastError();
 }
 
@@ -1770,8 +1781,10 @@ struct LstmPersistArgs {
     float* hist;         // [BH zeros][T x BH: h0(0..T-1)][T x BH: h1(0..T-1)]
     float* y;
     unsigned* sync;      // 16 counters at [32*i], error flag at [512]; zeroed by the caller before every launch
+    unsigned* status;    // host-visible engine status words (kernels.h FC_STATUS_*), or null
     int B, H, T;
-    int ablate;          // profiling aid (FC_ABLATE_LSTM env): 1 no grid barrier, 2 no h loads, 16 no MFMA, 32 no gate math/stores
+    int ablate;          // profiling aid (FC_ABLATE_LSTM env): 1 no grid barrier, 2 no h loads, 16 no MFMA, 32 no gate math/stores,
+                         // 64 test hook: behave as if the grid barrier had timed out
 };
 
 constexpr int kLstmSyncWords = 1024;
@@ -1941,7 +1954,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     }
     // a barrier that timed out (some workgroup was not resident) must not pass for a result: poison this workgroup's
     // outputs so that the failure is loud downstream (the engine's per-step launch path is the supported fallback)
-    if (__hip_atomic_load(p.sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    if (__hip_atomic_load(p.sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || (p.ablate & 64)) {
+        if (p.status && tid == 0) *(volatile unsigned*)(p.status + FC_STATUS_LSTM_TIMEOUT) = 1u;   // read by the host at its next fc_* call
         for (int i = tid; i < 4 * B * T; i += 256) {
             const int t = i % T, bu = i / T;
             p.y[((size_t)(bu / 4) * H + (size_t)blk * 4 + (bu & 3)) * T + t] = __builtin_nanf("");
@@ -1955,15 +1969,24 @@ size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords +
 // `state`: lstm_persist_state_floats() floats whose first lstm_persist_clear_floats() are zero (barrier words + the
 // all-zero initial hidden state)
 hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* state, float* y,
-                               int B, int H, int T, hipStream_t st) {
+                               int B, int H, int T, unsigned* status, hipStream_t st) {
     LstmPersistArgs a;
     a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.hist = state + kLstmSyncWords; a.y = y;
-    a.sync = (unsigned*)state; a.B = B; a.H = H; a.T = T;
+    a.sync = (unsigned*)state; a.status = status; a.B = B; a.H = H; a.T = T;
     static const int ablate = getenv("FC_ABLATE_LSTM") ? atoi(getenv("FC_ABLATE_LSTM")) : 0;
     a.ablate = ablate;
     const int nbt = (B + 15) / 16;
     dim3 grid(H / 4), block(256);
-#define FC_LP(NS, NBT) hipLaunchKernelGGL((lstm_persist_kernel<NS, NBT>), grid, block, 0, st, a)
+    // FC_LSTM_COOP=1: hipLaunchCooperativeKernel (the runtime validates the grid against the occupancy query at every launch,
+    // +15-19 us of host time per launch); default: plain launch, residency validated once per engine by lstm_persist_supported()
+    static const int coop = getenv("FC_LSTM_COOP") ? atoi(getenv("FC_LSTM_COOP")) : 0;
+    void* kargs[] = {(void*)&a};
+#define FC_LP(NS, NBT)                                                                                           \
+    do {                                                                                                         \
+        if (coop) { hipError_t ec = hipLaunchCooperativeKernel((const void*)lstm_persist_kernel<NS, NBT>, grid, block, kargs, 0, st); \
+                    if (ec != hipSuccess) return ec; }                                                            \
+        else hipLaunchKernelGGL((lstm_persist_kernel<NS, NBT>), grid, block, 0, st, a);                            \
+    } while (0)
     if (H == 1024 && nbt == 1) FC_LP(16, 1);
     else if (H == 1024 && nbt == 2) FC_LP(16, 2);
     else if (H == 512 && nbt == 1) FC_LP(8, 1);
@@ -1974,11 +1997,62 @@ hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bi
 }
 
 // can the persistent kernel be used? (every workgroup must be co-resident: one per CU)
+// The grid barrier needs all H/4 workgroups resident at once.  Checked against the runtime's own occupancy answer for the
+// instantiation that would run (not just the CU count): blocks per CU x CUs >= grid, with the one-block margin the
+// microarchitecture guide asks for near an SGPR edge (the kernel needs exactly ONE block per CU on a 256-CU part, and
+// two fit by registers, so the margin is met by construction).
 bool lstm_persist_supported(int B, int H, int L, int device) {
     if (L != 2 || (H != 1024 && H != 512) || B > 32) return false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
-    return prop.multiProcessorCount >= H / 4;
+    const int nbt = (B + 15) / 16;
+    int per_cu = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (H == 1024 && nbt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16, 1>, 256, 0);
+    else if (H == 1024 && nbt == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16, 2>, 256, 0);
+    else if (H == 512 && nbt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 1>, 256, 0);
+    else if (H == 512 && nbt == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 2>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) return false;
+    return (long long)per_cu * prop.multiProcessorCount >= H / 4 && prop.multiProcessorCount >= H / 4;
+}
+
+// =================================================================================================
+// 6. Triangle-weighted overlap-add of decoded segments (_linear_overlap_add, codec_basic.py:77-116)
+//    weight = 0.5 - |t - 0.5|, t = linspace(0, 1, L0 + 2)[1:-1] with L0 the FIRST frame's length; out = sum_f w*frame_f
+//    accumulated in frame order (product rounded, then added: the reference's `out += weight * frame`), divided once by
+//    the summed weights.  Frame f starts at f*stride and is lens[f] samples long ([B][lens[f]] contiguous).
+// =================================================================================================
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* const* __restrict__ frames, const int* __restrict__ lens,
+                                                          int n_frames, int L0, int stride, int out_len, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int steps = L0 + 2, halfway = steps / 2;
+    const float step = 1.0f / (float)(steps - 1);
+    for (int pos = blockIdx.x * 256 + threadIdx.x; pos < out_len; pos += gridDim.x * 256) {
+        int f_lo = pos - L0 + 1;
+        f_lo = f_lo <= 0 ? 0 : (f_lo + stride - 1) / stride;
+        int f_hi = pos / stride;
+        if (f_hi > n_frames - 1) f_hi = n_frames - 1;
+        float acc = 0.f, wsum = 0.f;
+        for (int f = f_lo; f <= f_hi; ++f) {
+            const int i = pos - f * stride, n = lens[f];
+            if (i >= n) continue;
+            const int idx = i + 1;                                     // linspace(...)[1:-1]
+            const float t = idx < halfway ? step * (float)idx : 1.0f - step * (float)(steps - idx - 1);
+            const float w = 0.5f - fabsf(t - 0.5f);
+            acc = __fadd_rn(acc, __fmul_rn(w, frames[f][(size_t)b * n + i]));
+            wsum = __fadd_rn(wsum, w);
+        }
+        out[(size_t)b * out_len + pos] = acc / wsum;
+    }
+}
+
+hipError_t launch_overlap_add(const float* const* frames, const int* lens, int n_frames, int B, int L0, int stride, int out_len,
+                              float* out, hipStream_t st) {
+    if (n_frames <= 0 || B <= 0 || out_len <= 0) return hipSuccess;
+    int gx = ceil_div(out_len, 256);
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(overlap_add_kernel, dim3(gx, B), dim3(256), 0, st, frames, lens, n_frames, L0, stride, out_len, out);
+    return hipGetLastError();
 }
 
 }  // namespace fc

@@ -272,6 +272,29 @@ class CodecEngine:
                                            self._stream()))
         return wav
 
+    @_on_device
+    def overlap_add(self, frames, stride: int, out_len: Optional[int] = None) -> torch.Tensor:
+        """_linear_overlap_add (codec_basic.py:77-116) of decoded segments: frames = list of [B,1,L_f] device tensors
+        (frame f starts at f*stride) -> [B,1,out_len or total]."""
+        frames = [self._dev(f.reshape(f.shape[0], -1), torch.float32) for f in frames]
+        B = frames[0].shape[0]
+        lens = [int(f.shape[1]) for f in frames]
+        total = stride * (len(frames) - 1) + lens[-1]
+        out_len = total if out_len is None else min(int(out_len), total)
+        ptrs = torch.tensor([f.data_ptr() for f in frames], dtype=torch.int64).to(self.device)     # plumbing: one small H2D
+        lens_d = torch.tensor(lens, dtype=torch.int32).to(self.device)
+        out = torch.empty((B, 1, out_len), dtype=torch.float32, device=self.device)
+        self._check(self.lib.fc_overlap_add(_ptr(ptrs), _ptr(lens_d), len(frames), B, lens[0], int(stride), out_len, _ptr(out),
+                                            self._stream()))
+        return out
+
+    def check_status(self, sync: bool = True) -> None:
+        """Raise if a kernel of an earlier call recorded a failure (persistent-LSTM barrier timeout, out-of-range code
+        index).  With sync=True the engine's stream is synchronised first, so every call enqueued so far is covered."""
+        if sync and torch.cuda.is_available():
+            torch.cuda.current_stream(self.device).synchronize()
+        self._check(self.lib.fc_engine_status(self._h, None))
+
     # -- per-op entry points (tests) -----------------------------------------------------------
     @_on_device
     def rvq_encode(self, x: torch.Tensor, n_q: int):

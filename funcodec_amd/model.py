@@ -54,27 +54,12 @@ class EncodecMI355X:
         return speech
 
     # -- Encodec._encode / _decode with segment_dur set (codec_basic.py:334-359,382-396,77-116) --
-    @staticmethod
-    def _linear_overlap_add(frames, stride: int) -> torch.Tensor:
-        """Triangle-weighted overlap-add, same operation order as the reference (weight*frame accumulated in frame order,
-        one division by the summed weights at the end)."""
-        total = stride * (len(frames) - 1) + frames[-1].shape[-1]
-        flen = frames[0].shape[-1]
-        t = torch.linspace(0, 1, flen + 2, device=frames[0].device, dtype=frames[0].dtype)[1:-1]
-        weight = 0.5 - (t - 0.5).abs()
-        sum_w = torch.zeros(total, device=frames[0].device, dtype=frames[0].dtype)
-        out = torch.zeros(*frames[0].shape[:-1], total, device=frames[0].device, dtype=frames[0].dtype)
-        off = 0
-        for f in frames:
-            n = f.shape[-1]
-            out[..., off:off + n] += weight[:n] * f
-            sum_w[off:off + n] += weight[:n]
-            off += stride
-        return out / sum_w
-
     def _inference_segmented(self, wav: torch.Tensor, n_q: int, need_recon: bool, use_scale: bool):
         """Every frame is an independent utterance for the engine (own volume scale, GroupNorm statistics, LSTM state), so
-        all frames of equal length go through ONE engine call as extra batch rows; the ragged tail frames follow."""
+        all frames of equal length go through ONE engine call as extra batch rows; the ragged tail frames follow.  Like the
+        reference's _decode, every frame is decoded to its FULL length ceil(len/hop)*hop (longer than the segment when the
+        segment length is not a multiple of the hop), the triangle window is sized from the first decoded frame, and the
+        overlap-add result is trimmed to the input length last (fc_overlap_add)."""
         B, T = wav.shape
         seg, stride = self.arch.segment_length, self.arch.segment_stride
         offsets = list(range(0, T, stride))
@@ -85,15 +70,18 @@ class EncodecMI355X:
             by_len.setdefault(n, []).append(i)
         for n, ids in by_len.items():
             stack = torch.cat([wav[:, offsets[i]:offsets[i] + n] for i in ids], 0).contiguous()   # [len(ids)*B, n]
-            r = self.engine.encode_decode(stack, n_q, use_scale=use_scale) if need_recon else self.engine.encode(stack, n_q)
+            r = self.engine.encode(stack, n_q)
+            rec = None
+            if need_recon:
+                rec = self.engine.decode_emb(r["quantized"], r["scale"] if use_scale else None)   # untrimmed: Tf*hop samples
             for j, i in enumerate(ids):
                 sl = slice(j * B, (j + 1) * B)
                 results[i] = dict(codes=r["codes"][:, sl], quantized=r["quantized"][sl], sub_quants=r["sub_quants"][:, sl],
                                   scale=r["scale"][sl] if r.get("scale") is not None else None,
-                                  recon=r["recon"][sl] if need_recon else None)
+                                  recon=rec[sl] if need_recon else None)
         recon = None
         if need_recon:
-            recon = self._linear_overlap_add([r["recon"] for r in results], stride)[:, :, :T]
+            recon = self.engine.overlap_add([r["recon"] for r in results], stride, out_len=T)
         return dict(recon_speech=recon, code_indices=[r["codes"] for r in results],
                     code_embeddings=[(r["quantized"], r["scale"] if use_scale else None) for r in results],
                     sub_quants=[r["sub_quants"] for r in results])
@@ -130,7 +118,7 @@ class EncodecMI355X:
                            use_scale: bool = True) -> Dict[str, torch.Tensor]:
         recon, emb = self.engine.decode_codes(token_idx)
         if self.arch.segment_length is not None and need_recon:      # _decode: one frame through the overlap-add (codec_basic.py:396)
-            recon = self._linear_overlap_add([recon], self.arch.segment_stride or 1)
+            recon = self.engine.overlap_add([recon], self.arch.segment_stride or 1)
         return dict(recon_speech=recon if need_recon else None, code_indices=None,
                     code_embeddings=[(emb, None)], sub_quants=None)
 
@@ -140,5 +128,5 @@ class EncodecMI355X:
                                use_scale: bool = True) -> Dict[str, torch.Tensor]:
         recon = self.engine.decode_emb(token_idx) if need_recon else None
         if self.arch.segment_length is not None and recon is not None:
-            recon = self._linear_overlap_add([recon], self.arch.segment_stride or 1)
+            recon = self.engine.overlap_add([recon], self.arch.segment_stride or 1)
         return dict(recon_speech=recon, code_indices=None, code_embeddings=[(token_idx, None)], sub_quants=None)

@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define FC_MAX_RATIOS 8
-#define FC_ABI_VERSION 2
+#define FC_ABI_VERSION 3
 
 typedef struct fc_engine fc_engine;
 
@@ -119,6 +119,26 @@ int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int 
                      int64_t* codes, float* quantized, float* sub_quants, float* scale, float* recon,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* _linear_overlap_add (funcodec/models/codec_basic.py:77-116), the tail of Encodec._decode (:382-396) when
+ * model_conf.segment_dur is set: triangle-weighted overlap-add of the decoded segments, products accumulated in
+ * frame order and divided once by the summed weights, exactly as the reference orders it.
+ *   frames      dev array of n_frames dev pointers, frame f = f32 [B, lens[f]] (decoded, UNTRIMMED segment f, which
+ *               starts at sample f*stride); lens dev i32 [n_frames]; frame0_len = lens[0] (sizes the window, host copy)
+ *   out         dev f32 [B, out_len]: the first out_len samples of the sum (Encodec.inference trims to the input, :711) */
+int fc_overlap_add(const float* const* frames, const int* lens, int n_frames, int B, int frame0_len, int stride,
+                   int out_len, float* out, void* stream);
+
+/* Deferred device-side failures.  Kernels cannot return a status, so two conditions are recorded in host-visible
+ * status words and reported by the NEXT fc_* compute call on the engine (non-zero return, message in fc_last_error(),
+ * condition cleared) or by this call.  *flags (may be NULL) receives the conditions pending at entry:
+ *   FC_STATUS_FLAG_LSTM_TIMEOUT  the persistent LSTM kernel's grid barrier timed out (workgroups not co-resident);
+ *                                that call's outputs are NaN-poisoned; the engine falls back to per-step launches
+ *   FC_STATUS_FLAG_BAD_CODE      fc_decode_codes saw an index outside [0, codebook_size) (F.embedding would raise)
+ * Call it after synchronising the stream to learn about the calls enqueued so far. */
+#define FC_STATUS_FLAG_LSTM_TIMEOUT 1u
+#define FC_STATUS_FLAG_BAD_CODE 2u
+int fc_engine_status(fc_engine* e, unsigned* flags);
+
 /* ---- per-op entry points (so tests can pin each kernel against torch.nn.functional) -------------- */
 /* DRVQ.forward on rows: x dev f32 [N,D], codebooks as loaded; codes dev i64 [n_q,N];
  * quantized dev f32 [N,D] or NULL. */
@@ -153,7 +173,8 @@ int fc_engine_work(const fc_engine* e, int B, int T, int n_q, fc_work* out);
  * bracketed by hipEventRecord on the caller's stream.  fc_engine_profile_read() synchronises on the
  * last event, returns per-kernel-class totals accumulated since the last read and resets them. */
 typedef struct fc_prof {
-    char    kernel[64];      /* named like rocprofv3 prints it, e.g. "conv_mfma_kernel<128, 128, 2, 2, 0, 8>" */
+    char    kernel[64];      /* named like rocprofv3 prints it, e.g. "conv_mfma_kernel<128, 128, 2, 2, 0, 8, false>",
+                                "lstm_persist_kernel<NS, NBT> (...)" for the persistent recurrence */
     double  total_ms;        /* sum of event-to-event durations */
     double  flops, bytes;    /* algorithmic work of those launches */
     int32_t launches;

@@ -31,6 +31,26 @@ from funcodec_amd.synth import make_state_dict, synthetic_audio, write_checkpoin
 from torch_oracle import Oracle  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+WAVS = os.path.join(GOLD, "wav")
+
+# The reference's own 16 kHz demo recordings: real speech / music dynamics instead of synthetic noise.  The
+# wav BYTES are committed under tests/golden/wav/ (data, not source) because /root/reference does not exist on the GPU box.
+REFERENCE_WAVS = {
+    "libritts_5105": "egs/LibriTTS/text2speech_laura/demo/5105_28241_000027_000002.wav",
+    "libritts_8230": "egs/LibriTTS/text2speech_laura/demo/8230_279154_000013_000003.wav",
+    "jamendo_0027": "egs/jamendo/text2music_laura/demo/03-1117703-0027.wav",
+}
+
+
+def case_audio(akind, aseed, B, T):
+    """Test audio of a case: synthetic (seeded, re-created on the GPU box) or one of the committed reference wavs
+    (audio_kind "wav:<name>", decoded exactly like the product's reader: PCM16 / 2^15)."""
+    if akind.startswith("wav:"):
+        from funcodec_amd.io import read_wav
+        x, sr = read_wav(os.path.join(WAVS, akind[4:] + ".wav"))
+        assert sr == 16000 and x.shape[0] == T and B == 1, (akind, sr, x.shape)
+        return x[None]
+    return synthetic_audio(B, T, aseed, akind)
 
 # name, config, weight seed, codebook decay, audio kind, audio seed, B, T, bit_width
 CASES = [
@@ -46,6 +66,27 @@ CASES = [
     # the SoundStream recipe shape: + three residual blocks per stage (dilations 1, 2, 4), no LSTM, 512-dim codebooks
     ("tinyss_b2_t600", "tinyss", 5, 1.0, "tones", 61, 2, 600, None),
     ("ss320_b1_t8000", "ss320", 0, 1.0, "noise", 62, 1, 8000, None),
+    # conf/soundstream_noncausal_16k_n32_600k_step.yaml: GroupNorm + three dilated residual blocks per stage (the two-source
+    # GroupNorm chain across consecutive blocks) + 512-dim codebooks, no LSTM
+    ("tinyssnc_b2_t600", "tinyssnc", 5, 1.0, "tones", 71, 2, 600, None),
+    ("ss320nc_b1_t8000", "ss320nc", 0, 1.0, "noise", 72, 1, 8000, None),
+    # the benchmark shape itself (BASELINE.json configs[1]): the first two utterances of bench.py's batch (seed 1234, 10 s)
+    ("ds640_b2_t160000", "ds640", 0, 1.0, "noise", 1234, 2, 160000, None),
+    # the reference's own demo recordings (real speech and music)
+    ("ds640_wav_libritts_5105", "ds640", 0, 1.0, "wav:libritts_5105", 0, 1, 18186, None),
+    ("ds640_wav_libritts_8230", "ds640", 0, 1.0, "wav:libritts_8230", 0, 1, 29440, None),
+    ("ds640_wav_jamendo_0027", "ds640", 0, 1.0, "wav:jamendo_0027", 0, 1, 160000, None),
+    ("ds320_wav_libritts_5105", "ds320", 0, 1.0, "wav:libritts_5105", 0, 1, 18186, None),
+    ("ds320_wav_libritts_8230", "ds320", 0, 1.0, "wav:libritts_8230", 0, 1, 29440, None),
+]
+# cases stored without the encoder output / decode-path waveform (file size): indices, scale, quantized, recon only
+SLIM = {"ds640_b2_t160000", "ds640_wav_jamendo_0027"}
+# segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
+SEG_CASES = [
+    ("ds320seg_b2_t20000", "ds320seg", 0, "tones", 41, 2, 20000),
+    # segment length 8000 is NOT a multiple of the hop 640: frames decode to 8320 samples, the window and the overlap
+    # contributions come from the untrimmed frames (codec_basic.py:382-396)
+    ("ds640seg_b2_t20000", "ds640seg", 0, "tones", 42, 2, 20000),
 ]
 
 
@@ -85,7 +126,12 @@ def main():
     # `python oracle/make_golden.py NAME...` regenerates only the named cases and merges them into MANIFEST.json
     only = set(sys.argv[1:]) or None
     torch.manual_seed(0)
-    os.makedirs(GOLD, exist_ok=True)
+    os.makedirs(WAVS, exist_ok=True)
+    for wname, rel in REFERENCE_WAVS.items():          # byte copies of the reference's demo recordings (test input data)
+        dst = os.path.join(WAVS, wname + ".wav")
+        if not os.path.exists(dst):
+            import shutil
+            shutil.copyfile(os.path.join(ref_shim.REFERENCE_ROOT, rel), dst)
     manifest = {"torch": torch.__version__, "threads": torch.get_num_threads(), "cases": {}}
     cache = {}
     with tempfile.TemporaryDirectory() as tmp:
@@ -96,7 +142,7 @@ def main():
             if key not in cache:
                 cache[key] = build_reference(cfg_name, wseed, decay, tmp)
             s2t, cfg, sd = cache[key]
-            wav = synthetic_audio(B, T, aseed, akind)
+            wav = case_audio(akind, aseed, B, T)
             x = torch.from_numpy(wav)
             idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=bw, use_scale=True, run_mod="inference")
             idx_e, _, _, _ = s2t(x.unsqueeze(1), bit_width=bw, run_mod="encode")
@@ -122,21 +168,20 @@ def main():
             assert torch.equal(od, recon_dec), f"{name}: oracle decode != reference"
             assert torch.equal(orc.decode_emb(quant), recon_emb)
 
-            np.savez_compressed(
-                os.path.join(GOLD, name + ".npz"),
-                indices=idx[0].numpy().astype(np.int16),
-                encoder_out=emb_ref.numpy(), scale=scale_ref.numpy(),
-                quantized=quant.numpy(), recon=recon.numpy(),
-                recon_from_codes=recon_dec.numpy(),
-            )
+            arrays = dict(indices=idx[0].numpy().astype(np.int16), scale=scale_ref.numpy(), quantized=quant.numpy(),
+                          recon=recon.numpy())
+            if name not in SLIM:
+                arrays.update(encoder_out=emb_ref.numpy(), recon_from_codes=recon_dec.numpy())
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
             manifest["cases"][name] = dict(config=cfg_name, weight_seed=wseed, codebook_decay=decay,
                                            audio_kind=akind, audio_seed=aseed, batch=B, samples=T,
                                            bit_width=bw, n_q=int(idx[0].shape[0]), frames=int(idx[0].shape[2]))
             print(f"[golden] {name}: idx{tuple(idx[0].shape)} recon{tuple(recon.shape)} oracle==reference OK")
 
         # ---- segmented overlap-add mode (model_conf.segment_dur, codec_basic.py:334-359,382-396): 0.5 s frames, 10 % overlap
-        if only is None or "ds320seg_b2_t20000" in only:
-            name, cfg_name, wseed, akind, aseed, B, T = "ds320seg_b2_t20000", "ds320seg", 0, "tones", 41, 2, 20000
+        for name, cfg_name, wseed, akind, aseed, B, T in SEG_CASES:
+            if only is not None and name not in only:
+                continue
             s2t, cfg, sd = build_reference(cfg_name, wseed, 1.0, tmp)
             x = torch.from_numpy(synthetic_audio(B, T, aseed, akind))
             idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=None, use_scale=True, run_mod="inference")
@@ -155,6 +200,32 @@ def main():
                                            audio_kind=akind, audio_seed=aseed, batch=B, samples=T, bit_width=None,
                                            n_q=int(idx[0].shape[0]), frames=[int(i.shape[2]) for i in idx])
             print(f"[golden] {name}: {len(idx)} frames {[tuple(i.shape) for i in idx]} oracle==reference OK")
+
+        # ---- `use_ddp: false` quantiser (core_vq.ResidualVectorQuantization, core_vq.py:324-396): the CostumeQuantizer wrapper
+        # cannot construct it at this commit (vq.py:73 passes q0_ds_ratio to a ctor that does not take it), so the class is
+        # instantiated directly; its per-layer codebooks `layers.{i}._codebook.embed` are what such a checkpoint stores
+        if only is None or "rvq_noddp" in only:
+            from funcodec.modules.quantization.core_vq import ResidualVectorQuantization
+            name, seed, nq = "rvq_noddp", 33, 8
+            rng = np.random.Generator(np.random.PCG64(seed))
+            embed = rng.standard_normal((nq, 1024, 128)).astype(np.float32)
+            z = rng.standard_normal((4, 125, 128)).astype(np.float32) * 1.5
+            rvq = ResidualVectorQuantization(num_quantizers=nq, dim=128, codebook_size=1024, codebook_dim=None, decay=0.99,
+                                             kmeans_init=False, kmeans_iters=50, threshold_ema_dead_code=2).eval()
+            with torch.no_grad():
+                for i, layer in enumerate(rvq.layers):
+                    layer._codebook.embed.copy_(torch.from_numpy(embed[i]))
+                    layer._codebook.inited.fill_(1.0)
+                qo, oi, _, osub = rvq(torch.from_numpy(z).permute(0, 2, 1), n_q=nq)
+            keys = sorted(k for k in rvq.state_dict() if k.endswith("_codebook.embed"))
+            assert keys[0] == "layers.0._codebook.embed" and len(keys) == nq, keys[:2]
+            orc = Oracle(recipe_config("ds640"), {"quantizer.rq.model.embed": torch.from_numpy(embed)})
+            q2, i2, s2 = orc.rvq_forward(torch.from_numpy(z), nq)
+            assert torch.equal(i2, oi) and torch.equal(q2, qo.permute(0, 2, 1)) and torch.equal(s2, osub)
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"),
+                                indices=oi.numpy().astype(np.int16), quantized=qo.permute(0, 2, 1).numpy())
+            manifest["cases"][name] = dict(kind="rvq_noddp", codebook_decay=1.0, seed=seed, rows=[4, 125], n_q=nq)
+            print(f"[golden] {name}: core_vq.ResidualVectorQuantization (use_ddp: false), oracle==reference OK")
         if only is not None:
             old = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
             old["cases"].update(manifest["cases"])

@@ -107,7 +107,7 @@ class Oracle:
         self.lstm_layers = enc.get("seq_layer_num", 2) if enc.get("seq_model", "lstm") == "lstm" else 0
         self.alpha = (enc.get("activation_params") or {"alpha": 1.0}).get("alpha", 1.0)
         self.eps = (enc.get("norm_params") or {}).get("eps", 1e-5)
-        self.audio_normalize = m.get("audio_normalize", False)
+        self.audio_normalize = m.get("audio_normalize", True)      # Encodec.__init__ default, codec_basic.py:139
         self.codebook_size = q.get("codebook_size", 1024)
         self.num_quantizers = q.get("num_quantizers", 8)
         self.hop = q.get("encoder_hop_length", 320)
@@ -277,9 +277,9 @@ class Oracle:
         if speech.dim() == 2:
             speech = speech.unsqueeze(1)
         m = self.cfg.get("model_conf", {})
-        sr = int(m.get("target_sample_hz", self.cfg.get("sampling_rate", 16000)))
-        seg = int(m["segment_dur"] * sr)
-        ov = 0.01 if m.get("overlap_ratio", None) is None else m["overlap_ratio"]
+        sr = int(m.get("target_sample_hz", 24000))                   # Encodec.__init__ defaults, codec_basic.py:132-141
+        seg = int(m.get("segment_dur", 1.0) * sr)
+        ov = 0.01 if m.get("overlap_ratio", 0.01) is None else m.get("overlap_ratio", 0.01)
         stride = max(1, int((1 - ov) * seg))
         T = speech.shape[-1]
         idxs, embs, subs_all, recons, encs, scales = [], [], [], [], [], []
@@ -301,7 +301,7 @@ class Oracle:
     @torch.no_grad()
     def inference(self, speech: torch.Tensor, bit_width=None, use_scale=True, need_recon=True):
         """Encodec.inference codec_basic.py:670-718 (one frame when segment_dur is null)."""
-        if self.cfg.get("model_conf", {}).get("segment_dur", None) is not None:
+        if self.cfg.get("model_conf", {}).get("segment_dur", 1.0) is not None:
             return self.inference_segmented(speech, bit_width, use_scale, need_recon)
         if speech.dim() == 2:
             speech = speech.unsqueeze(1)

@@ -45,6 +45,13 @@ def oracle_for(cfg_name, seed, decay=1.0):
 
 
 def audio(B, T, seed, kind="noise"):
+    """Test audio of a golden case: seeded synthetic audio, or (kind "wav:<name>") one of the reference's own demo
+    recordings committed under tests/golden/wav/ (decoded like the product's reader: PCM16 / 2^15)."""
+    if kind.startswith("wav:"):
+        from funcodec_amd.io import read_wav
+        x, sr = read_wav(os.path.join(GOLD, "wav", kind[4:] + ".wav"))
+        assert sr == 16000 and x.shape[0] == T and B == 1
+        return torch.from_numpy(x[None].copy())
     return torch.from_numpy(synthetic_audio(B, T, seed, kind))
 
 

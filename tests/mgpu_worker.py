@@ -1,0 +1,52 @@
+"""Worker of tests/test_multigpu_gpu.py: one process per GPU (torchrun), utterances sharded, codes all-gathered over RCCL."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+
+def main():
+    rank, local, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from funcodec_amd.config import arch_from_config, recipe_config
+    from funcodec_amd.model import EncodecMI355X
+    from funcodec_amd.parallel import gather_codes, shard_range
+    from funcodec_amd.synth import make_state_dict, synthetic_audio
+    arch = arch_from_config(recipe_config("ds320"))
+    model = EncodecMI355X(arch, f"cuda:{local}")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(arch, 0).items()})
+    total = 5                                                      # ragged shards: 3 + 2
+    wav_all = torch.from_numpy(synthetic_audio(total, 32000, 77, "tones"))
+    lo, hi = shard_range(total, rank, world)
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    wav = wav_all[lo:hi].cuda()
+    # a concurrent RCCL kernel on a side stream while the persistent LSTM (grid barrier, one workgroup per CU) runs
+    side = torch.cuda.Stream()
+    junk = torch.ones(1 << 22, device="cuda")
+    for it in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                dist.all_reduce(junk)
+        r = model.engine.encode_decode(wav, 32)
+        codes = gather_codes(r["codes"], dist, shard_sizes=sizes)
+    torch.cuda.synchronize()
+    model.engine.check_status()                                    # no barrier timeout went unnoticed
+    assert codes.shape == (32, total, 100)
+    if rank == 0:
+        single = model.engine.encode_decode(wav_all.cuda(), 32)    # the whole batch on ONE GPU
+        assert torch.equal(single["codes"], codes), "gathered codes differ from the single-GPU result"
+        assert torch.equal(single["recon"][lo:hi], r["recon"])
+        with open(sys.argv[1], "wt") as f:
+            f.write(f"ok ranks_seen={dist.get_world_size()}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@ from helpers import (audio, engine_for, golden, index_report, manifest, oracle_f
 
 pytestmark = pytest.mark.gpu
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "segmented")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 
 # tolerances (north_star): integer codec indices bit-exact; waveforms within 1e-4 RMS
@@ -35,8 +35,9 @@ def test_e2e_against_reference_golden(name):
     wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
     g = golden(name)
     r = m.engine.encode(wav, c["n_q"], want_enc_out=True)
-    assert rms(r["enc_out"], g["encoder_out"]) < 2e-5
-    assert float((r["scale"].cpu() - torch.from_numpy(g["scale"])).abs().max()) < 1e-6
+    if "encoder_out" in g:                         # the two 10 s fixtures store indices / scale / quantized / recon only
+        assert rms(r["enc_out"], g["encoder_out"]) < 2e-5
+    assert float(((r["scale"].cpu() - torch.from_numpy(g["scale"])).abs() / torch.from_numpy(g["scale"])).max()) < 1e-5
     rep = index_report(r["codes"], g["indices"].astype(np.int64))
     assert rep["mismatched_indices"] == 0, rep
     assert rms(r["quantized"], g["quantized"]) == 0.0
@@ -47,10 +48,15 @@ def test_e2e_against_reference_golden(name):
     # decode the REFERENCE's codes: isolates the decoder from any encoder-side index flip
     tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
     w2, emb = m.engine.decode_codes(tok)
-    assert rms(w2, g["recon_from_codes"]) < WAV_RMS_TOL
     assert rms(emb, g["quantized"]) == 0.0
     w3 = m.engine.decode_emb(torch.from_numpy(g["quantized"]))
-    assert rms(w3, g["recon_from_codes"]) < WAV_RMS_TOL
+    if "recon_from_codes" in g:
+        assert rms(w2, g["recon_from_codes"]) < WAV_RMS_TOL
+        assert rms(w3, g["recon_from_codes"]) < WAV_RMS_TOL
+    else:                                          # un-scaled decode x the reference's scale == its scaled reconstruction
+        sc = torch.from_numpy(g["scale"]).view(-1, 1, 1)
+        assert rms(w2.cpu()[:, :, :c["samples"]] * sc, g["recon"]) < WAV_RMS_TOL
+        assert rms(w3.cpu()[:, :, :c["samples"]] * sc, g["recon"]) < WAV_RMS_TOL
 
 
 @pytest.mark.parametrize("name", SEG)
@@ -61,6 +67,7 @@ def test_segmented_mode_against_reference_golden(name):
     c = MAN["cases"][name]
     m = engine_for(c["config"], c["weight_seed"], c["codebook_decay"])
     assert m.arch.segment_length == 8000 and m.arch.segment_stride == 7200
+    # ds640seg: 8000 % 640 != 0 -> frames decode to 13 * 640 = 8320 samples; window and overlap use the untrimmed frames
     wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
     g = golden(name)
     r = m.inference(wav.unsqueeze(1), bit_width=c["bit_width"], use_scale=True)
@@ -118,6 +125,100 @@ def test_rvq_bit_exact_vs_c_oracle_random_shapes():
         cc, cq = c_oracle.rvq_encode(x, cb, 6)
         assert np.array_equal(codes.cpu().numpy(), cc), N
         assert np.array_equal(quant.cpu().numpy(), cq), N
+
+
+def test_use_ddp_false_checkpoint_layout_against_reference_golden():
+    """`use_ddp: false` checkpoints store one codebook per layer (`quantizer.rq.model.layers.{i}._codebook.embed`,
+    core_vq.py:147-150,324-396).  Golden = core_vq.ResidualVectorQuantization itself, run in the build container."""
+    from funcodec_amd.config import arch_from_config, recipe_config
+    from funcodec_amd.model import EncodecMI355X
+    from funcodec_amd.synth import make_state_dict
+    c = MAN["cases"]["rvq_noddp"]
+    nq = c["n_q"]
+    rng = np.random.Generator(np.random.PCG64(c["seed"]))
+    embed = rng.standard_normal((nq, 1024, 128)).astype(np.float32)
+    z = rng.standard_normal((4, 125, 128)).astype(np.float32) * 1.5
+    cfg = recipe_config("ds640")
+    cfg["quantizer_conf"]["num_quantizers"] = nq
+    cfg["quantizer_conf"]["use_ddp"] = False
+    arch = arch_from_config(cfg)
+    sd = {k: v for k, v in make_state_dict(arch, 0).items() if not k.startswith("quantizer.")}
+    for i in range(nq):
+        sd[f"quantizer.rq.model.layers.{i}._codebook.embed"] = embed[i]
+        sd[f"quantizer.rq.model.layers.{i}._codebook.inited"] = np.ones((1,), np.float32)
+    mm = EncodecMI355X(arch, "cuda:0")
+    mm.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    codes, quant = mm.engine.rvq_encode(torch.from_numpy(z).reshape(-1, 128), nq)
+    g = golden("rvq_noddp")
+    rep = index_report(codes.reshape(nq, 4, 125), g["indices"].astype(np.int64))
+    assert rep["mismatched_indices"] == 0, rep
+    assert rms(quant.reshape(4, 125, 128), g["quantized"]) == 0.0
+
+
+def test_overlap_add_entry_point_against_the_reference_formula():
+    """fc_overlap_add = _linear_overlap_add (codec_basic.py:77-116): ragged last frame, more than two frames per position
+    (stride < length / 2), a single frame, output trimmed to a shorter length."""
+    import torch_oracle as TO
+    m = engine_for("tiny", 7)
+    gen = torch.Generator().manual_seed(3)
+    for lens, stride, out_len in (([832, 832, 500], 720, 1900), ([400, 400, 400, 400, 123], 150, None), ([77], 5, None),
+                                  ([8320, 8320, 5760], 7200, 20000)):
+        frames = [torch.randn(3, 1, n, generator=gen) for n in lens]
+        ref = TO.Oracle.linear_overlap_add(frames, stride)
+        if out_len is not None:
+            ref = ref[..., :out_len]
+        got = m.engine.overlap_add([f.cuda() for f in frames], stride, out_len).cpu()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 2e-6, (lens, stride)
+
+
+def test_deferred_device_errors_are_reported():
+    """Kernels cannot return a status: an out-of-range code index (the reference's F.embedding raises, ddp_core_vq.py:191)
+    and a persistent-LSTM grid-barrier timeout are written to host-visible status words and raised by check_status() /
+    the next engine call; afterwards the engine keeps working (the LSTM on its per-step launch path, same bits)."""
+    import subprocess
+    import sys
+    from funcodec_amd.engine import EngineError
+    m = engine_for("ds320", 0)
+    eng = m.engine
+    wav = audio(2, 6400, 3, "tones").cuda()
+    good = eng.encode_decode(wav, 32)
+    eng.check_status()                                               # nothing pending
+    tok = good["codes"].permute(1, 2, 0).contiguous().clone()
+    tok[0, 0, 0] = 99999
+    w, _ = eng.decode_codes(tok)
+    assert torch.isfinite(w).all()                                    # clamped, never an out-of-bounds read
+    with pytest.raises(EngineError, match="outside"):
+        eng.check_status()
+    eng.check_status()                                               # reported once
+    tok[0, 0, 0] = -3
+    eng.decode_codes(tok)
+    torch.cuda.synchronize()
+    with pytest.raises(EngineError, match="outside"):                 # ... or by the next compute call
+        eng.encode_decode(wav, 32)
+    again = eng.encode_decode(wav, 32)
+    assert torch.equal(again["codes"], good["codes"]) and torch.equal(again["recon"], good["recon"])
+    # forced barrier "timeout" (FC_ABLATE_LSTM=64 is the kernel's test hook) in a subprocess: env is read once per process
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle'); sys.path.insert(0, '.')\n"
+        "from helpers import engine_for, audio\n"
+        "from funcodec_amd.engine import EngineError\n"
+        "m = engine_for('ds320', 0); wav = audio(2, 6400, 3, 'tones').cuda()\n"
+        "r = m.engine.encode_decode(wav, 32)\n"
+        "try:\n"
+        "    m.engine.check_status(); raise SystemExit('timeout was not reported')\n"
+        "except EngineError as e:\n"
+        "    assert 'grid barrier' in str(e), str(e)\n"
+        "assert not torch.isfinite(r['recon']).all()\n"
+        "r2 = m.engine.encode_decode(wav, 32); m.engine.check_status()\n"     # per-step fallback from now on
+        "assert torch.isfinite(r2['recon']).all()\n"
+        "torch.save(r2['codes'].cpu(), sys.argv[1])\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "_status_codes.pt")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=dict(os.environ, FC_ABLATE_LSTM="64"), timeout=300)
+    assert torch.equal(torch.load(path), good["codes"].cpu())
 
 
 # ---- (b) per-op parity against torch.nn.functional on CPU -----------------------------------------
@@ -419,15 +520,40 @@ def test_full_size_encode_decode_round_trip_and_prefix(config_b):
     assert float((chosen - best).max()) < 1e-3
 
 
+def _check_against(orc, got_codes, got_recon, ref_codes, ref_recon, o=None, wav=None):
+    """Bit-exact indices, else every flip must be PROVEN a near-tie in the oracle's own distances; the waveform is
+    checked regardless."""
+    rep = index_report(got_codes, ref_codes)
+    if rep["mismatched_indices"]:
+        if o is None:
+            o = orc.inference(wav, None, True)
+        _assert_flips_are_near_ties(orc, o, dict(code_indices=[got_codes]), rep)
+        assert rep["frames_bad"] <= 1, rep
+    assert rms(got_recon, ref_recon) < WAV_RMS_TOL
+    return rep
+
+
+def test_full_size_matches_the_reference_golden_at_the_benchmark_shape(config_b):
+    """BASELINE.json configs[1] itself: utterances 0 and 1 of bench.py's batch (16 x 10 s, seed 1234) against the REAL
+    reference's output for exactly those inputs (tests/golden/ds640_b2_t160000.npz, oracle/make_golden.py)."""
+    m, wav, r = config_b
+    c = MAN["cases"]["ds640_b2_t160000"]
+    assert c["samples"] == 160000 and c["audio_seed"] == 1234 and c["config"] == "ds640" and c["weight_seed"] == 0
+    assert torch.equal(audio(2, 160000, 1234), wav[:2].cpu())          # the fixture's input IS the head of the benchmark batch
+    g = golden("ds640_b2_t160000")
+    rep = _check_against(oracle_for("ds640", 0), r["codes"][:, :2], r["recon"][:2], g["indices"].astype(np.int64), g["recon"],
+                         wav=wav[:2].cpu())
+    assert rep["mismatched_indices"] == 0, rep                         # measured: none; a proven near-tie would still be reported here
+    assert rms(r["quantized"][:2], g["quantized"]) == 0.0
+    assert float(((r["scale"][:2].cpu() - torch.from_numpy(g["scale"])).abs() / torch.from_numpy(g["scale"])).max()) < 1e-5
+
+
 def test_full_size_matches_oracle_on_a_sampled_utterance(config_b):
-    """The CPU oracle needs ~1 s per 10 s utterance: check utterance 3 of the benchmark batch end to end."""
+    """A third utterance of the benchmark batch (not in the fixture) against the oracle run here (~1 s per 10 s of audio)."""
     m, wav, r = config_b
     orc = oracle_for("ds640", 0)
     o = orc.inference(wav[3:4].cpu(), None, True)
-    rep = index_report(r["codes"][:, 3:4], o["code_indices"][0])
-    assert rep["frames_bad"] <= 2, rep
-    if rep["frames_bad"] == 0:
-        assert rms(r["recon"][3:4], o["recon_speech"]) < WAV_RMS_TOL
+    _check_against(orc, r["codes"][:, 3:4], r["recon"][3:4], o["code_indices"][0], o["recon_speech"], o=o)
 
 
 def test_lstm_persistent_kernel_back_to_back_calls_full_size():
@@ -603,3 +729,5 @@ def test_boundary_error_behaviour():
     tok[0, 1, 1] = -5
     w, _ = eng.decode_codes(tok)
     assert torch.isfinite(w).all()
+    with pytest.raises(EngineError, match="outside"):                  # ... and reported (test_deferred_device_errors_are_reported)
+        eng.check_status()

@@ -84,6 +84,32 @@ def test_out_of_scope_configs_are_refused(mut):
         arch_from_config(cfg)
 
 
+def test_config_defaults_follow_the_reference_constructor():
+    """An ESPnet-style config.yaml stores only the keys the user set; omitted model_conf keys take Encodec.__init__'s
+    defaults (codec_basic.py:132-141): audio_normalize=True, segment_dur=1.0, overlap_ratio=0.01, target_sample_hz=24000.
+    An explicit null is kept (the recipes set segment_dur: null)."""
+    cfg = recipe_config("ds320")
+    cfg["model_conf"] = {"odim": 128}
+    a = arch_from_config(cfg)
+    assert a.audio_normalize is True and a.segment_dur == 1.0 and a.overlap_ratio == 0.01 and a.sample_rate == 24000
+    assert a.segment_length == 24000 and a.segment_stride == 23760
+    cfg["model_conf"] = {"segment_dur": None, "audio_normalize": False, "target_sample_hz": 16000}
+    b = arch_from_config(cfg)
+    assert b.segment_length is None and b.audio_normalize is False and b.sample_rate == 16000
+    # encoder / decoder values that differ are refused, not silently taken from the encoder
+    for key, val in (("activation_params", {"alpha": 0.5}), ("norm_params", {"eps": 1e-3}), ("seq_model", "none")):
+        cfg = recipe_config("ds320")
+        cfg["decoder_conf"][key] = val
+        with pytest.raises(NotImplementedError):
+            arch_from_config(cfg)
+    for name in ("ss320nc", "tinyssnc", "ds640seg"):                   # the accepted noncausal SoundStream / segmented recipes
+        arch_from_config(recipe_config(name))
+    bad = arch_from_config(recipe_config("tiny"))
+    bad.codebook_size = 192                                            # > 128 and not a multiple of 128: refused at create time
+    with pytest.raises(EngineError, match="codebook_size"):
+        CodecEngine(bad)
+
+
 def test_engine_sizes_and_work_accounting():
     arch = arch_from_config(recipe_config("ds640"))
     eng = CodecEngine(arch)
