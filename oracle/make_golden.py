@@ -79,7 +79,8 @@ CASES = [
     ("ds320_wav_libritts_5105", "ds320", 0, 1.0, "wav:libritts_5105", 0, 1, 18186, None),
     ("ds320_wav_libritts_8230", "ds320", 0, 1.0, "wav:libritts_8230", 0, 1, 29440, None),
 ]
-# cases stored without the encoder output / decode-path waveform (file size): indices, scale, quantized, recon only
+# cases stored without the decode-path waveform (file size): indices, scale, encoder output (the tie proof of the parity tests
+# needs it), quantized, recon
 SLIM = {"ds640_b2_t160000", "ds640_wav_jamendo_0027"}
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [
@@ -169,9 +170,9 @@ def main():
             assert torch.equal(orc.decode_emb(quant), recon_emb)
 
             arrays = dict(indices=idx[0].numpy().astype(np.int16), scale=scale_ref.numpy(), quantized=quant.numpy(),
-                          recon=recon.numpy())
+                          recon=recon.numpy(), encoder_out=emb_ref.numpy())
             if name not in SLIM:
-                arrays.update(encoder_out=emb_ref.numpy(), recon_from_codes=recon_dec.numpy())
+                arrays.update(recon_from_codes=recon_dec.numpy())
             np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
             manifest["cases"][name] = dict(config=cfg_name, weight_seed=wseed, codebook_decay=decay,
                                            audio_kind=akind, audio_seed=aseed, batch=B, samples=T,
