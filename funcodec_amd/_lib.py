@@ -58,6 +58,7 @@ SYMBOLS = {
     "fc_layer_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "fc_layer_out_len": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "fc_lstm_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "fc_resblock_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "fc_engine_work": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(FcWork)]),
     "fc_engine_profile": (C.c_int, [_P, C.c_int]),
     "fc_engine_profile_read": (C.c_int, [_P, C.POINTER(FcProf)]),
@@ -70,7 +71,8 @@ _lib = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # FC_LIB: tuning aid only (e.g. a profiling build made with FC_TIMELINE=1 next to the product library)
+    return os.environ.get("FC_LIB") or _build.LIB_PATH
 
 
 def load():

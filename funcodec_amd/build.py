@@ -28,16 +28,19 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+    timeline = bool(os.environ.get("FC_TIMELINE"))
+    # profiling build (phase timestamps inside the conv kernel, fc_debug_timeline): a SEPARATE file, selected with FC_LIB=<path>
+    out = LIB_PATH.replace(".so", "_timeline.so") if timeline else LIB_PATH
+    if not force and not timeline and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
-    if os.environ.get("FC_TIMELINE"):       # profiling build: phase timestamps inside the conv kernel (fc_debug_timeline)
+           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    if timeline:
         cmd.insert(1, "-DFC_TIMELINE")
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":

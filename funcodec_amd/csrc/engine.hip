@@ -111,11 +111,17 @@ struct fc_engine {
     std::map<std::string, HostTensor> host;
     // plan
     ConvLayer enc_first, enc_last, dec_first, dec_last;
-    struct ResBlock { ConvLayer shortcut, block1, block3; };              // SEANetResnetBlock: shortcut(x) + block(x)
+    struct ResBlock {                                                     // SEANetResnetBlock: shortcut(x) + block(x)
+        ConvLayer shortcut, block1, block3;
+        bool fused_head = false;                // shortcut + block.1 in one launch (thin blocks, kernels.hip 1c)
+        float *wsc = nullptr, *wb1 = nullptr;   // LDS images of the two weight matrices for that kernel
+        float *bsc = nullptr, *bb1 = nullptr;
+    };
     struct Stage { std::vector<ResBlock> res; ConvLayer resample; };      // n_residual_layers blocks; resample = down (enc) / up (dec)
     std::vector<Stage> enc_stages, dec_stages;
     LstmBlock enc_lstm, dec_lstm;
     std::map<std::string, ConvLayer*> by_prefix;
+    std::map<std::string, ResBlock*> res_by_prefix;                       // "encoder.model.1" -> block (fc_resblock_forward)
     std::map<std::string, LstmBlock*> lstm_by_prefix;
     // quantiser
     float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
@@ -230,7 +236,7 @@ void build_plan(fc_engine* e) {
             idx++;
         }
         idx++;                                                                    // ELU
-        S.resample = mk_conv(name("encoder", idx, ".conv"), c, 2 * c, 2 * ratio, ratio, false, true);
+        S.resample = mk_conv(name("encoder", idx, ".conv"), c, 2 * c, 2 * ratio, ratio, false, true, s == a.n_ratios - 1);
         idx++;
         mult *= 2;
     }
@@ -288,6 +294,12 @@ void build_plan(fc_engine* e) {
             L->causal = a.causal != 0;
         }
     }
+    for (auto* stg : {&e->enc_stages, &e->dec_stages})
+        for (auto& S : *stg)
+            for (auto& R : S.res) {
+                const std::string& sp = R.shortcut.prefix;               // "<side>.model.<i>.shortcut.conv"
+                e->res_by_prefix[sp.substr(0, sp.size() - std::string(".shortcut.conv").size())] = &R;
+            }
     // ---- checkpoint contract, in execution order
     add_conv_expect(e, e->enc_first);
     for (auto& S : e->enc_stages) {
@@ -332,6 +344,11 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     // always run the PLAIN variant: no affine tables, and the 16-element staging variant has no register pressure.
     const bool plain = ceil_div_i(L.M, L.BM) >= 3;
     const bool dual_eff = L.dual && !plain;
+    // LDS budget of one workgroup.  Layers at the bottleneck frame rate with M <= 1024 have at most one workgroup per CU at the
+    // benchmark shape anyway (M/128 x 2 N tiles x 16 utterances <= 256): they take the whole CU's LDS, i.e. twice as deep K
+    // chunks -> half as many per-item barriers / pipeline refills for the same MFMA work (FC_SMALLN_LDS=80 restores round 1)
+    static const int smalln_lds = getenv("FC_SMALLN_LDS") ? atoi(getenv("FC_SMALLN_LDS")) : 160;
+    const size_t lds_budget = (size_t)((L.small_n && L.M <= 1024) ? smalln_lds : 160 / fc::conv_wgs_per_cu(L.BM)) * 1024;
     int cin_p2 = 2;
     while (cin_p2 < L.cin) cin_p2 *= 2;
     int cc = 2;
@@ -339,8 +356,7 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
         const int n = cc * 2;
         if (n > 32 || n > cin_p2 || n * L.gk > 64) break;
         if (!fc::conv_slab_fits(L.gk, L.gstride, L.dil, n, L.BN, L.BM, dual_eff)) break;
-        if (fc::conv_lds_bytes_for(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 0) >
-            (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) break;
+        if (fc::conv_lds_bytes_for(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 0) > lds_budget) break;
         cc = n;
     }
     // stride-1 layers: row staging (16-byte loads and LDS stores) lifts the register bound on the chunk; take it when
@@ -351,8 +367,7 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
         int best = 0;
         for (int n = 4; n <= 64 && n <= L.cin; n *= 2) {
             if (!fc::conv_row_ok(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, dual_eff)) continue;
-            if (fc::conv_lds_bytes_for(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 1) >
-                (size_t)(160 / fc::conv_wgs_per_cu(L.BM)) * 1024) continue;
+            if (fc::conv_lds_bytes_for(L.gk, L.gstride, L.dil, n, L.BM, L.BN, L.cin, plain ? 0 : (L.dual ? 2 : 1), 1) > lds_budget) continue;
             best = n;
         }
         if (best > cc || (best == cc && !plain)) { L.row = true; cc = best; }   // equal chunk + no prologue: the general
@@ -445,6 +460,44 @@ int pack_conv(fc_engine* e, ConvLayer& L) {
         if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
         if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
     }
+    return 0;
+}
+
+// folded (weight-norm applied) Conv1d weight [cout][cin][k] of a layer, as pack_conv computes it
+std::vector<float> folded_conv_weight(fc_engine* e, const ConvLayer& L) {
+    const std::string inner = L.transposed ? ".convtr" : ".conv";
+    if (!L.wnorm) return e->host[L.prefix + inner + ".weight"].data;
+    const auto& V = e->host[L.prefix + inner + ".weight_v"].data;
+    const auto& G = e->host[L.prefix + inner + ".weight_g"].data;
+    const size_t d0 = L.transposed ? L.cin : L.cout, inner_n = V.size() / d0;
+    std::vector<float> folded(V.size());
+    for (size_t r = 0; r < d0; ++r) {
+        double ss = 0.0;
+        for (size_t j = 0; j < inner_n; ++j) ss += (double)V[r * inner_n + j] * (double)V[r * inner_n + j];
+        const float sc = G[r] / (float)sqrt(ss);
+        for (size_t j = 0; j < inner_n; ++j) folded[r * inner_n + j] = V[r * inner_n + j] * sc;
+    }
+    return folded;
+}
+
+// Thin residual blocks (C = 32 / 64): shortcut + block.1 run as ONE launch (kernels.hip 1c).  Weight images exactly as they sit
+// in LDS: wsc[c][m] = W_sc[m][c][0];  wb1[kk*C + c][h] = W_b1[h][c][kk].
+int pack_reshead(fc_engine* e, fc_engine::ResBlock& R) {
+    static const int enable = getenv("FC_RESHEAD") ? atoi(getenv("FC_RESHEAD")) : 1;
+    const int C = R.shortcut.cin, hid = R.block1.cout, K = R.block1.k;
+    R.fused_head = enable && R.shortcut.cout == C && R.block1.cin == C && fc::reshead_ok(C, hid, R.shortcut.k, K, R.block1.dil, R.block1.stride) &&
+                   R.shortcut.has_norm == R.block1.has_norm;
+    if (!R.fused_head) return 0;
+    const std::vector<float> Wsc = folded_conv_weight(e, R.shortcut), Wb1 = folded_conv_weight(e, R.block1);
+    std::vector<float> a((size_t)C * C), b((size_t)K * C * hid);
+    for (int m = 0; m < C; ++m)
+        for (int c = 0; c < C; ++c) a[(size_t)c * C + m] = Wsc[(size_t)m * C + c];
+    for (int h = 0; h < hid; ++h)
+        for (int c = 0; c < C; ++c)
+            for (int kk = 0; kk < K; ++kk) b[((size_t)kk * C + c) * hid + h] = Wb1[((size_t)h * C + c) * K + kk];
+    if (upload(e, a, &R.wsc) || upload(e, b, &R.wb1)) return 1;
+    if (upload(e, e->host[R.shortcut.prefix + ".conv.bias"].data, &R.bsc)) return 1;
+    if (upload(e, e->host[R.block1.prefix + ".conv.bias"].data, &R.bb1)) return 1;
     return 0;
 }
 
@@ -634,10 +687,63 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
 
 // SEANetResnetBlock (seanet_encoder.py:16-61): returns the two raw branches whose GroupNorm'd sum is the output
 // The block's input is one tensor (first block of a stage) or the pending sum of the previous block's two branches.
+// shortcut(x) and block.1(ELU(x)) of a thin residual block from ONE staging of x (kernels.hip 1c); same outputs / statistics
+// contract as two run_conv() calls
+void run_reshead(fc_engine* e, Ctx& cx, const fc_engine::ResBlock& R, fc::Src a0, fc::Src a1, int T, Act* sc, Act* b1) {
+    const int C = R.shortcut.cin, hid = R.block1.cout;
+    const ConvGeom g = conv_geom(R.block1, T);              // stride 1: Tout == T
+    sc->C = C; sc->T = T; b1->C = hid; b1->T = T;
+    sc->raw = cx.alloc<float>((size_t)cx.B * C * T);
+    b1->raw = cx.alloc<float>((size_t)cx.B * hid * T);
+    fc::ResHeadLaunch c;
+    c.s0 = a0; c.s1 = a1; c.wsc = R.wsc; c.wb1 = R.wb1; c.bsc = R.bsc; c.bb1 = R.bb1;
+    c.out_sc = sc->raw; c.out_b1 = b1->raw;
+    c.B = cx.B; c.C = C; c.T = T; c.k = R.block1.k; c.dil = R.block1.dil; c.padL = g.padL; c.padR = g.padR;
+    c.alpha = e->arch.elu_alpha;
+    const int nblk = fc::reshead_ntiles(T);
+    if (R.shortcut.has_norm) {
+        c.part_sc = cx.alloc<double>((size_t)cx.B * nblk * 2);
+        c.part_b1 = cx.alloc<double>((size_t)cx.B * nblk * 2);
+        sc->aff = cx.alloc<float>((size_t)cx.B * C * 2); sc->normed = true;
+        b1->aff = cx.alloc<float>((size_t)cx.B * hid * 2); b1->normed = true;
+    }
+    const double fl = 2.0 * cx.B * (double)T * ((double)C * C + (double)hid * C * R.block1.k);
+    const double by = 4.0 * cx.B * (double)T * ((double)C * (a1.used ? 2 : 1) + C + hid);      // x read ONCE, both outputs written
+    cx.conv_flops += fl; cx.conv_bytes += by;
+    cx.launches += R.shortcut.has_norm ? 3 : 1;
+    cx.conv_launches += 1;
+    if (cx.dry || cx.err) return;
+    hipError_t er;
+    {
+        int cls = 0;
+        if (e->profiling) {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "reshead_kernel<%d, %d, %s>", C, R.block1.k, a1.ptr ? "true" : "false");
+            cls = e->prof_class(nm);
+        }
+        ProfSpan sp(e, cx, cls, fl, by);
+        er = fc::launch_reshead(c, cx.st);
+    }
+    if (er != hipSuccess) { cx.err = 1; g_err = "fused res-block head launch failed (" + R.shortcut.prefix + "): " + hipGetErrorString(er); return; }
+    if (R.shortcut.has_norm) {
+        er = fc::launch_gn_finalize(c.part_sc, nblk, (double)C * T, R.shortcut.gamma, R.shortcut.beta, C, e->arch.gn_eps, cx.B, sc->aff, cx.st);
+        if (er == hipSuccess)
+            er = fc::launch_gn_finalize(c.part_b1, nblk, (double)hid * T, R.block1.gamma, R.block1.beta, hid, e->arch.gn_eps, cx.B, b1->aff, cx.st);
+        if (er != hipSuccess) { cx.err = 1; g_err = std::string("gn_finalize launch failed: ") + hipGetErrorString(er); }
+    }
+}
+
+// SEANetResnetBlock (seanet_encoder.py:16-61): returns the two raw branches whose GroupNorm'd sum is the output
+// The block's input is one tensor (first block of a stage) or the pending sum of the previous block's two branches.
 void run_resblocks(fc_engine* e, Ctx& cx, const fc_engine::Stage& S, fc::Src a0, fc::Src a1, int T, Act* sc, Act* b3) {
     for (const auto& R : S.res) {
-        *sc = run_conv(e, cx, R.shortcut, a0, a1, 0, T);
-        Act b1 = run_conv(e, cx, R.block1, a0, a1, 1, T);
+        Act b1;
+        if (R.fused_head && !a0.div) {
+            run_reshead(e, cx, R, a0, a1, T, sc, &b1);
+        } else {
+            *sc = run_conv(e, cx, R.shortcut, a0, a1, 0, T);
+            b1 = run_conv(e, cx, R.block1, a0, a1, 1, T);
+        }
         *b3 = run_conv(e, cx, R.block3, src_of(b1), fc::Src(), 1, b1.T);
         a0 = src_of(*sc); a1 = src_of(*b3);
     }
@@ -880,6 +986,12 @@ int fc_engine_finalize(fc_engine* e) {
             for (auto& R : S.res) { convs.push_back(&R.shortcut); convs.push_back(&R.block1); convs.push_back(&R.block3); }
             convs.push_back(&S.resample);
         }
+    // fused res-block heads read the host copies of the two convs' weights: pack them before pack_conv drops nothing (host map is
+    // still alive here)
+    for (auto* stg : {&e->enc_stages, &e->dec_stages})
+        for (auto& S : *stg)
+            for (auto& R : S.res)
+                if (pack_reshead(e, R)) return 1;
     for (ConvLayer* L : convs)
         if (pack_conv(e, *L)) return 1;
     if (pack_lstm(e, e->enc_lstm)) return 1;
@@ -1035,6 +1147,23 @@ int fc_layer_forward(fc_engine* e, const char* prefix, const float* x, int B, in
     Act o = run_conv(e, cx, *it->second, s, fc::Src(), apply_elu, T);
     if (cx.err) return 1;
     HIP_TRY(fc::launch_combine(src_of(o), fc::Src(), 0, 1.f, nullptr, B, o.C, o.T, o.T, y, (long long)o.C * o.T, o.T, 1, cx.st));
+    return 0;
+}
+
+int fc_resblock_forward(fc_engine* e, const char* prefix, const float* x, int B, int T, float* y, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    if (check_ready(e)) return 1;
+    if (!prefix || !x || !y || B <= 0 || T <= 0) return fail("bad argument");
+    auto it = e->res_by_prefix.find(prefix);
+    if (it == e->res_by_prefix.end()) return fail(std::string("unknown residual block ") + prefix);
+    Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
+    fc_engine::Stage one;
+    one.res.push_back(*it->second);
+    fc::Src s; s.ptr = x; s.used = 1;
+    Act sc, b3;
+    run_resblocks(e, cx, one, s, fc::Src(), T, &sc, &b3);
+    if (cx.err) return 1;
+    HIP_TRY(fc::launch_combine(src_of(sc), src_of(b3), 0, 1.f, nullptr, B, sc.C, T, T, y, (long long)sc.C * T, T, 1, cx.st));
     return 0;
 }
 

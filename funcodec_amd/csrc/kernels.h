@@ -50,6 +50,21 @@ std::vector<int> conv_koff_table(int k, int stride, int dil, int CC, int BN, int
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st);
 void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row);    // template instantiation launch_conv() picks
 
+// Fused head of a thin residual block (kernels.hip 1c): sc = shortcut(x) (k = 1, C -> C) and b1 = block.1(ELU(x)) (k, dilation,
+// C -> C/2, reflect padded) from ONE staging of x = f0(s0) [+ f1(s1)].
+struct ResHeadLaunch {
+    Src s0, s1;
+    const float *wsc = nullptr, *wb1 = nullptr;     // LDS images: wsc[c][m] (C x C); wb1[kk*C + c][h] (k*C x C/2)
+    const float *bsc = nullptr, *bb1 = nullptr;     // biases [C], [C/2]
+    float *out_sc = nullptr, *out_b1 = nullptr;     // [B][C][T], [B][C/2][T] raw conv outputs
+    double *part_sc = nullptr, *part_b1 = nullptr;  // [B][reshead_ntiles(T)][2] or null
+    int B = 0, C = 0, T = 0, k = 3, dil = 1, padL = 0, padR = 0;
+    float alpha = 1.f;
+};
+bool reshead_ok(int C, int hid, int k_sc, int k_b1, int dil, int stride);
+int reshead_ntiles(int T);
+hipError_t launch_reshead(const ResHeadLaunch& c, hipStream_t st);
+
 // Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)
 hipError_t launch_gn_finalize(const double* partials, int nblk, double count, const float* gamma,
                               const float* beta, int C, float eps, int B, float* aff, hipStream_t st);

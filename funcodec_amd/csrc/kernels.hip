@@ -78,7 +78,14 @@ __device__ __forceinline__ float elu_f(float v, float alpha) {
     return v > 0.f ? v : fmaf(e, alpha, -alpha);
 }
 
-constexpr int SLAB_PER_THREAD = 16;          // register-staged slab elements per thread per chunk (NU = 8 or 16)
+// Element staging: NU = register slots (slab elements) per staging thread per chunk, a compile-time constant so that the staging
+// code is straight-line (a run-time slot count put a scalar branch between every load: measured 15 % slower).  The strided
+// layers' slabs are 4.03 / 8.06 / 10.1 / 16.0 / 16.1 x 256 elements, so the instantiations are 5, 9, 11, 16 and 18 slots (two
+// sizes, 8 and 16, ran those layers with up to half of the slots empty, and every staging instruction is paid on top of the MFMA
+// time: fp32 MFMA and VALU share the SIMD's lanes).  Two-source prologues hold two values and two table entries per slot: <= 9.
+constexpr int NU_BIG = 18;
+constexpr int NU_DUAL = 9;
+constexpr int SLAB_PER_THREAD = NU_BIG;      // register-staged slab elements per thread per chunk (NU = 8 or NU_BIG)
 
 // Direct global -> LDS copy of one packed weight chunk (contiguous, multiple of 4 KiB): each wave
 // instruction moves 1 KiB (64 lanes x 16 B) with no VGPR round trip.
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool STAGING_DMA = PLAIN;
     constexpr bool DEEP = PLAIN;                      // two register sets of staged input in flight
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int XSF = ROW ? p.xsf : NU * 256 + 4;       // floats per slab buffer
+    const int XSF = p.xsf;                            // floats per slab buffer (host: image + pad, see make_args)
     float* Xs0 = smem + 2 * p.Wbuf;                   // slab, double buffered
     const int cin_pad = (p.Cin + 1) & ~1;             // keeps everything behind the tables 16-byte aligned
     float2* tab0 = (float2*)(Xs0 + 2 * XSF);
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 all_valid[S] = false;
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    unsigned ee = (unsigned)(rtid + 256 * u);
+                        unsigned ee = (unsigned)(rtid + 256 * u);
                     asm volatile("" : "+v"(ee));
                     const bool ok = c0 + (int)__umulhi(ee, p.magic_slabW) < p.Cin;
                     const unsigned off = ok ? base0[u] + ubase : 0u;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             if (!PLAIN) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    a0[u] = *(const float2*)(t0 + cl8[u]);               // a missing element has cl = 0
+                        a0[u] = *(const float2*)(t0 + cl8[u]);               // a missing element has cl = 0
                     if (DUAL) a1[u] = *(const float2*)(t1 + cl8[u]);
                 }
             }
@@ -743,7 +750,9 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.rowStride = a.PL * c.stride;
     a.row = c.row;
     if (c.row) { a.rowStride = (a.slabW + 3) & ~3; a.PL = a.rowStride; }   // 16-byte aligned rows
-    a.xsf = c.CC * a.rowStride + 4;
+    // floats per slab buffer: row staging = the image; element staging = whole 256-element slots (the last float is the dummy
+    // slot of lanes without an element)
+    a.xsf = c.row ? c.CC * a.rowStride + 4 : ceil_div(c.CC * a.rowStride, 256) * 256 + 4;
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.koff = c.koff;
     a.koff_n = conv_koff_len(c.k, c.CC);
@@ -791,7 +800,7 @@ size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, in
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int rowStride = row ? ((slabW + 3) & ~3) : ceil_div(slabW, stride) * stride;
     const int img = CC * rowStride;
-    const int xs = row ? img + 4 : (img <= 8 * 256 ? 8 : 16) * 256 + 4;   // XSF of the variant the launcher will pick
+    const int xs = row ? img + 4 : ceil_div(img, 256) * 256 + 4;   // make_args(): xsf
     const size_t koff_bytes = (size_t)conv_koff_len(k, CC) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
            (size_t)BM * sizeof(float) + 2 * 256 * 8;
@@ -803,7 +812,7 @@ int conv_wgs_per_cu(int) { return 2; }
 bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dual) {
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int img = CC * ceil_div(slabW, stride) * stride;
-    if (dual && CC > 2) return img <= 8 * 256;      // two-source prologue: keep the low-register (NU = 8) variant
+    if (dual && CC > 2) return img <= NU_DUAL * 256;   // two-source prologue: the low-register variants (NU = 8 / NU_DUAL)
     return img <= SLAB_PER_THREAD * 256;
 }
 
@@ -830,11 +839,31 @@ static hipError_t launch_conv_k(const ConvArgs& a, dim3 grid, size_t lds, hipStr
     return hipGetLastError();
 }
 
+// slots of the instantiation that stages `total` slab elements (0: none)
+static int conv_nu_for(int total, int mode) {
+    const int need = (total + 255) / 256;
+    if (need <= 5) return 5;
+    if (need <= 9) return 9;
+    if (mode >= 3) return 0;
+    if (mode == 0 && need <= 11) return 11;
+    if (mode == 0 && need <= 16) return 16;
+    return need <= NU_BIG ? NU_BIG : 0;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE>
 static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t lds, hipStream_t st) {
     if (a.row) return launch_conv_k<BM, BN, WM, WN, MODE, 8, true>(a, grid, lds, st);
-    if (total <= 256 * 8) return launch_conv_k<BM, BN, WM, WN, MODE, 8, false>(a, grid, lds, st);
-    return launch_conv_k<BM, BN, WM, WN, MODE, 16, false>(a, grid, lds, st);
+    const int nu = conv_nu_for(total, MODE);
+    if (nu == 5) return launch_conv_k<BM, BN, WM, WN, MODE, 5, false>(a, grid, lds, st);
+    if (nu == 9) return launch_conv_k<BM, BN, WM, WN, MODE, 9, false>(a, grid, lds, st);
+    if constexpr (MODE < 3) {
+        if constexpr (MODE == 0) {
+            if (nu == 11) return launch_conv_k<BM, BN, WM, WN, MODE, 11, false>(a, grid, lds, st);
+            if (nu == 16) return launch_conv_k<BM, BN, WM, WN, MODE, 16, false>(a, grid, lds, st);
+        }
+        if (nu == NU_BIG) return launch_conv_k<BM, BN, WM, WN, MODE, NU_BIG, false>(a, grid, lds, st);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -851,10 +880,10 @@ static hipError_t launch_conv_t(const ConvLaunch& c, const ConvArgs& a, dim3 gri
 void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row) {
     const ConvArgs a = make_args(c);
     *row = a.row;
-    *nu = a.row || a.CC * a.rowStride <= 256 * 8 ? 8 : 16;
     if (c.s1.ptr) *mode = c.elu ? 4 : 3;
     else if (c.s0.aff || c.s0.div || c.elu) *mode = c.elu ? 2 : 1;
     else *mode = 0;
+    *nu = a.row ? 8 : conv_nu_for(a.CC * a.rowStride, *mode);
 }
 
 static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st);
@@ -1054,6 +1083,361 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
     }
 #undef FC_C1
     return hipGetLastError();
+}
+
+// =================================================================================================
+// 1c. Fused head of a THIN residual block (C = 32 or 64 channels, the HBM-bound end of the nets):
+//         sc = shortcut(x)           Conv1d(C -> C, k = 1)            on x
+//         b1 = block.1(ELU(x))       Conv1d(C -> C/2, k = K3, dil)    on ELU(x), reflect padded
+//     (SEANetResnetBlock.forward seanet_encoder.py:44-61; x = the block's input with its pending GroupNorm affine(s) applied,
+//     one tensor or the sum of two).  Both convs read the same activation: as two launches of the general kernel the input
+//     (the largest tensors of the whole path) is streamed from HBM twice, and the 16-row block.1 is padded to a 32-row MFMA tile.
+//     Here one workgroup stages a [32 channels][128 + halo columns] slab ONCE into LDS in two views (affine'd, and ELU'd),
+//     both weight matrices stay resident in LDS for the workgroup's whole tile range, and each of the 4 waves computes 32
+//     columns of BOTH outputs: shortcut on 32x32x2 MFMAs, block.1 on 16x16x4 MFMAs when it has 16 rows (no padded rows).
+//     Next item's global loads (16-byte, one channel row per 32 lanes) are issued right after the registers were consumed and
+//     fly during the MFMA phase; 2-3 workgroups per CU cover each other's barriers.  Same epilogue contract as the general
+//     kernel: raw outputs + one deterministic fp64 (sum, sum of squares) partial per (utterance, tile) and output.
+//     Accumulation order per output element: bias, then channels ascending (shortcut) / (tap, channel) ascending (block.1).
+// =================================================================================================
+struct ResHeadArgs {
+    const float *src0, *aff0, *src1, *aff1;    // [B][C][T], per-(b,c) affine or null
+    const float *wsc, *wb1;                    // LDS images: wsc[c][m] (C x C), wb1[kk*C + c][h] (K3*C x C/2)
+    const float *bsc, *bb1;                    // biases [C], [C/2]
+    float *out_sc, *out_b1;                    // [B][C][T], [B][C/2][T]
+    double *part_sc, *part_b1;                 // [B][ntiles][2] or null
+    int T, padL, padR, dil, Leff, ntiles;
+    float alpha;
+    int ablate;                                // profiling aid (FC_ABLATE_RH env): 1 no MFMA, 2 no stores, 4 no loads, 8 no statistics.  0 in production
+};
+constexpr int RH_BN = 128, RH_XS = 144, RH_CH = 32;      // columns per tile, LDS row stride (== 16 mod 32), channels per chunk
+
+template <int C, int K3, bool DUAL>
+__global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const ResHeadArgs p) {
+    constexpr int HID = C / 2, NCH = C / RH_CH, MT = C / 32;
+    constexpr bool B16 = HID == 16;                         // block.1 on 16x16x4 tiles
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wsc = smem;                                      // [C][C]
+    float* Wb1 = Wsc + C * C;                               // [K3*C][HID]
+    float* Xa = Wb1 + K3 * C * HID;                         // [32][XS]  affine'd input (shortcut operand)
+    float* Xe = Xa + RH_CH * RH_XS;                         // [32][XS]  ELU'd input (block.1 operand)
+    float* bias_s = Xe + RH_CH * RH_XS;                     // [C + HID]
+    double* red = (double*)(bias_s + C + HID + ((C + HID) & 1));   // [2 outputs][4 waves][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31, g4 = lane >> 4, r16 = lane & 15;
+    const int b = blockIdx.y;
+    const int t_begin = (int)(((long long)p.ntiles * blockIdx.x) / gridDim.x);
+    const int t_end = (int)(((long long)p.ntiles * (blockIdx.x + 1)) / gridDim.x);
+    if (t_begin >= t_end) return;
+
+    // ---- resident weights and biases
+    for (int i = tid * 4; i < C * C; i += 1024) *(f32x4*)(Wsc + i) = *(const f32x4*)(p.wsc + i);
+    for (int i = tid * 4; i < K3 * C * HID; i += 1024) *(f32x4*)(Wb1 + i) = *(const f32x4*)(p.wb1 + i);
+    for (int i = tid; i < C + HID; i += 256) bias_s[i] = i < C ? p.bsc[i] : p.bb1[i - C];
+
+    const int halo = (K3 - 1) * p.dil;                      // <= 8 (host)
+    const int OFF = (4 - (p.padL & 3)) & 3;                 // main columns start 16-byte aligned in LDS
+    // my elements of a chunk: 4 rows (8 apart) x 4 consecutive main columns, + one halo element for the first 32*halo threads
+    const int c4 = tid & 31, row0 = tid >> 5;
+    const bool has_h = tid < RH_CH * halo;
+    const int h_row = has_h ? tid / halo : 0, h_j = has_h ? tid - h_row * halo : 0;
+    const int h_col = h_j < p.padL ? h_j - p.padL : RH_BN + (h_j - p.padL);      // slab column relative to n0
+    const size_t ubase = (size_t)b * C * p.T;
+    const float* s0 = p.src0 + ubase;
+    const float* s1 = DUAL ? p.src1 + ubase : s0;
+    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)b * C : nullptr;
+    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)b * C : nullptr;
+    const int refl = 2 * (p.Leff - 1);
+    auto resolve = [&](int g, bool& ok) __attribute__((always_inline)) {      // global column -> source index (pad1d reflect, conv.py:82-99)
+        ok = g >= -p.padL && g < p.T + p.padR;
+        int src = g < 0 ? -g : g;
+        src = src >= p.Leff ? refl - src : src;
+        ok = ok && src >= 0 && src < p.T;
+        return ok ? src : 0;
+    };
+
+    // TWO register sets: the loads of item f+2 are issued while those of item f+1 are still in flight, so every load has two
+    // item times (~2 x 1.2 us) to come back and a workgroup keeps 2 x 16 KiB (x2 with two sources) of reads outstanding
+    // (one set measured 3.06 TB/s on the 32-channel block: the three workgroups of a CU each waited for their slab)
+    f32x4 v0[2][4], v1[2][DUAL ? 4 : 1];
+    float hv0[2] = {0.f, 0.f}, hv1[2] = {0.f, 0.f};
+    unsigned vmask[2] = {0u, 0u};                            // validity of my 16 main elements + bit 16 the halo element
+    int ld_tile = t_begin, ld_chunk = 0;
+    auto load_item = [&](auto set_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_tag)::value;
+        const int n0 = ld_tile * RH_BN, c0 = ld_chunk * RH_CH;
+        if (++ld_chunk == NCH) { ld_chunk = 0; ++ld_tile; }
+        const bool interior = n0 - p.padL >= 0 && n0 + RH_BN + p.padR <= p.T;
+        if (p.ablate & 4) { vmask[S] = 0x1ffffu; return; }
+        if (interior) {
+            vmask[S] = 0x1ffffu;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(c0 + row0 + 8 * r) * p.T + n0 + 4 * c4;
+                v0[S][r] = *(const f32x4u*)(s0 + o);
+                if (DUAL) v1[S][r] = *(const f32x4u*)(s1 + o);
+            }
+            if (has_h) {
+                const size_t o = (size_t)(c0 + h_row) * p.T + n0 + h_col;
+                hv0[S] = s0[o];
+                if (DUAL) hv1[S] = s1[o];
+            }
+        } else {
+            unsigned vm = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t ro = (size_t)(c0 + row0 + 8 * r) * p.T;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bool ok;
+                    const int src = resolve(n0 + 4 * c4 + j, ok);
+                    v0[S][r][j] = s0[ro + src];
+                    if (DUAL) v1[S][r][j] = s1[ro + src];
+                    vm |= (ok ? 1u : 0u) << (4 * r + j);
+                }
+            }
+            if (has_h) {
+                bool ok;
+                const int src = resolve(n0 + h_col, ok);
+                const size_t o = (size_t)(c0 + h_row) * p.T + src;
+                hv0[S] = s0[o];
+                if (DUAL) hv1[S] = s1[o];
+                vm |= (ok ? 1u : 0u) << 16;
+            }
+            vmask[S] = vm;
+        }
+    };
+    int st_chunk = 0;
+    auto stage_item = [&](auto set_tag) __attribute__((always_inline)) {     // registers -> (affine, + second source) -> Xa ; ELU -> Xe
+        constexpr int S = decltype(set_tag)::value;
+        const int c0 = st_chunk * RH_CH;
+        if (++st_chunk == NCH) st_chunk = 0;
+        const unsigned vm = vmask[S];
+        const bool all = vm == 0x1ffffu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = c0 + row0 + 8 * r;
+            const float2 A = a0 ? a0[c] : make_float2(1.f, 0.f);
+            const float2 A1 = a1 ? a1[c] : make_float2(1.f, 0.f);
+            f32x4 xa, xe;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = fmaf(v0[S][r][j], A.x, A.y);
+                if (DUAL) v = v + fmaf(v1[S][r][j], A1.x, A1.y);
+                float e = elu_f(v, p.alpha);
+                if (!all && !((vm >> (4 * r + j)) & 1u)) { v = 0.f; e = 0.f; }
+                xa[j] = v; xe[j] = e;
+            }
+            const int o = (row0 + 8 * r) * RH_XS + OFF + p.padL + 4 * c4;
+            *(f32x4*)(Xa + o) = xa;
+            *(f32x4*)(Xe + o) = xe;
+        }
+        if (has_h) {
+            const int c = c0 + h_row;
+            const float2 A = a0 ? a0[c] : make_float2(1.f, 0.f);
+            const float2 A1 = a1 ? a1[c] : make_float2(1.f, 0.f);
+            float v = fmaf(hv0[S], A.x, A.y);
+            if (DUAL) v = v + fmaf(hv1[S], A1.x, A1.y);
+            float e = elu_f(v, p.alpha);
+            if (!((vm >> 16) & 1u)) e = 0.f;
+            Xe[h_row * RH_XS + OFF + p.padL + h_col] = e;       // the shortcut (k = 1) never reads halo columns
+        }
+    };
+
+    // accumulators: shortcut MT x (32 rows x 32 cols); block.1 one 32x32 tile or two 16x16 tiles
+    f32x16 asc[MT];
+    f32x16 ab32;
+    f32x4 ab16[2];
+    auto init_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asc[mt][r] = bias_s[mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+        if (B16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ab16[j][r] = bias_s[C + 4 * g4 + r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ab32[r] = bias_s[C + (r & 3) + 8 * (r >> 2) + 4 * hi];
+        }
+    };
+    const int nl0 = wid * 32;
+    const int nitems = (t_end - t_begin) * NCH;
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    load_item(Set0());
+    if (nitems > 1) load_item(Set1());
+    __syncthreads();                                        // weights / biases visible
+    init_acc();
+    int tile = t_begin, chunk = 0;
+    auto item = [&](int f, auto set_tag) __attribute__((always_inline)) {
+        stage_item(set_tag);
+        if (f + 2 < nitems) load_item(set_tag);             // refill the set just consumed: in flight for two item times
+        __syncthreads();
+        const int c0 = chunk * RH_CH;
+        if (!(p.ablate & 1)) {
+        {   // ---- shortcut: sc += Wsc[:, c0 .. c0+31] . Xa
+            const float* xb = Xa + hi * RH_XS + OFF + p.padL + nl0 + l31;
+            const float* wa = Wsc + (c0 + hi) * C + l31;
+#pragma unroll 2
+            for (int ks = 0; ks < 16; ++ks) {
+                const float bv = xb[2 * ks * RH_XS];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    asc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * ks * C + mt * 32], bv, asc[mt], 0, 0, 0);
+            }
+        }
+        if (B16) {   // ---- block.1, 16 rows: 16x16x4 tiles, 4 channels per k-step, two 16-column groups
+#pragma unroll 1
+            for (int kk = 0; kk < K3; ++kk) {
+                const float* xb = Xe + g4 * RH_XS + OFF + nl0 + r16 + kk * p.dil;
+                const float* wa = Wb1 + (kk * C + c0 + g4) * HID + r16;
+#pragma unroll 4
+                for (int q = 0; q < 8; ++q) {
+                    const float av = wa[4 * q * HID];
+                    ab16[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[4 * q * RH_XS], ab16[0], 0, 0, 0);
+                    ab16[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xb[4 * q * RH_XS + 16], ab16[1], 0, 0, 0);
+                }
+            }
+        } else {     // ---- block.1, 32 rows
+#pragma unroll 1
+            for (int kk = 0; kk < K3; ++kk) {
+                const float* xb = Xe + hi * RH_XS + OFF + nl0 + l31 + kk * p.dil;
+                const float* wa = Wb1 + (kk * C + c0 + hi) * HID + l31;
+#pragma unroll 4
+                for (int ks = 0; ks < 16; ++ks)
+                    ab32 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * ks * HID], xb[2 * ks * RH_XS], ab32, 0, 0, 0);
+            }
+        }
+        }
+        const bool tile_done = chunk == NCH - 1;
+        if (tile_done) {
+            // ---- epilogue: raw stores + per-lane statistics of the valid columns
+            const int n0 = tile * RH_BN;
+            float s1 = 0.f, s2 = 0.f, u1 = 0.f, u2 = 0.f;
+            {
+                const int col = n0 + nl0 + l31;
+                const bool okc = col < p.T;
+                float* o = p.out_sc + ubase + col;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float v = asc[mt][r];
+                        if (okc) { if (!(p.ablate & 2)) o[(size_t)m * p.T] = v; s1 += v; s2 = fmaf(v, v, s2); }
+                    }
+            }
+            float* ob = p.out_b1 + (size_t)b * HID * p.T;
+            if (B16) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + nl0 + 16 * j + r16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = ab16[j][r];
+                        if (col < p.T) { if (!(p.ablate & 2)) ob[(size_t)(4 * g4 + r) * p.T + col] = v; u1 += v; u2 = fmaf(v, v, u2); }
+                    }
+                }
+            } else {
+                const int col = n0 + nl0 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = ab32[r];
+                    if (col < p.T) { if (!(p.ablate & 2)) ob[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * p.T + col] = v; u1 += v; u2 = fmaf(v, v, u2); }
+                }
+            }
+            if ((p.part_sc || p.part_b1) && !(p.ablate & 8)) {
+                double d[4] = {(double)s1, (double)s2, (double)u1, (double)u2};
+#pragma unroll
+                for (int o2 = 32; o2 >= 1; o2 >>= 1)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[q] += __shfl_xor(d[q], o2, 64);
+                if (lane == 0) {
+                    red[(0 * 4 + wid) * 2 + 0] = d[0]; red[(0 * 4 + wid) * 2 + 1] = d[1];
+                    red[(1 * 4 + wid) * 2 + 0] = d[2]; red[(1 * 4 + wid) * 2 + 1] = d[3];
+                }
+            }
+            init_acc();
+        }
+        __syncthreads();                                    // Xa / Xe free for the next item; red visible
+        if (tile_done) {
+            if (tid < 4) {                                  // fixed-order sum over the 4 waves
+                const int outp = tid >> 1, comp = tid & 1;
+                double* dst = outp ? p.part_b1 : p.part_sc;
+                if (dst) {
+                    const double* rr = red + outp * 8 + comp;
+                    dst[((size_t)b * p.ntiles + tile) * 2 + comp] = ((rr[0] + rr[2]) + rr[4]) + rr[6];
+                }
+            }
+            ++tile; chunk = 0;
+        } else {
+            ++chunk;
+        }
+    };
+    for (int f = 0; f < nitems; f += 2) {
+        item(f, Set0());
+        if (f + 1 < nitems) item(f + 1, Set1());
+    }
+}
+
+size_t reshead_lds_bytes(int C, int K3) {
+    const int HID = C / 2;
+    return (size_t)(C * C + K3 * C * HID + 2 * RH_CH * RH_XS + C + HID + ((C + HID) & 1)) * sizeof(float) + 2 * 4 * 2 * sizeof(double);
+}
+int reshead_ntiles(int T) { return ceil_div(T, RH_BN); }
+bool reshead_ok(int C, int hid, int k_sc, int k_b1, int dil, int stride) {
+    return (C == 32 || C == 64) && hid * 2 == C && k_sc == 1 && stride == 1 && (k_b1 == 3 || k_b1 == 5 || k_b1 == 7) && (k_b1 - 1) * dil <= 8;
+}
+
+template <int C, int K3, bool DUAL>
+static hipError_t launch_reshead_t(const ResHeadArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_done{0ull};
+    auto kfn = reshead_kernel<C, K3, DUAL>;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        hipError_t ea = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ea != hipSuccess) return ea;
+        attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_reshead(const ResHeadLaunch& c, hipStream_t st) {
+    if (!reshead_ok(c.C, c.C / 2, 1, c.k, c.dil, 1)) return hipErrorInvalidValue;
+    ResHeadArgs a;
+    a.src0 = c.s0.ptr; a.aff0 = c.s0.aff; a.src1 = c.s1.ptr; a.aff1 = c.s1.aff;
+    a.wsc = c.wsc; a.wb1 = c.wb1; a.bsc = c.bsc; a.bb1 = c.bb1;
+    a.out_sc = c.out_sc; a.out_b1 = c.out_b1; a.part_sc = c.part_sc; a.part_b1 = c.part_b1;
+    a.T = c.T; a.padL = c.padL; a.padR = c.padR; a.dil = c.dil;
+    const int maxpad = c.padL > c.padR ? c.padL : c.padR;
+    a.Leff = c.T > maxpad ? c.T : maxpad + 1;
+    a.ntiles = reshead_ntiles(c.T);
+    a.alpha = c.alpha;
+    static const int ablate = getenv("FC_ABLATE_RH") ? atoi(getenv("FC_ABLATE_RH")) : 0;
+    a.ablate = ablate;
+    const size_t lds = reshead_lds_bytes(c.C, c.k);
+    const int per_cu = (int)((160 * 1024) / lds) > 3 ? 3 : (int)((160 * 1024) / lds);
+    static const int target_env = getenv("FC_RH_WGS") ? atoi(getenv("FC_RH_WGS")) : 0;
+    const int target = target_env ? target_env : 256 * (per_cu < 1 ? 1 : per_cu);
+    int G = target / c.B;
+    if (G < 1) G = 1;
+    if (G > a.ntiles) G = a.ntiles;
+    dim3 grid(G, c.B);
+    const bool dual = c.s1.ptr != nullptr;
+#define FC_RH(CC, KK)                                                                              \
+    if (c.C == CC && c.k == KK)                                                                    \
+        return dual ? launch_reshead_t<CC, KK, true>(a, grid, lds, st) : launch_reshead_t<CC, KK, false>(a, grid, lds, st);
+    FC_RH(32, 3) FC_RH(64, 3) FC_RH(32, 5) FC_RH(64, 5) FC_RH(32, 7) FC_RH(64, 7)
+#undef FC_RH
+    return hipErrorInvalidValue;
 }
 
 // =================================================================================================
@@ -1783,8 +2167,7 @@ struct LstmPersistArgs {
     unsigned* sync;      // 16 counters at [32*i], error flag at [512]; zeroed by the caller before every launch
     unsigned* status;    // host-visible engine status words (kernels.h FC_STATUS_*), or null
     int B, H, T;
-    int ablate;          // profiling aid (FC_ABLATE_LSTM env): 1 no grid barrier, 2 no h loads, 16 no MFMA, 32 no gate math/stores,
-                         // 64 test hook: behave as if the grid barrier had timed out
+    int ablate;          // FC_ABLATE_LSTM env: 1 no grid barrier (profiling aid), 64 test hook: behave as if the grid barrier had timed out
 };
 
 constexpr int kLstmSyncWords = 1024;
@@ -1868,35 +2251,34 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
                 xp = *(const f32x4*)(p.xproj + ((size_t)s * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
             f32x4 b0l[NBT == 1 ? 1 : NS], b1[NS];
             f32x4 (&b0)[NS] = *(NBT == 1 ? &b0keep : (f32x4 (*)[NS])&b0l);   // single batch tile: h0(s-1) stays in registers for the shadow phase
+            // All 2*NS loads are issued back to back in the order the MFMAs consume them and NOTHING touches the values before
+            // their MFMA: the k slices then start as they arrive (counted vmcnt) instead of after the last one (round 1 masked
+            // the columns of batch rows >= B right after the loads, which put one vmcnt(0) in front of all 128 MFMAs: 3.3 us
+            // of loads and 2.1 us of MFMAs ran back to back).  Columns of rows >= B read row 0 and compute values nobody stores.
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                if (!(p.ablate & 2)) {
-                    b0[q] = *(const f32x4*)(h0in + hoff + 16 * q);
-                    b1[q] = *(const f32x4*)(h1in + hoff + 16 * q);
-                } else { b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-                if (!bvalid) { b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+                b0[q] = *(const f32x4*)(h0in + hoff + 16 * q);
+                b1[q] = *(const f32x4*)(h1in + hoff + 16 * q);
             }
             // four accumulators (layer 0 / layer 1 x even / odd k slice); the ISSUE order interleaves them so that two
             // MFMAs on the same accumulator are never back to back, the order WITHIN each accumulator is that of
             // lstm_wave_kernel (layer 1: the W_ih1 terms -- already in pa / pb -- then the W_hh1 terms)
             f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = {0.f, 0.f, 0.f, 0.f};
             f32x4 c1a = pa[nb], c1b = pb[nb];
-            if (!(p.ablate & 16)) {
 #pragma unroll
-                for (int q = 0; q < NS; q += 2) {
+            for (int q = 0; q < NS; q += 2) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0a, 0, 0, 0);
-                        c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1a, 0, 0, 0);
-                        c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q + 1][j], b0[q + 1][j], c0b, 0, 0, 0);
-                        c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q + 1][j], b1[q + 1][j], c1b, 0, 0, 0);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0a, 0, 0, 0);
+                    c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q][j], b1[q][j], c1a, 0, 0, 0);
+                    c0b = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q + 1][j], b0[q + 1][j], c0b, 0, 0, 0);
+                    c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1h[q + 1][j], b1[q + 1][j], c1b, 0, 0, 0);
                 }
             }
             red[0][wid][lane] = c0a + c0b;
             red[1][wid][lane] = c1a + c1b;
             __syncthreads();
-            if (wid < 2 && !(p.ablate & 32)) {
+            if (wid < 2) {
                 const int layer = wid;
                 const bool act = layer ? act1 : act0;
                 f32x4 sg = red[layer][0][lane];
@@ -1931,20 +2313,15 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
                 f32x4 (&b0)[NS] = *(NBT == 1 ? &b0keep : (f32x4 (*)[NS])&b0l);
                 if (NBT > 1) {                        // several batch tiles: re-read (L2 hit) instead of holding NBT x 64 registers
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        b0[q] = (p.ablate & 2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : *(const f32x4*)(h0in + hoff + 16 * q);
-                        if (!bvalid) b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
+                    for (int q = 0; q < NS; ++q) b0[q] = *(const f32x4*)(h0in + hoff + 16 * q);
                 }
                 f32x4 c1a = {0.f, 0.f, 0.f, 0.f}, c1b = {0.f, 0.f, 0.f, 0.f};
-                if (!(p.ablate & 16)) {
 #pragma unroll
-                    for (int q = 0; q < NS; q += 2) {
+                for (int q = 0; q < NS; q += 2) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
-                            c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q + 1][j], b0[q + 1][j], c1b, 0, 0, 0);
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
+                        c1b = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q + 1][j], b0[q + 1][j], c1b, 0, 0, 0);
                     }
                 }
                 pa[nb] = c1a; pb[nb] = c1b;

@@ -325,6 +325,19 @@ class CodecEngine:
         return y
 
     @_on_device
+    def resblock_forward(self, prefix: str, x: torch.Tensor) -> torch.Tensor:
+        """SEANetResnetBlock.forward of the block at Sequential prefix `prefix` (e.g. "encoder.model.1"): [B,C,T] -> [B,C,T]."""
+        x = self._dev(x, torch.float32)
+        B, Cc, T = x.shape
+        y = torch.empty_like(x)
+        need = B * Cc * (T + 64) * 4 * 4 + (4 << 20)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws
+        self._check(self.lib.fc_resblock_forward(self._h, prefix.encode(), _ptr(x), B, T, _ptr(y), _ptr(ws), ws.numel(), self._stream()))
+        return y
+
+    @_on_device
     def lstm_forward(self, prefix: str, x: torch.Tensor) -> torch.Tensor:
         x = self._dev(x, torch.float32)
         B, H, T = x.shape

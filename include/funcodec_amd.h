@@ -154,6 +154,12 @@ int fc_layer_forward(fc_engine* e, const char* prefix, const float* x, int B, in
 /* output length of that layer for input length T */
 int fc_layer_out_len(const fc_engine* e, const char* prefix, int T);
 
+/* SEANetResnetBlock.forward (seanet_encoder.py:44-61; decoder copy seanet_decoder.py:42-59) addressed by its Sequential
+ * prefix ("encoder.model.1", "decoder.model.16"): y = shortcut(x) + block(x), each conv followed by its GroupNorm (when the
+ * recipe has one); x, y dev f32 [B,C,T].  Exercises the fused shortcut + block.1 launch of the thin (C <= 64) blocks. */
+int fc_resblock_forward(fc_engine* e, const char* prefix, const float* x, int B, int T,
+                        float* y, void* workspace, size_t workspace_bytes, void* stream);
+
 /* SLSTM.forward (lstm.py:22-28) addressed by prefix ("encoder.model.16.lstm"): x,y dev f32 [B,C,T]. */
 int fc_lstm_forward(fc_engine* e, const char* prefix, const float* x, int B, int T,
                     float* y, void* workspace, size_t workspace_bytes, void* stream);

@@ -333,6 +333,32 @@ def test_conv_layers_random_shape_sweep():
             assert err < tol, (cfg_name, p, B, T, elu, err)
 
 
+@pytest.mark.parametrize("cfg_name", ["ds640", "ss320nc", "ss320"])
+def test_fused_resblock_head_against_torch_cpu(cfg_name):
+    """The thin residual blocks (C = 32 / 64) run shortcut + block.1 as ONE launch (reshead_kernel): whole blocks against the
+    torch restatement of SEANetResnetBlock.forward (seanet_encoder.py:44-61) at lengths around the 128-column tile (edge-only,
+    interior, straddling, shorter than the reflect pad), GroupNorm / weight-norm causal flavours and dilations 1, 2, 4."""
+    from funcodec_amd.plan import decoder_plan, encoder_plan
+    m = engine_for(cfg_name, 0)
+    orc = oracle_for(cfg_name, 0)
+    ops = [op for op in encoder_plan(m.arch) + decoder_plan(m.arch) if op.key.endswith(".block.1.conv") and op.cin in (32, 64)]
+    assert ops
+    gen = torch.Generator().manual_seed(11)
+    worst = 0.0
+    for op in ops:
+        prefix = op.key[: -len(".block.1.conv")]
+        for B, T in ((2, 1), (1, 3), (3, 127), (2, 128), (2, 129), (1, 257), (2, 1000), (1, 4099)):
+            x = torch.randn(B, op.cin, T, generator=gen)
+            ref = orc._resblock(x, prefix, op.dilation)
+            got = m.engine.resblock_forward(prefix, x).cpu()
+            assert got.shape == ref.shape
+            err = (got - ref).abs().max().item()
+            worst = max(worst, err)
+            tol = 4e-4 if T * op.cin < 4096 else 2 * LAYER_ABS_TOL      # GroupNorm over very few elements amplifies rounding
+            assert err < tol, (cfg_name, prefix, B, T, err)
+    print(f"{cfg_name}: worst fused res-block abs err {worst:.2e} over {len(ops)} blocks")
+
+
 @pytest.mark.parametrize("T", [769, 1024, 1291])
 def test_row_staging_interior_and_straddling_tiles(T):
     """The stride-1 layers of the real recipe use row staging (16-byte loads, one channel row per 32 / 64 lanes, k-1 tail

@@ -21,7 +21,7 @@ B = 16
 x = torch.randn(B, cin, T, device="cuda")
 Tout = eng.lib.fc_layer_out_len(eng._h, prefix.encode(), T)
 y = torch.empty(B, cout, Tout, device="cuda")
-ws = torch.empty(B * cout * (Tout + 64) * 4 * 3 + (8 << 20), dtype=torch.uint8, device="cuda")
+ws = torch.empty(B * (cin * T + cout * (Tout + 64)) * 4 * 2 + (64 << 20), dtype=torch.uint8, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
