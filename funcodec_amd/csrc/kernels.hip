@@ -1108,9 +1108,22 @@ struct ResHeadArgs {
     double *part_sc, *part_b1;                 // [B][ntiles][2] or null
     int T, padL, padR, dil, Leff, ntiles;
     float alpha;
-    int ablate;                                // profiling aid (FC_ABLATE_RH env): 1 no MFMA, 2 no stores, 4 no loads, 8 no statistics.  0 in production
 };
 constexpr int RH_BN = 128, RH_XS = 144, RH_CH = 32;      // columns per tile, LDS row stride (== 16 mod 32), channels per chunk
+
+// sum over the 64 lanes of a wave in a FIXED order: 16-lane rows by DPP butterflies (quad swaps, half-row and row mirrors), then
+// the four row totals added in row order.  ~20 VALU instructions (a 64-bit __shfl_xor tree is 12 ds_bpermute + 6 v_add_f64).
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));   // row_mirror
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
 
 template <int C, int K3, bool DUAL>
 __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const ResHeadArgs p) {
@@ -1123,7 +1136,7 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const Res
     float* Xa = Wb1 + K3 * C * HID;                         // [32][XS]  affine'd input (shortcut operand)
     float* Xe = Xa + RH_CH * RH_XS;                         // [32][XS]  ELU'd input (block.1 operand)
     float* bias_s = Xe + RH_CH * RH_XS;                     // [C + HID]
-    double* red = (double*)(bias_s + C + HID + ((C + HID) & 1));   // [2 outputs][4 waves][2]
+    float* red = bias_s + C + HID;                          // [2 outputs][4 waves][2]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31, g4 = lane >> 4, r16 = lane & 15;
@@ -1143,12 +1156,25 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const Res
     const int c4 = tid & 31, row0 = tid >> 5;
     const bool has_h = tid < RH_CH * halo;
     const int h_row = has_h ? tid / halo : 0, h_j = has_h ? tid - h_row * halo : 0;
-    const int h_col = h_j < p.padL ? h_j - p.padL : RH_BN + (h_j - p.padL);      // slab column relative to n0
+    const int h_col = has_h ? (h_j < p.padL ? h_j - p.padL : RH_BN + (h_j - p.padL)) : 0;   // slab column relative to n0
     const size_t ubase = (size_t)b * C * p.T;
     const float* s0 = p.src0 + ubase;
     const float* s1 = DUAL ? p.src1 + ubase : s0;
-    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)b * C : nullptr;
-    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)b * C : nullptr;
+    // the producers' GroupNorm affine of MY rows, once per workgroup (a global load per row inside the item loop costs an L2
+    // round trip on the critical path and, worse, a vmcnt(0) that drains every prefetch and store in flight)
+    float2 A0[NCH][4], A1[DUAL ? NCH : 1][DUAL ? 4 : 1], Ah0[NCH], Ah1[DUAL ? NCH : 1];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = ch * RH_CH + row0 + 8 * r;
+            A0[ch][r] = p.aff0 ? ((const float2*)p.aff0)[(size_t)b * C + c] : make_float2(1.f, 0.f);
+            if (DUAL) A1[ch][r] = p.aff1 ? ((const float2*)p.aff1)[(size_t)b * C + c] : make_float2(1.f, 0.f);
+        }
+        const int c = ch * RH_CH + h_row;
+        Ah0[ch] = p.aff0 ? ((const float2*)p.aff0)[(size_t)b * C + c] : make_float2(1.f, 0.f);
+        if (DUAL) Ah1[ch] = p.aff1 ? ((const float2*)p.aff1)[(size_t)b * C + c] : make_float2(1.f, 0.f);
+    }
     const int refl = 2 * (p.Leff - 1);
     auto resolve = [&](int g, bool& ok) __attribute__((always_inline)) {      // global column -> source index (pad1d reflect, conv.py:82-99)
         ok = g >= -p.padL && g < p.T + p.padR;
@@ -1159,31 +1185,29 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const Res
     };
 
     // TWO register sets: the loads of item f+2 are issued while those of item f+1 are still in flight, so every load has two
-    // item times (~2 x 1.2 us) to come back and a workgroup keeps 2 x 16 KiB (x2 with two sources) of reads outstanding
-    // (one set measured 3.06 TB/s on the 32-channel block: the three workgroups of a CU each waited for their slab)
+    // item times to come back and a workgroup keeps 2 x 16 KiB (x2 with two sources) of reads outstanding.
     f32x4 v0[2][4], v1[2][DUAL ? 4 : 1];
     float hv0[2] = {0.f, 0.f}, hv1[2] = {0.f, 0.f};
-    unsigned vmask[2] = {0u, 0u};                            // validity of my 16 main elements + bit 16 the halo element
-    int ld_tile = t_begin, ld_chunk = 0;
-    auto load_item = [&](auto set_tag) __attribute__((always_inline)) {
+    unsigned vmask[2] = {0u, 0u};                            // GENERIC path: validity of my 16 main elements + bit 16 the halo element
+    int ld_tile = 0, ld_chunk = 0, st_chunk = 0;
+    // FAST = every tile of the segment is a full interior tile: no padding, no masks, no per-lane conditions around memory
+    // instructions -> the whole item is straight-line code and the compiler's vmcnt waits are exact (conditional loads / stores
+    // made it fall back to vmcnt(0) in front of every use: each wait then drained the prefetch AND the previous tile's stores)
+    auto load_item = [&](auto set_tag, auto fast_tag) __attribute__((always_inline)) {
         constexpr int S = decltype(set_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;
         const int n0 = ld_tile * RH_BN, c0 = ld_chunk * RH_CH;
         if (++ld_chunk == NCH) { ld_chunk = 0; ++ld_tile; }
-        const bool interior = n0 - p.padL >= 0 && n0 + RH_BN + p.padR <= p.T;
-        if (p.ablate & 4) { vmask[S] = 0x1ffffu; return; }
-        if (interior) {
-            vmask[S] = 0x1ffffu;
+        if (FAST) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const size_t o = (size_t)(c0 + row0 + 8 * r) * p.T + n0 + 4 * c4;
                 v0[S][r] = *(const f32x4u*)(s0 + o);
                 if (DUAL) v1[S][r] = *(const f32x4u*)(s1 + o);
             }
-            if (has_h) {
-                const size_t o = (size_t)(c0 + h_row) * p.T + n0 + h_col;
-                hv0[S] = s0[o];
-                if (DUAL) hv1[S] = s1[o];
-            }
+            const size_t o = (size_t)(c0 + h_row) * p.T + n0 + h_col;     // lanes without a halo element re-read column n0 of row c0
+            hv0[S] = s0[o];
+            if (DUAL) hv1[S] = s1[o];
         } else {
             unsigned vm = 0;
 #pragma unroll
@@ -1198,51 +1222,46 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const Res
                     vm |= (ok ? 1u : 0u) << (4 * r + j);
                 }
             }
-            if (has_h) {
-                bool ok;
-                const int src = resolve(n0 + h_col, ok);
-                const size_t o = (size_t)(c0 + h_row) * p.T + src;
-                hv0[S] = s0[o];
-                if (DUAL) hv1[S] = s1[o];
-                vm |= (ok ? 1u : 0u) << 16;
-            }
+            bool ok;
+            const int src = resolve(n0 + h_col, ok);
+            const size_t o = (size_t)(c0 + h_row) * p.T + src;
+            hv0[S] = s0[o];
+            if (DUAL) hv1[S] = s1[o];
+            vm |= (ok ? 1u : 0u) << 16;
             vmask[S] = vm;
         }
     };
-    int st_chunk = 0;
-    auto stage_item = [&](auto set_tag) __attribute__((always_inline)) {     // registers -> (affine, + second source) -> Xa ; ELU -> Xe
+    auto stage_item = [&](auto set_tag, auto fast_tag) __attribute__((always_inline)) {   // registers -> (affine, + second source) -> Xa ; ELU -> Xe
         constexpr int S = decltype(set_tag)::value;
-        const int c0 = st_chunk * RH_CH;
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const int ch = st_chunk;
         if (++st_chunk == NCH) st_chunk = 0;
-        const unsigned vm = vmask[S];
-        const bool all = vm == 0x1ffffu;
+        const unsigned vm = FAST ? 0x1ffffu : vmask[S];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int c = c0 + row0 + 8 * r;
-            const float2 A = a0 ? a0[c] : make_float2(1.f, 0.f);
-            const float2 A1 = a1 ? a1[c] : make_float2(1.f, 0.f);
+            const float2 A = NCH == 1 ? A0[0][r] : (ch ? A0[NCH - 1][r] : A0[0][r]);
+            const float2 B1 = !DUAL ? make_float2(1.f, 0.f) : (NCH == 1 ? A1[0][DUAL ? r : 0] : (ch ? A1[DUAL ? NCH - 1 : 0][DUAL ? r : 0] : A1[0][DUAL ? r : 0]));
             f32x4 xa, xe;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = fmaf(v0[S][r][j], A.x, A.y);
-                if (DUAL) v = v + fmaf(v1[S][r][j], A1.x, A1.y);
+                if (DUAL) v = v + fmaf(v1[S][DUAL ? r : 0][j], B1.x, B1.y);
                 float e = elu_f(v, p.alpha);
-                if (!all && !((vm >> (4 * r + j)) & 1u)) { v = 0.f; e = 0.f; }
+                if (!FAST) { const bool ok = (vm >> (4 * r + j)) & 1u; v = ok ? v : 0.f; e = ok ? e : 0.f; }
                 xa[j] = v; xe[j] = e;
             }
             const int o = (row0 + 8 * r) * RH_XS + OFF + p.padL + 4 * c4;
             *(f32x4*)(Xa + o) = xa;
             *(f32x4*)(Xe + o) = xe;
         }
-        if (has_h) {
-            const int c = c0 + h_row;
-            const float2 A = a0 ? a0[c] : make_float2(1.f, 0.f);
-            const float2 A1 = a1 ? a1[c] : make_float2(1.f, 0.f);
+        {
+            const float2 A = NCH == 1 ? Ah0[0] : (ch ? Ah0[NCH - 1] : Ah0[0]);
+            const float2 B1 = !DUAL ? make_float2(1.f, 0.f) : (NCH == 1 ? Ah1[0] : (ch ? Ah1[DUAL ? NCH - 1 : 0] : Ah1[0]));
             float v = fmaf(hv0[S], A.x, A.y);
-            if (DUAL) v = v + fmaf(hv1[S], A1.x, A1.y);
+            if (DUAL) v = v + fmaf(hv1[S], B1.x, B1.y);
             float e = elu_f(v, p.alpha);
-            if (!((vm >> 16) & 1u)) e = 0.f;
-            Xe[h_row * RH_XS + OFF + p.padL + h_col] = e;       // the shortcut (k = 1) never reads halo columns
+            if (!FAST) e = ((vm >> 16) & 1u) ? e : 0.f;
+            if (has_h) Xe[h_row * RH_XS + OFF + p.padL + h_col] = e;        // the shortcut (k = 1) never reads halo columns
         }
     };
 
@@ -1266,20 +1285,18 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const Res
         }
     };
     const int nl0 = wid * 32;
-    const int nitems = (t_end - t_begin) * NCH;
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
-    load_item(Set0());
-    if (nitems > 1) load_item(Set1());
     __syncthreads();                                        // weights / biases visible
     init_acc();
-    int tile = t_begin, chunk = 0;
-    auto item = [&](int f, auto set_tag) __attribute__((always_inline)) {
-        stage_item(set_tag);
-        if (f + 2 < nitems) load_item(set_tag);             // refill the set just consumed: in flight for two item times
+
+    // one item = one 32-channel chunk of one 128-column tile
+    auto item = [&](int f, int nitems, int& tile, int& chunk, auto set_tag, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        stage_item(set_tag, fast_tag);
+        if (f + 2 < nitems) load_item(set_tag, fast_tag);   // refill the set just consumed: in flight for two item times
         __syncthreads();
         const int c0 = chunk * RH_CH;
-        if (!(p.ablate & 1)) {
         {   // ---- shortcut: sc += Wsc[:, c0 .. c0+31] . Xa
             const float* xb = Xa + hi * RH_XS + OFF + p.padL + nl0 + l31;
             const float* wa = Wsc + (c0 + hi) * C + l31;
@@ -1313,7 +1330,6 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const Res
                     ab32 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * ks * HID], xb[2 * ks * RH_XS], ab32, 0, 0, 0);
             }
         }
-        }
         const bool tile_done = chunk == NCH - 1;
         if (tile_done) {
             // ---- epilogue: raw stores + per-lane statistics of the valid columns
@@ -1321,73 +1337,91 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 2) void reshead_kernel(const Res
             float s1 = 0.f, s2 = 0.f, u1 = 0.f, u2 = 0.f;
             {
                 const int col = n0 + nl0 + l31;
-                const bool okc = col < p.T;
-                float* o = p.out_sc + ubase + col;
+                const bool okc = FAST || col < p.T;
+                // one lane pointer (column + the lane's row offset); every accumulator row is a wave-uniform offset from it
+                float* o = p.out_sc + ubase + col + (size_t)(4 * hi) * p.T;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const size_t mo = (size_t)(mt * 32 + (r & 3) + 8 * (r >> 2)) * p.T;
                         const float v = asc[mt][r];
-                        if (okc) { if (!(p.ablate & 2)) o[(size_t)m * p.T] = v; s1 += v; s2 = fmaf(v, v, s2); }
+                        if (FAST) { o[mo] = v; s1 += v; s2 = fmaf(v, v, s2); }
+                        else if (okc) { o[mo] = v; s1 += v; s2 = fmaf(v, v, s2); }
                     }
             }
             float* ob = p.out_b1 + (size_t)b * HID * p.T;
             if (B16) {
+                const int col = n0 + nl0 + r16;
+                float* o = ob + col + (size_t)(4 * g4) * p.T;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + nl0 + 16 * j + r16;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float v = ab16[j][r];
-                        if (col < p.T) { if (!(p.ablate & 2)) ob[(size_t)(4 * g4 + r) * p.T + col] = v; u1 += v; u2 = fmaf(v, v, u2); }
+                        const size_t mo = (size_t)r * p.T + 16 * j;
+                        if (FAST) { o[mo] = v; u1 += v; u2 = fmaf(v, v, u2); }
+                        else if (col + 16 * j < p.T) { o[mo] = v; u1 += v; u2 = fmaf(v, v, u2); }
                     }
                 }
             } else {
                 const int col = n0 + nl0 + l31;
+                float* o = ob + col + (size_t)(4 * hi) * p.T;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = ab32[r];
-                    if (col < p.T) { if (!(p.ablate & 2)) ob[(size_t)((r & 3) + 8 * (r >> 2) + 4 * hi) * p.T + col] = v; u1 += v; u2 = fmaf(v, v, u2); }
+                    const size_t mo = (size_t)((r & 3) + 8 * (r >> 2)) * p.T;
+                    if (FAST) { o[mo] = v; u1 += v; u2 = fmaf(v, v, u2); }
+                    else if (col < p.T) { o[mo] = v; u1 += v; u2 = fmaf(v, v, u2); }
                 }
             }
-            if ((p.part_sc || p.part_b1) && !(p.ablate & 8)) {
-                double d[4] = {(double)s1, (double)s2, (double)u1, (double)u2};
-#pragma unroll
-                for (int o2 = 32; o2 >= 1; o2 >>= 1)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) d[q] += __shfl_xor(d[q], o2, 64);
-                if (lane == 0) {
-                    red[(0 * 4 + wid) * 2 + 0] = d[0]; red[(0 * 4 + wid) * 2 + 1] = d[1];
-                    red[(1 * 4 + wid) * 2 + 0] = d[2]; red[(1 * 4 + wid) * 2 + 1] = d[3];
-                }
+            if (p.part_sc) {                                // wave totals in a fixed order (fp32: <= 24 values per lane, 64 lanes)
+                const float w0 = wave_sum_f32(s1), w1 = wave_sum_f32(s2), w2 = wave_sum_f32(u1), w3 = wave_sum_f32(u2);
+                if (lane == 0) *(f32x4*)(red + 4 * wid) = (f32x4){w0, w1, w2, w3};
             }
             init_acc();
         }
         __syncthreads();                                    // Xa / Xe free for the next item; red visible
         if (tile_done) {
-            if (tid < 4) {                                  // fixed-order sum over the 4 waves
+            if (p.part_sc && tid < 4) {                     // fp64 sum of the 4 wave totals in wave order: one partial per (utterance, tile)
                 const int outp = tid >> 1, comp = tid & 1;
                 double* dst = outp ? p.part_b1 : p.part_sc;
-                if (dst) {
-                    const double* rr = red + outp * 8 + comp;
-                    dst[((size_t)b * p.ntiles + tile) * 2 + comp] = ((rr[0] + rr[2]) + rr[4]) + rr[6];
-                }
+                const float* rr = red + outp * 2 + comp;
+                dst[((size_t)b * p.ntiles + tile) * 2 + comp] = (((double)rr[0] + (double)rr[4]) + (double)rr[8]) + (double)rr[12];
             }
             ++tile; chunk = 0;
         } else {
             ++chunk;
         }
     };
-    for (int f = 0; f < nitems; f += 2) {
-        item(f, Set0());
-        if (f + 1 < nitems) item(f + 1, Set1());
-    }
+    // a segment = consecutive tiles handled by one code path; its pipeline is self-contained (prologue loads of its first two
+    // items, nothing prefetched past its end)
+    auto run = [&](int ta, int tb, auto fast_tag) __attribute__((always_inline)) {
+        if (ta >= tb) return;
+        const int nitems = (tb - ta) * NCH;
+        ld_tile = ta; ld_chunk = 0; st_chunk = 0;
+        int tile = ta, chunk = 0;
+        load_item(Set0(), fast_tag);
+        if (nitems > 1) load_item(Set1(), fast_tag);
+        for (int f = 0; f < nitems; f += 2) {
+            item(f, nitems, tile, chunk, Set0(), fast_tag);
+            if (f + 1 < nitems) item(f + 1, nitems, tile, chunk, Set1(), fast_tag);
+        }
+    };
+    // interior tiles: slab [n0 - padL, n0 + BN + padR) inside [0, T)
+    int e0 = (p.padL + RH_BN - 1) / RH_BN;                                       // first tile with n0 - padL >= 0
+    int e1 = p.T - p.padR - RH_BN >= 0 ? (p.T - p.padR - RH_BN) / RH_BN + 1 : 0;  // one past the last tile with n0 + BN + padR <= T
+    if (e1 < e0) e1 = e0;
+    const int f0 = e0 < t_begin ? t_begin : (e0 > t_end ? t_end : e0);
+    const int f1 = e1 < f0 ? f0 : (e1 > t_end ? t_end : e1);
+    run(t_begin, f0, std::false_type());
+    run(f0, f1, std::true_type());
+    run(f1, t_end, std::false_type());
 }
 
 size_t reshead_lds_bytes(int C, int K3) {
     const int HID = C / 2;
-    return (size_t)(C * C + K3 * C * HID + 2 * RH_CH * RH_XS + C + HID + ((C + HID) & 1)) * sizeof(float) + 2 * 4 * 2 * sizeof(double);
+    return (size_t)(C * C + K3 * C * HID + 2 * RH_CH * RH_XS + C + HID + 16) * sizeof(float);
 }
 int reshead_ntiles(int T) { return ceil_div(T, RH_BN); }
 bool reshead_ok(int C, int hid, int k_sc, int k_b1, int dil, int stride) {
@@ -1421,8 +1455,6 @@ hipError_t launch_reshead(const ResHeadLaunch& c, hipStream_t st) {
     a.Leff = c.T > maxpad ? c.T : maxpad + 1;
     a.ntiles = reshead_ntiles(c.T);
     a.alpha = c.alpha;
-    static const int ablate = getenv("FC_ABLATE_RH") ? atoi(getenv("FC_ABLATE_RH")) : 0;
-    a.ablate = ablate;
     const size_t lds = reshead_lds_bytes(c.C, c.k);
     const int per_cu = (int)((160 * 1024) / lds) > 3 ? 3 : (int)((160 * 1024) / lds);
     static const int target_env = getenv("FC_RH_WGS") ? atoi(getenv("FC_RH_WGS")) : 0;
