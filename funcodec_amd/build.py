@@ -37,6 +37,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
            "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if timeline:
         cmd.insert(1, "-DFC_TIMELINE")
+    for flag in os.environ.get("FC_BUILD_DEFINES", "").split():      # tuning aid: experimental -D switches into a separate file
+        cmd.insert(1, "-D" + flag)
+    if os.environ.get("FC_BUILD_OUT"):
+        out = os.environ["FC_BUILD_OUT"]
+        cmd[cmd.index("-o") + 1] = out
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

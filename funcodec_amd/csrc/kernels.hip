@@ -135,7 +135,11 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     constexpr bool ELU = MODE == 2 || MODE == 4;
     // which role streams the weight chunks: the staging waves when they have no prologue math (PLAIN), else the matrix
     // waves, one DMA piece per loop trip (measured: each choice loses 5-8 % on the other kind of layer)
+#ifdef FC_EXP_MATRIX_DMA
+    constexpr bool STAGING_DMA = false;
+#else
     constexpr bool STAGING_DMA = PLAIN;
+#endif
     constexpr bool DEEP = PLAIN;                      // two register sets of staged input in flight
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int XSF = p.xsf;                            // floats per slab buffer (host: image + pad, see make_args)
@@ -216,15 +220,20 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             // ---------------------------------------------------------------------------------------------
             typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
             constexpr int LPR = BN / 4, RPI = 64 / LPR, RPR = 4 * RPI;     // lanes per row, rows per instruction / round
-            constexpr int MAXR = DUAL ? 4 : 8;
-            const int NR = p.CC / RPR;                     // rounds per item (host: 1 <= NR <= MAXR)
+            // rounds per item: a compile-time constant in the specialised instantiations (NU = 2 / 4 / 8 here) so that the loads
+            // of an item are straight-line code.  With a run-time count every load sat behind its own scalar branch, the loaded
+            // registers became loop phis, and hipcc copied them (after an s_waitcnt vmcnt(0)) right behind the load issue: the
+            // "prefetch" was waited for before the barrier of the same step.  NU = 1: generic fallback (run-time count).
+            constexpr bool RFIX = NU > 1;
+            constexpr int MAXR = RFIX ? NU : (DUAL ? 4 : 8);
+            const int NR = RFIX ? NU : p.CC / RPR;         // host: 1 <= NR <= MAXR
             const int rsub = wid * RPI + lane / LPR;       // my row inside a round
             const int c4 = lane % LPR;                     // my 4-column group
             const unsigned slot0 = 4u * (unsigned)(rsub * p.rowStride + 4 * c4);
             const unsigned lds_round = 4u * (unsigned)(RPR * p.rowStride);
             const size_t src_round = (size_t)RPR * p.Tin;  // floats between the rows of consecutive rounds
             const int km1 = p.slabW - BN;                  // tail columns of a row: (k - 1) * dilation
-            const bool has_tail = rtid < p.CC * km1;
+            const bool has_tail = rtid < p.CC * km1;       // lanes without a tail element re-read their first main element (unconditional load)
             const int t_cl = has_tail ? rtid / km1 : 0, t_j = has_tail ? rtid - t_cl * km1 : 0;
             const unsigned t_slot = 4u * (unsigned)(t_cl * p.rowStride + BN + t_j);
             // per-tile state of the item being LOADED, and of the registers waiting to be written
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 ld_edge = !(tbase >= 0 && tbase + p.slabW <= p.Tin);
                 if (!ld_edge) {
                     src_off = 4u * (unsigned)(rsub * p.Tin + tbase + 4 * c4);
-                    t_off = 4u * (unsigned)(t_cl * p.Tin + tbase + BN + t_j);
+                    t_off = has_tail ? 4u * (unsigned)(t_cl * p.Tin + tbase + BN + t_j) : src_off;
                     t_ok = true;
                 } else {
                     emask = 0;
@@ -258,8 +267,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         eoff[j] = 4u * (unsigned)(rsub * p.Tin + src);
                         emask |= (ok ? 1u : 0u) << j;
                     }
-                    const int src = resolve(tbase + BN + t_j, t_ok);
-                    t_off = 4u * (unsigned)(t_cl * p.Tin + src);
+                    const int src = resolve(has_tail ? tbase + BN + t_j : tbase + 4 * c4, t_ok);
+                    t_off = 4u * (unsigned)((has_tail ? t_cl : rsub) * p.Tin + src);
                 }
             };
             auto load_slab = [&]() __attribute__((always_inline)) {
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 if (!ld_edge) {
 #pragma unroll
                     for (int r = 0; r < MAXR; ++r) {
-                        if (r < NR) {
+                        if (RFIX || r < NR) {
                             v0[r] = *(const f32x4u*)((const char*)(r0 + r * src_round) + src_off);
                             if (DUAL) v1[r] = *(const f32x4u*)((const char*)(r1 + r * src_round) + src_off);
                         }
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 } else {
 #pragma unroll
                     for (int r = 0; r < MAXR; ++r) {
-                        if (r < NR) {
+                        if (RFIX || r < NR) {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 v0[r][j] = *(const float*)((const char*)(r0 + r * src_round) + eoff[j]);
@@ -291,10 +300,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         }
                     }
                 }
-                if (has_tail) {
-                    tv0 = *(const float*)((const char*)r0 + t_off);
-                    if (DUAL) tv1 = *(const float*)((const char*)r1 + t_off);
-                }
+                tv0 = *(const float*)((const char*)r0 + t_off);
+                if (DUAL) tv1 = *(const float*)((const char*)r1 + t_off);
             };
             auto prologue = [&](float v, float w, float2 a, float2 a1) __attribute__((always_inline)) {
                 if (PLAIN) return v;
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 if (!PLAIN) {                             // all table reads ahead of the stores (possible aliasing)
 #pragma unroll
                     for (int r = 0; r < MAXR; ++r) {
-                        if (r < NR) {
+                        if (RFIX || r < NR) {
                             a[r] = tab0[c0 + r * RPR + rsub];
                             if (DUAL) a1[r] = tab1[c0 + r * RPR + rsub];
                         }
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 }
 #pragma unroll
                 for (int r = 0; r < MAXR; ++r) {
-                    if (r < NR) {
+                    if (RFIX || r < NR) {
                         f32x4 v;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -852,7 +859,15 @@ static int conv_nu_for(int total, int mode) {
 
 template <int BM, int BN, int WM, int WN, int MODE>
 static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t lds, hipStream_t st) {
-    if (a.row) return launch_conv_k<BM, BN, WM, WN, MODE, 8, true>(a, grid, lds, st);
+    if (a.row) {   // row staging: NU = rounds per item (2 / 4 / 8 specialised, 1 = run-time count)
+        const int nr = a.CC / (4 * (64 / (BN / 4)));
+        if (nr == 2) return launch_conv_k<BM, BN, WM, WN, MODE, 2, true>(a, grid, lds, st);
+        if (nr == 4) return launch_conv_k<BM, BN, WM, WN, MODE, 4, true>(a, grid, lds, st);
+        if constexpr (MODE < 3) {
+            if (nr == 8) return launch_conv_k<BM, BN, WM, WN, MODE, 8, true>(a, grid, lds, st);
+        }
+        return launch_conv_k<BM, BN, WM, WN, MODE, 1, true>(a, grid, lds, st);
+    }
     const int nu = conv_nu_for(total, MODE);
     if (nu == 5) return launch_conv_k<BM, BN, WM, WN, MODE, 5, false>(a, grid, lds, st);
     if (nu == 9) return launch_conv_k<BM, BN, WM, WN, MODE, 9, false>(a, grid, lds, st);
@@ -883,7 +898,12 @@ void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row) {
     if (c.s1.ptr) *mode = c.elu ? 4 : 3;
     else if (c.s0.aff || c.s0.div || c.elu) *mode = c.elu ? 2 : 1;
     else *mode = 0;
-    *nu = a.row ? 8 : conv_nu_for(a.CC * a.rowStride, *mode);
+    if (a.row) {
+        const int nr = a.CC / (4 * (64 / (c.BN / 4)));
+        *nu = (nr == 2 || nr == 4 || (nr == 8 && *mode < 3)) ? nr : 1;
+    } else {
+        *nu = conv_nu_for(a.CC * a.rowStride, *mode);
+    }
 }
 
 static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st);
