@@ -1,6 +1,12 @@
-"""Build the gfx950 shared library in-tree (hipcc cross-compiles without a GPU)."""
+"""Build the gfx950 shared library in-tree (hipcc cross-compiles without a GPU).
+
+The conv kernel template is instantiated in one translation unit per tile shape (csrc/conv_tile_*.hip); all
+translation units compile in parallel and are linked into ONE library, funcodec_amd/libfuncodec_amd.so.
+"""
 from __future__ import annotations
 
+import concurrent.futures
+import glob
 import os
 import shutil
 import subprocess
@@ -8,8 +14,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libfuncodec_amd.so")
-SOURCES = ["kernels.hip", "engine.hip"]
-HEADERS = ["kernels.h", os.path.join("..", "..", "include", "funcodec_amd.h")]
+OBJ_DIR = os.path.join(CSRC, "_obj")
+HEADERS = ["kernels.h", "conv_kernel.h", os.path.join("..", "..", "include", "funcodec_amd.h")]
+
+
+def sources():
+    return ["kernels.hip", "engine.hip"] + sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "conv_tile_*.hip")))
 
 
 def _hipcc() -> str:
@@ -23,7 +33,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in sources() + HEADERS]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -31,20 +41,37 @@ def build(force: bool = False, verbose: bool = False) -> str:
     timeline = bool(os.environ.get("FC_TIMELINE"))
     # profiling build (phase timestamps inside the conv kernel, fc_debug_timeline): a SEPARATE file, selected with FC_LIB=<path>
     out = LIB_PATH.replace(".so", "_timeline.so") if timeline else LIB_PATH
-    if not force and not timeline and not needs_build():
-        return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
-    if timeline:
-        cmd.insert(1, "-DFC_TIMELINE")
-    for flag in os.environ.get("FC_BUILD_DEFINES", "").split():      # tuning aid: experimental -D switches into a separate file
-        cmd.insert(1, "-D" + flag)
+    defines = ["-DFC_TIMELINE"] if timeline else []
+    defines += ["-D" + f for f in os.environ.get("FC_BUILD_DEFINES", "").split()]      # tuning aid: experimental -D switches
     if os.environ.get("FC_BUILD_OUT"):
         out = os.environ["FC_BUILD_OUT"]
-        cmd[cmd.index("-o") + 1] = out
+    if not force and not defines and out == LIB_PATH and not needs_build():
+        return LIB_PATH
+    tag = "".join(c if c.isalnum() else "_" for c in os.path.basename(out))
+    obj_dir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = _hipcc()
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + defines
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            return obj
+        cmd = base + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    srcs = sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True)
     return out
 
 

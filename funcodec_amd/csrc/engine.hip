@@ -337,6 +337,8 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     if (L.M > 64) {
         L.BM = 128; L.BN = 128;
         if (L.small_n && L.M <= 256) { L.BM = 32; L.BN = 128; }   // too few 128x128 tiles at the bottleneck rate
+        // (256 x 128 tiles -- one 8-wave workgroup per CU, the slab staged once per 256 rows -- were measured in round 2: every layer
+        // slower, 18.1 vs 16.9 ms per step.  Two workgroups per CU covering each other's barriers are worth more than the halved staging.)
     } else if (L.M > 32) { L.BM = 64; L.BN = 256; }
     else { L.BM = 32; L.BN = 256; }
     // channels per K-chunk: as many as fit (a) the register-staged slab, (b) K-chunk <= 64, (c) half of the LDS
@@ -626,8 +628,8 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
             int row = 0;
             fc::conv_variant(c, &mode, &nu, &row);
             char nm[64];
-            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM == 128 ? 2 : 1,
-                     L.BM == 128 ? 2 : 4, mode, nu, row ? "true" : "false");
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1,
+                     L.BM >= 128 ? 2 : 4, mode, nu, row ? "true" : "false");
             if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s>", c.k, c.s1.ptr ? "true" : "false");
             cls = e->prof_class(nm);
         }
