@@ -8,7 +8,7 @@
 One "step" = one Speech2Token(run_mod="inference") pass (encode -> 32-stage RVQ -> decode) over this rank's utterances of
 synthetic 10 s / 16 kHz audio on the 16k-nq32ds640 architecture:
   N = 1: BASELINE.json configs[1], 16 x 10 s in ONE engine call;
-  N > 1: BASELINE.json configs[2], 128 utterances per GPU (1024 at N = 8) walked in micro-batches of 16 (every op of the path is
+  N > 1: BASELINE.json configs[2], 128 utterances per GPU (1024 at N = 8) walked in micro-batches of 32 (every op of the path is
          per-utterance, results do not depend on the micro-batch), the int64 code indices all-gathered over RCCL inside the step.
 Inputs are resident in HBM when timing starts.  The timed region runs WITHOUT the in-engine HIP-event brackets; the per-kernel
 table (and with it `roofline`) comes from a second, separate pass of the same step.  Rank 0 prints ONE JSON line.
@@ -25,7 +25,10 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-MICRO_BATCH = 16
+# utterances per engine call.  N = 1 is Config B itself (16 utterances, one call).  For N > 1 (Config C, 128 per GPU) the micro-batch
+# is free (every op is per-utterance): 32 lets the persistent LSTM run two batch tiles per recurrence step (its per-step exchange
+# latency is paid once for 32 utterances) and doubles the tile count of the layers at the bottleneck frame rate.
+MICRO_BATCH = int(os.environ.get("FC_BENCH_MICRO", "0")) or (16 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 32)
 SAMPLES = 160000
 CONFIG = os.environ.get("FC_BENCH_CONFIG", "ds640")   # the contract metric is ds640; other recipes only for side measurements
 PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix (= vector) peak
@@ -176,6 +179,7 @@ def main():
     model = EncodecMI355X(arch, f"cuda:{local_rank}")
     model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(arch, 0).items()})
     eng = model.engine
+    eng.micro_batch = max(eng.micro_batch, MICRO_BATCH)      # one engine call per bench micro-batch
 
     # N = 1: Config B (16 utterances, one engine call).  N > 1: Config C (128 utterances per GPU, micro-batches of 16).
     utts_per_gpu = int(os.environ.get("FC_BENCH_UTTS", MICRO_BATCH if world == 1 else 128))

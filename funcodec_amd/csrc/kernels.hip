@@ -910,8 +910,11 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
                                                          int ablate) {
     constexpr int NQ4 = D / 16;
     constexpr int ROWS = 16 * RS;
-    __shared__ __attribute__((aligned(16))) float R[ROWS][D];
-    __shared__ __attribute__((aligned(16))) float Q[ROWS][D];
+    // residual rows, padded by 4 floats: the |x|^2 chains read R[r][32 j + i] from 64 lanes (r, j) at once -- with a row stride of
+    // D every lane hit the same bank (32-way conflict, ~1 us per stage); stride D + 4 spreads the 8 rows of a lane group over 8 banks
+    __shared__ __attribute__((aligned(16))) float R[ROWS][D + 4];
+    constexpr int NEL = (ROWS * D + 511) / 512;                // elements of the row set owned by one thread: e = tid + 512 * it
+    float qreg[NEL];                                    // running sum of the selected code rows (was an LDS array)
     __shared__ float xn[ROWS];
     __shared__ float bestv[8][ROWS];
     __shared__ int besti[8][ROWS];
@@ -925,8 +928,9 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
         const int r = e / D, d = e - r * D;
         const int n = row0 + r;
         R[r][d] = n < N ? x[(size_t)n * D + d] : 0.f;
-        Q[r][d] = 0.f;
     }
+#pragma unroll
+    for (int it = 0; it < NEL; ++it) qreg[it] = 0.f;
     const int codes_per_wave = (K >> 3) < 16 ? 16 : (K >> 3);   // 8 waves: two per SIMD hide the codebook-row load latency
     const bool wactive = wid * codes_per_wave < K;            // small codebooks keep only K/16 waves busy
 
@@ -1042,25 +1046,34 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
             if (row0 + tid < N) codes[(size_t)i * N + row0 + tid] = (int64_t)bi;
         }
         __syncthreads();
-        for (int e = tid; e < ROWS * D; e += 512) {
-            const int r = e / D, d = e - r * D;
-            const float qv = (ablate & 8) ? 0.001f : cbi[(size_t)sel[r] * D + d];
-            R[r][d] = R[r][d] - qv;
-            Q[r][d] = Q[r][d] + qv;
+        // gather the selected code rows: all loads first (they are independent), then the LDS / register updates
+        float qv[NEL];
+#pragma unroll
+        for (int it = 0; it < NEL; ++it) {
+            const int e = tid + 512 * it, r = e / D, d = e - r * D;
+            qv[it] = 0.f;
+            if (ROWS * D % 512 == 0 || e < ROWS * D) qv[it] = (ablate & 8) ? 0.001f : cbi[(size_t)sel[r] * D + d];
+        }
+#pragma unroll
+        for (int it = 0; it < NEL; ++it) {
+            const int e = tid + 512 * it, r = e / D, d = e - r * D;
+            if (ROWS * D % 512 != 0 && e >= ROWS * D) continue;
+            R[r][d] = R[r][d] - qv[it];
+            qreg[it] = qreg[it] + qv[it];
             const int n = row0 + r;
             if (subq && n < N && !(ablate & 4)) {
                 const int bb = n / Tf, t = n - bb * Tf;
                 const int Bn = N / Tf;
-                subq[(((size_t)i * Bn + bb) * D + d) * Tf + t] = qv;
+                subq[(((size_t)i * Bn + bb) * D + d) * Tf + t] = qv[it];
             }
         }
     }
-    __syncthreads();
-    for (int e = tid; e < ROWS * D; e += 512) {
-        const int r = e / D, d = e - r * D;
+#pragma unroll
+    for (int it = 0; it < NEL; ++it) {
+        const int e = tid + 512 * it, r = e / D, d = e - r * D;
         const int n = row0 + r;
-        if (n >= N) continue;
-        const float v = Q[r][d];
+        if (n >= N || (ROWS * D % 512 != 0 && e >= ROWS * D)) continue;
+        const float v = qreg[it];
         if (quant) quant[(size_t)n * D + d] = v;
         if (quant_bdt) {
             const int bb = n / Tf, t = n - bb * Tf;

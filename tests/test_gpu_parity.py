@@ -410,7 +410,8 @@ def test_staging_scheme_and_workgroup_count_do_not_change_results():
     assert rms(outs["base"]["recon"], outs["norow"]["recon"]) < WAV_RMS_TOL
 
 
-@pytest.mark.parametrize("cfg_name,seed,B,T", [("tiny", 7, 3, 9), ("tiny", 7, 17, 4), ("ds640", 0, 2, 9), ("ds320", 0, 33, 3)])
+@pytest.mark.parametrize("cfg_name,seed,B,T", [("tiny", 7, 3, 9), ("tiny", 7, 17, 4), ("ds640", 0, 2, 9), ("ds320", 0, 33, 3),
+                                                ("ds640", 0, 32, 7), ("ds320", 0, 20, 11)])     # two batch tiles in the persistent kernel
 def test_lstm_against_torch_cpu(cfg_name, seed, B, T):
     m = engine_for(cfg_name, seed)
     orc = oracle_for(cfg_name, seed)
