@@ -34,6 +34,7 @@ CONFIG = os.environ.get("FC_BENCH_CONFIG", "ds640")   # the contract metric is d
 PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix (= vector) peak
 PEAK_HBM_TBS = 8.0
 RIDGE = PEAK_F32_TFLOPS / PEAK_HBM_TBS      # FLOP per byte above which the fp32 roof is the tighter one
+CONV_CLASSES = ("conv_", "reshead_")        # kernel classes of the Conv1d / ConvTranspose1d layers (fc_engine_profile names)
 
 
 def physical_cores() -> int:
@@ -278,7 +279,7 @@ def main():
                 gbs = p["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 and p["bytes"] else None
                 # which roof binds this class: algorithmic intensity against the ridge (157.3 TF / 8 TB/s = 19.7 FLOP/B)
                 bound = None
-                if p["bytes"] and p["kernel"].startswith("conv_"):
+                if p["bytes"] and p["kernel"].startswith(CONV_CLASSES):
                     bound = "mfma" if p["flops"] / p["bytes"] >= RIDGE else "hbm"
                 kern.append({"kernel": p["kernel"], "launches_per_step": p["launches"] // prof_steps,
                              "ms_per_step": round(ms / prof_steps, 3),
@@ -288,10 +289,10 @@ def main():
                              "bound": bound,
                              "f32_frac": round(tfl / PEAK_F32_TFLOPS, 4) if tfl else None,
                              "hbm_frac": round(gbs / 1e3 / PEAK_HBM_TBS, 4) if gbs else None})
-            convs = [k for k in kern if k["kernel"].startswith("conv_")]
+            convs = [k for k in kern if k["kernel"].startswith(CONV_CLASSES)]
             dom = max((k for k in convs if k["bound"] != "hbm"), key=lambda k: k["ms_per_step"])
             conv_ms = sum(k["ms_per_step"] for k in convs)
-            conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith("conv_")) / prof_steps
+            conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith(CONV_CLASSES)) / prof_steps
             traffic = pmc_traffic(dom["kernel"])
             out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",

@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/rp -o out --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rp.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/pmc_write.err
