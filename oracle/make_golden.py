@@ -82,6 +82,11 @@ CASES = [
 # cases stored without the decode-path waveform (file size): indices, scale, encoder output (the tie proof of the parity tests
 # needs it), quantized, recon
 SLIM = {"ds640_b2_t160000", "ds640_wav_jamendo_0027"}
+# FreqCodec (STFT-domain 2-D SEANet): (name, config, weight seed, audio kind, audio seed, B, T)
+FREQ_CASES = [
+    ("tinyfreq_b2_t2000", "tinyfreq", 3, "tones", 81, 2, 2000),
+    ("freqmp_b1_t16000", "freqmp", 0, "noise", 82, 1, 16000),
+]
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [
     ("ds320seg_b2_t20000", "ds320seg", 0, "tones", 41, 2, 20000),
@@ -227,6 +232,48 @@ def main():
                                 indices=oi.numpy().astype(np.int16), quantized=qo.permute(0, 2, 1).numpy())
             manifest["cases"][name] = dict(kind="rvq_noddp", codebook_decay=1.0, seed=seed, rows=[4, 125], n_q=nq)
             print(f"[golden] {name}: core_vq.ResidualVectorQuantization (use_ddp: false), oracle==reference OK")
+        # ---- FreqCodec: oracle/freq_oracle.py pinned against the real reference.  The engine does not run
+        # this path yet; these fixtures are the oracle-first step for it.
+        for name, cfg_name, wseed, akind, aseed, B, T in FREQ_CASES:
+            if only is not None and name not in only:
+                continue
+            ref_shim.install_torchaudio_transforms()
+            import yaml
+            from freq_oracle import FreqOracle
+            from freq_synth import freq_recipe_config, make_freq_state_dict
+            from funcodec.bin.codec_inference import Speech2Token
+            cfg = freq_recipe_config(cfg_name)
+            sd = make_freq_state_dict(cfg, wseed)
+            d = os.path.join(tmp, f"{cfg_name}_{wseed}")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "config.yaml"), "wt") as f:
+                yaml.safe_dump(reference_config(cfg), f)
+            torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, os.path.join(d, "model.pth"))
+            s2t = Speech2Token(os.path.join(d, "config.yaml"), os.path.join(d, "model.pth"), device="cpu")
+            ref_sd = s2t.model.state_dict()
+            for k, v in sd.items():
+                assert k in ref_sd and torch.equal(ref_sd[k], torch.from_numpy(v)), f"{k} not loaded by the reference"
+            for k in ref_sd:
+                if k.startswith(("encoder.", "decoder.", "quantizer.")):
+                    assert k in sd, f"reference key {k} missing from the synthetic checkpoint"
+            x = torch.from_numpy(synthetic_audio(B, T, aseed, akind))
+            idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=None, use_scale=True, run_mod="inference")
+            with torch.no_grad():
+                emb_ref, scale_ref = s2t.model._encode_frame(x.unsqueeze(1))
+            orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
+            o = orc.inference(x, None, True)
+            assert torch.equal(o["encoder_out"], emb_ref), f"{name}: oracle encoder != reference"
+            assert torch.equal(o["code_indices"][0], idx[0]), f"{name}: oracle indices != reference"
+            assert torch.equal(o["code_embeddings"][0][0], embs[0][0]), f"{name}: oracle quantized != reference"
+            assert torch.equal(o["recon_speech"], recon), f"{name}: oracle recon != reference"
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), indices=idx[0].numpy().astype(np.int16),
+                                encoder_out=emb_ref.numpy(), scale=scale_ref.numpy(), quantized=embs[0][0].numpy(),
+                                recon=recon.numpy())
+            manifest["cases"][name] = dict(kind="freq", config=cfg_name, weight_seed=wseed, codebook_decay=1.0, audio_kind=akind,
+                                           audio_seed=aseed, batch=B, samples=T, bit_width=None, n_q=int(idx[0].shape[0]),
+                                           frames=int(idx[0].shape[2]),
+                                           note="torchaudio Spectrogram / InverseSpectrogram restated over torch.stft / istft (oracle/ref_shim.py)")
+            print(f"[golden] {name}: FreqCodec idx{tuple(idx[0].shape)} recon{tuple(recon.shape)} oracle==reference OK")
         if only is not None:
             old = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
             old["cases"].update(manifest["cases"])

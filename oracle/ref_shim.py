@@ -43,6 +43,50 @@ class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return None
 
 
+def install_torchaudio_transforms():
+    """FreqCodec builds `torchaudio.transforms.Spectrogram / InverseSpectrogram` (codec_freq.py:185-210).  torchaudio is a stub
+    in this image, so the two transforms are provided here exactly as torchaudio publishes them: thin wrappers over `torch.stft`
+    / `torch.istft` (center=True, pad_mode="reflect", periodic Hann window of win_length = n_fft, normalized=False,
+    onesided=True).  The FreqCodec goldens are therefore pinned to the reference's own code over THIS restatement of the
+    third-party transform (said so in tests/golden/MANIFEST.json)."""
+    import torch
+    import torchaudio
+
+    class Spectrogram(torch.nn.Module):
+        def __init__(self, n_fft=400, win_length=None, hop_length=None, pad=0, power=2.0, normalized=False, center=True,
+                     pad_mode="reflect", onesided=True, **_):
+            super().__init__()
+            self.n_fft, self.win_length = n_fft, win_length or n_fft
+            self.hop_length, self.power = hop_length or self.win_length // 2, power
+            self.register_buffer("window", torch.hann_window(self.win_length), persistent=False)
+
+        def forward(self, x):
+            shape = x.shape
+            s = torch.stft(x.reshape(-1, shape[-1]), self.n_fft, self.hop_length, self.win_length, self.window, center=True,
+                           pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+            s = s.reshape(shape[:-1] + s.shape[-2:])
+            if self.power is None:
+                return s
+            return s.abs() if self.power == 1 else s.abs().pow(self.power)
+
+    class InverseSpectrogram(torch.nn.Module):
+        def __init__(self, n_fft=400, win_length=None, hop_length=None, pad=0, normalized=False, center=True,
+                     pad_mode="reflect", onesided=True, **_):
+            super().__init__()
+            self.n_fft, self.win_length = n_fft, win_length or n_fft
+            self.hop_length = hop_length or self.win_length // 2
+            self.register_buffer("window", torch.hann_window(self.win_length), persistent=False)
+
+        def forward(self, s, length=None):
+            shape = s.shape
+            w = torch.istft(s.reshape(-1, shape[-2], shape[-1]), self.n_fft, self.hop_length, self.win_length, self.window,
+                            center=True, normalized=False, onesided=True, length=length, return_complex=False)
+            return w.reshape(shape[:-2] + w.shape[-1:])
+
+    torchaudio.transforms.Spectrogram = Spectrogram
+    torchaudio.transforms.InverseSpectrogram = InverseSpectrogram
+
+
 def available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "funcodec"))
 

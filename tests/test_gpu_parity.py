@@ -12,7 +12,7 @@ from helpers import (audio, engine_for, golden, index_report, manifest, oracle_f
 
 pytestmark = pytest.mark.gpu
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 
 # tolerances (north_star): integer codec indices bit-exact; waveforms within 1e-4 RMS

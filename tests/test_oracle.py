@@ -7,7 +7,7 @@ import torch
 from helpers import audio, golden, index_report, manifest, oracle_for, rms
 
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 SAME_BUILD = torch.__version__ == MAN["torch"]
 
@@ -52,6 +52,30 @@ def test_c_oracle_rvq_matches_the_use_ddp_false_reference_quantiser():
     codes, quant = c_oracle.rvq_encode(z.reshape(-1, 128)[rows], embed, c["n_q"])
     assert np.array_equal(codes, g["indices"].astype(np.int64).reshape(c["n_q"], -1)[:, rows])
     assert np.array_equal(quant, g["quantized"].reshape(-1, 128)[rows])
+
+
+@pytest.mark.parametrize("name", [n for n, c in MAN["cases"].items() if c.get("kind") == "freq"])
+def test_freq_oracle_matches_reference_golden(name):
+    """FreqCodec (STFT-domain 2-D SEANet): the restatement oracle/freq_oracle.py against the real reference's
+    outputs.  Oracle-first step for that row: the engine does not run this path yet (config.py refuses `model: freq_codec`)."""
+    from freq_oracle import FreqOracle
+    from freq_synth import freq_recipe_config, make_freq_state_dict
+    c = MAN["cases"][name]
+    cfg = freq_recipe_config(c["config"])
+    orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, c["weight_seed"]).items()})
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    g = golden(name)
+    o = orc.inference(wav, None, True)
+    assert o["features"].shape[1:3] == (3, 257)
+    assert rms(o["encoder_out"], g["encoder_out"]) < 1e-5 and rms(o["recon_speech"], g["recon"]) < 1e-4
+    rep = index_report(o["code_indices"][0], g["indices"].astype(np.int64))
+    if SAME_BUILD and torch.get_num_threads() == MAN["threads"]:
+        assert rep["mismatched_indices"] == 0 and np.array_equal(o["recon_speech"].numpy(), g["recon"])
+    else:
+        assert rep["frames_bad"] <= max(1, rep["frames"] // 50)
+    from funcodec_amd.config import arch_from_config
+    with pytest.raises(NotImplementedError):
+        arch_from_config(cfg)                      # refused, not mis-decoded, until the kernels exist
 
 
 @pytest.mark.parametrize("name", SEG)
