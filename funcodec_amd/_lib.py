@@ -7,7 +7,7 @@ import os
 from . import build as _build
 
 FC_MAX_RATIOS = 8
-FC_ABI_VERSION = 3
+FC_ABI_VERSION = 4
 
 
 class FcArch(C.Structure):
@@ -20,6 +20,8 @@ class FcArch(C.Structure):
         ("elu_alpha", C.c_float), ("gn_eps", C.c_float),
         ("codebook_size", C.c_int32), ("num_quantizers", C.c_int32),
         ("norm_type", C.c_int32), ("causal", C.c_int32), ("n_residual_layers", C.c_int32), ("dilation_base", C.c_int32),
+        ("model_type", C.c_int32), ("input_channels", C.c_int32), ("n_fft", C.c_int32), ("stft_hop", C.c_int32),
+        ("ratios_f", C.c_int32 * FC_MAX_RATIOS),
     ]
 
 
@@ -49,6 +51,7 @@ SYMBOLS = {
     "fc_engine_finalize": (C.c_int, [_P]),
     "fc_engine_hop_length": (C.c_int, [_P]),
     "fc_engine_frames": (C.c_int, [_P, C.c_int]),
+    "fc_engine_decoded_samples": (C.c_int, [_P, C.c_int]),
     "fc_engine_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "fc_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "fc_decode_emb": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),

@@ -51,6 +51,12 @@ class ArchSpec:
     # Encodec framing (codec_basic.py:288-298): None = one frame; else frames of segment_dur seconds, hop (1-overlap)*length
     segment_dur: Optional[float] = None
     overlap_ratio: float = 0.01
+    # STFT-domain codec (model: freq_codec, codec_freq.py:123-210; 2-D SEANet, seanet_encoder.py:252-363): `ratios` then holds
+    # the TIME ratios and `ratios_f` the frequency ratios of the stages (decoder order)
+    model_type: str = "encodec"                   # "encodec" | "freq_codec" (codec_domain [mag_phase, mag_phase])
+    ratios_f: Tuple[int, ...] = ()
+    n_fft: int = 512
+    stft_hop: int = 160
 
     @property
     def segment_length(self) -> Optional[int]:
@@ -63,7 +69,7 @@ class ArchSpec:
 
     @property
     def hop_length(self) -> int:
-        return int(math.prod(self.ratios))
+        return int(math.prod(self.ratios)) * (self.stft_hop if self.model_type == "freq_codec" else 1)
 
     @property
     def n_stages(self) -> int:
@@ -84,6 +90,8 @@ class ArchSpec:
     def frames_for(self, n_samples: int) -> int:
         """Number of codec frames the encoder emits for ``n_samples`` (ceil at every stride)."""
         t = n_samples
+        if self.model_type == "freq_codec":
+            t = 1 + t // self.stft_hop            # torch.stft, center=True
         for r in reversed(self.ratios):
             t = -(-t // r)
         return t
@@ -126,8 +134,78 @@ def _check_seanet_conf(conf: Dict[str, Any], which: str) -> Dict[str, Any]:
     return conf
 
 
+def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
+    """``model: freq_codec`` (FreqCodec, codec_freq.py:123-210) with the 2-D SEANet nets; only the recipe's
+    ``codec_domain: [mag_phase, mag_phase]`` over a GroupNorm, non-causal, un-grouped net is built."""
+    if cfg.get("encoder") != "encodec_seanet_encoder_2d" or cfg.get("decoder") != "encodec_seanet_decoder_2d":
+        raise _unsupported("encoder/decoder", (cfg.get("encoder"), cfg.get("decoder")), "freq_codec needs the 2-D SEANet nets")
+    if cfg.get("quantizer", "costume_quantizer") != "costume_quantizer":
+        raise _unsupported("quantizer", cfg.get("quantizer"))
+    enc, dec = dict(cfg.get("encoder_conf", {}) or {}), dict(cfg.get("decoder_conf", {}) or {})
+    q, m = dict(cfg.get("quantizer_conf", {}) or {}), dict(cfg.get("model_conf", {}) or {})
+    for which, conf in (("encoder_conf", enc), ("decoder_conf", dec)):
+        if conf.get("norm", "weight_norm") != "time_group_norm" or conf.get("causal", False):
+            raise _unsupported(f"{which}.norm/causal", (conf.get("norm", "weight_norm"), conf.get("causal", False)), "GroupNorm non-causal only")
+        if dict(conf.get("norm_params", {}) or {}).get("num_groups", 1) != 1:
+            raise _unsupported(f"{which}.norm_params.num_groups", conf["norm_params"]["num_groups"])
+        for key, ok in (("conv_group_ratio", -1), ("tr_conv_group_ratio", -1), ("true_skip", False), ("pad_mode", "reflect"),
+                        ("activation", "ELU"), ("seq_model", "lstm"), ("final_activation", None), ("trim_right_ratio", 1.0)):
+            if conf.get(key, ok) != ok:
+                raise _unsupported(f"{which}.{key}", conf[key])
+    if list(m.get("codec_domain", ["time", "time"])) != ["mag_phase", "mag_phase"]:
+        raise _unsupported("model_conf.codec_domain", m.get("codec_domain"), "only [mag_phase, mag_phase] is built")
+    if m.get("bypass_quantizer", False):
+        raise _unsupported("model_conf.bypass_quantizer", True)
+    if cfg.get("input_size", 1) != 3 or dec.get("channels", 1) != 3:
+        raise _unsupported("input_size/channels", (cfg.get("input_size", 1), dec.get("channels", 1)), "3 = log-magnitude, phase re, phase im")
+
+    def shared(key, default):
+        a, b = enc.get(key, default), dec.get(key, default)
+        if key == "ratios":
+            a, b = [list(r) for r in a], [list(r) for r in b]
+        if a != b:
+            raise _unsupported(f"encoder_conf.{key} != decoder_conf.{key}", (a, b))
+        return a
+
+    ratios2 = shared("ratios", [[4, 1], [4, 1], [4, 2], [4, 1]])
+    dimension = int(enc.get("dimension", 128))
+    if q.get("codec_dim", None) not in (None, dimension) or q.get("codec_range", None) is not None or q.get("q0_ds_ratio", 1) != 1:
+        raise _unsupported("quantizer_conf.codec_dim/codec_range/q0_ds_ratio", (q.get("codec_dim"), q.get("codec_range"), q.get("q0_ds_ratio")))
+    if int(shared("n_residual_layers", 1)) != 1 and int(shared("dilation_base", 2)) != 1:
+        raise _unsupported("n_residual_layers/dilation_base", (enc.get("n_residual_layers"), enc.get("dilation_base")))
+    dc = dict(m.get("domain_conf", {}) or {})
+    seg = m["segment_dur"] if "segment_dur" in m else 1.0
+    if seg is not None:
+        raise _unsupported("model_conf.segment_dur", seg, "segmented mode is not built for freq_codec")
+    act_params = dict(shared("activation_params", {"alpha": 1.0}) or {})
+    norm_params = dict(shared("norm_params", {}) or {})
+    arch = ArchSpec(
+        sample_rate=int(m.get("target_sample_hz", 24000)), input_channels=3,
+        audio_normalize=bool(m.get("audio_normalize", False)),            # FreqCodec.__init__ default is False (codec_freq.py:141)
+        n_filters=int(shared("n_filters", 32)), dimension=dimension,
+        ratios=tuple(int(r[1]) for r in ratios2), ratios_f=tuple(int(r[0]) for r in ratios2),
+        kernel_size=int(shared("kernel_size", 7)), last_kernel_size=int(shared("last_kernel_size", 7)),
+        residual_kernel_size=int(shared("residual_kernel_size", 3)), n_residual_layers=int(shared("n_residual_layers", 1)),
+        dilation_base=int(shared("dilation_base", 2)), compress=int(shared("compress", 2)),
+        lstm_layers=int(shared("seq_layer_num", 2)), lstm_skip=bool(shared("res_seq", True)),
+        elu_alpha=float(act_params.get("alpha", 1.0)), gn_eps=float(norm_params.get("eps", 1e-5)),
+        codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=dimension, num_quantizers=int(q.get("num_quantizers", 8)),
+        encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
+        use_ddp=bool(q.get("use_ddp", True)), norm="time_group_norm", causal=False, segment_dur=None,
+        model_type="freq_codec", n_fft=int(dc.get("n_fft", 512)), stft_hop=int(dc.get("hop_length", 160)),
+    )
+    f = arch.n_fft // 2 + 1
+    for fr in reversed(arch.ratios_f):
+        f = (f + fr - 2 * fr) // fr + 1          # SConv2d, kernel 2 fr, stride fr: padding_total = fr, no extra padding in frequency
+    if f != 1:
+        raise _unsupported("encoder_conf.ratios", ratios2, "the frequency ratios must reduce n_fft/2+1 bins to one (ReshapeModule)")
+    return arch
+
+
 def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     """Build an :class:`ArchSpec` from a dict loaded from the reference's ``config.yaml``."""
+    if cfg.get("model", "encodec") == "freq_codec":
+        return _freq_arch_from_config(cfg)
     if cfg.get("model", "encodec") != "encodec":
         raise _unsupported("model", cfg.get("model"))
     if cfg.get("encoder", "encodec_seanet_encoder") != "encodec_seanet_encoder":

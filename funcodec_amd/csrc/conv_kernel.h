@@ -60,6 +60,14 @@ struct ConvArgs {
     const int* koff;        // [koff_n] B-operand LDS float offset per k-step (padded, multiple of 4)
     int koff_n;
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
+    // two-level batch addressing (2-D nets in frequency-major layout [B][F][C][T]: a frequency row of an utterance is one
+    // "virtual utterance" of the 1-D conv): blockIdx.z = breal*Fo + fo.  1-D layers: Fo = 1, in_sB0 = Cin*Tin, affC = Cin.
+    int Fo;                 // virtual utterances (output frequency rows) per real utterance
+    int affC;               // channels of the affine tables (table index = channel % affC)
+    long long in_sB0, in_sB1;     // floats between real utterances / consecutive fo of the inputs
+    long long out_sF;             // floats between consecutive fo of the output (out_sB: between real utterances)
+    long long part_sB0;           // partial (sum, sumsq) pairs between real utterances; fo-th row at fo * nblk
+    int store_lo, store_hi;       // only virtual utterances fo in [store_lo, store_hi) store their outputs (all contribute statistics)
     int ablate;             // profiling aid (FC_ABLATE env): 1 no MFMA, 2 no stores, 4 no slab loads, 16 no weight DMA,
                             // 128 no epilogue.  0 in production.
 };
@@ -158,7 +166,13 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     const int t_begin = (int)(((long long)ntiles * bx) / gridDim.x);
     const int t_end = (int)(((long long)ntiles * (bx + 1)) / gridDim.x);
     if (t_begin >= t_end) return;
-    const size_t rowbase = (size_t)b * p.Cin;
+    const int breal = p.Fo > 1 ? b / p.Fo : b, fo = p.Fo > 1 ? b - breal * p.Fo : 0;
+    const size_t in_off = (size_t)breal * (size_t)p.in_sB0 + (size_t)fo * (size_t)p.in_sB1;
+    const size_t affbase = (size_t)breal * p.affC;
+    const bool store_ok = fo >= p.store_lo && fo < p.store_hi;
+    // wave-uniform bases of this (virtual) utterance, computed once
+    const size_t out_off0 = (size_t)breal * (size_t)p.out_sB + (size_t)fo * (size_t)p.out_sF;
+    const size_t part_off0 = ((size_t)breal * (size_t)p.part_sB0 + (size_t)fo * ((size_t)((p.Tout + BN - 1) / BN) * gridDim.y)) * 2;
     const int nitems = (t_end - t_begin) * p.nchunk;  // flattened (tile, chunk) work items of this workgroup
     const bool resident = p.nchunk <= 2;              // the whole K extent of this M tile stays in LDS
     const float* wt_tile = p.wt + (size_t)mt * p.nchunk * p.Wbuf;
@@ -166,8 +180,9 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     // ---- common prologue: tables -------------------------------------------------------------------
     if (!PLAIN) {   // per-(b, channel) GroupNorm affine of the producers, staged once per workgroup
         for (int c = tid; c < p.Cin; c += 512) {
-            tab0[c] = p.aff0 ? ((const float2*)p.aff0)[rowbase + c] : make_float2(1.f, 0.f);
-            if (DUAL) tab1[c] = p.aff1 ? ((const float2*)p.aff1)[rowbase + c] : make_float2(1.f, 0.f);
+            const int ca = p.affC == p.Cin ? c : c % p.affC;
+            tab0[c] = p.aff0 ? ((const float2*)p.aff0)[affbase + ca] : make_float2(1.f, 0.f);
+            if (DUAL) tab1[c] = p.aff1 ? ((const float2*)p.aff1)[affbase + ca] : make_float2(1.f, 0.f);
         }
     }
     for (int i = tid; i < p.koff_n; i += 512) kofs_i[i] = p.koff[i];
@@ -176,8 +191,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
 
     if (role == 1) {
         // =========================================== staging waves =====================================
-        const float* __restrict__ s0b = p.src0 + rowbase * p.Tin;     // wave-uniform bases, 32-bit lane offsets
-        const float* __restrict__ s1b = DUAL ? p.src1 + rowbase * p.Tin : p.src0;
+        const float* __restrict__ s0b = p.src0 + in_off;              // wave-uniform bases, 32-bit lane offsets
+        const float* __restrict__ s1b = DUAL ? p.src1 + in_off : p.src0;
         // GroupNorm partial of a finished tile: fixed-order fp64 reduction of the 256 per-lane fp32 partials the
         // matrix waves left in LDS (done here because the staging waves idle at the barrier anyway)
         auto flush_stats = [&](int tile) __attribute__((always_inline)) {
@@ -192,8 +207,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 d2 += __shfl_xor(d2, o, 64);
             }
             if (lane == 0) {
-                const int nblk = ntiles * gridDim.y;
-                const size_t slot_p = ((size_t)b * nblk + (size_t)mt * ntiles + tile) * 2;
+                const size_t slot_p = part_off0 + ((size_t)mt * ntiles + tile) * 2;
                 p.partials[slot_p] = d1;
                 p.partials[slot_p + 1] = d2;
             }
@@ -371,7 +385,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             return;
         }
         const int total = p.CC * p.slabW;             // <= 256 * NU
-        const float divv = (MODE == 1 && p.div0) ? p.div0[b] : 1.f;
+        const float divv = (MODE == 1 && p.div0) ? p.div0[breal] : 1.f;
         // element e = rtid + 256*u of every chunk of every tile maps to the same (local channel cl, slab column tau):
         //   base0[u] = cl*Tin + tau      slot[u] = LDS float index | cl << 16
         // Per-element descriptors, all in BYTES and unpacked (every extraction / shift would be a VALU instruction per
@@ -576,14 +590,15 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     // epilogue of one tile: bias, store, per-wave GroupNorm partial statistics into red[par][..]
     auto epilogue = [&](int tile, int par) {
         const int n0 = tile * BN;
-        int m0_l = m0, b_l = b;                        // opaque copies keep the row-pointer math inside the tile loop
-        asm volatile("" : "+s"(m0_l), "+s"(b_l));
+        int m0_l = m0;                                 // opaque copy keeps the row-pointer math inside the tile loop
+        asm volatile("" : "+s"(m0_l));
+        const size_t out_off = out_off0;
         float s1 = 0.f, s2 = 0.f;
-        const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2);
+        const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2) && store_ok;
         if (full) {
             // one 64-bit lane pointer for accumulator row 0; every other row / column tile is a wave-uniform offset
             const size_t sM = (size_t)p.out_sM;
-            const float* __restrict__ row0c = p.out + (size_t)b_l * p.out_sB + (size_t)(n0 + wn * (TN * 32) + l31) +
+            const float* __restrict__ row0c = p.out + out_off + (size_t)(n0 + wn * (TN * 32) + l31) +
                                              (size_t)(m0_l + wm * (TM * 32) + 4 * hi) * sM;
             float* __restrict__ row0 = const_cast<float*>(row0c);
 #pragma unroll
@@ -609,8 +624,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                     const int m = m0_l + ml;
                     if (m >= p.M) continue;
                     int co = m, phs = 0;
-                    if (p.up_r) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }
-                    float* __restrict__ rowp = p.out + (size_t)b_l * p.out_sB + (size_t)co * p.out_sM;
+                    if (p.up_r > 1) { co = (int)__umulhi((unsigned)m, p.magic_r); phs = m - co * p.up_r; }   // up_r == 1: co = m (k = 2, stride 1)
+                    float* __restrict__ rowp = p.out + out_off + (size_t)co * p.out_sM;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         const int n = n0 + wn * (TN * 32) + j * 32 + l31;
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         const float v = acc[i][j][r];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
-                        if (p.ablate & 2) continue;
+                        if ((p.ablate & 2) || !store_ok) continue;
                         if (p.up_r) {
                             const int t = n * p.up_r + phs - p.trimL;
                             if (t >= 0 && t < p.Tfinal) rowp[t] = v;

@@ -46,6 +46,13 @@ struct ConvLayer {
     bool causal = false;
     bool dual = false;      // the plan feeds it two summed sources (residual sum / LSTM skip)
     bool small_n = false;   // runs at the bottleneck frame rate: few columns per utterance
+    // 2-D layers (STFT-domain codec), frequency-major layout: a Conv2d (kf x k, stride sf x stride) over c2d channels is the 1-D
+    // conv (k, stride) over cin = kf * c2d channels of the virtual utterance starting at frequency row fo * sf
+    int kf = 1, sf = 1, c2d = 0;
+    bool extra_left = false;    // SConv2d puts the "extra" time padding on the LEFT (conv.py:377), SConv1d on the right
+    bool valid = false;         // no padding at all (the STFT GEMM)
+    int zpadL = -1, zpadR = -1; // explicit ZERO padding (the inverse-STFT GEMM); -1: reference padding rules
+    bool synthetic = false;     // weights generated at finalize (DFT matrices), not part of the checkpoint
     // GEMM view
     int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
     int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
@@ -121,7 +128,11 @@ struct fc_engine {
     std::vector<Stage> enc_stages, dec_stages;
     LstmBlock enc_lstm, dec_lstm;
     std::map<std::string, ConvLayer*> by_prefix;
-    std::map<std::string, ResBlock*> res_by_prefix;                       // "encoder.model.1" -> block (fc_resblock_forward)
+    std::map<std::string, ResBlock*> res_by_prefix;
+    // STFT-domain codec (arch.model_type == 1)
+    ConvLayer enc2_first, dec2_last, stft, istft;
+    std::vector<std::vector<ConvLayer>> dec_up_phases;                    // decoder stage s: one transposed 1-D GEMM per frequency phase
+    float* win2 = nullptr;                                                // squared Hann window [n_fft] (istft envelope)                       // "encoder.model.1" -> block (fc_resblock_forward)
     std::map<std::string, LstmBlock*> lstm_by_prefix;
     // quantiser
     float *cb = nullptr, *enorm = nullptr;   // [nq][K][D], [nq][K]
@@ -212,7 +223,129 @@ ConvLayer mk_conv_(const std::string& prefix, int cin, int cout, int k, int stri
     return L;
 }
 
+void choose_tiling(ConvLayer& L);
+
+// ---- STFT-domain codec: SEANetEncoder2d / SEANetDecoder2d (seanet_encoder.py:252-363, seanet_decoder.py:244-360) ---------------
+// Same Sequential indexing as the reference; every Conv2d is planned as a 1-D GEMM over kf * C channels (frequency-major layout).
+ConvLayer mk_conv2d(const std::string& prefix, int cin, int cout, int kf, int kt, int sf, int st, bool dual) {
+    ConvLayer L = mk_conv(prefix, kf * cin, cout, kt, st, false, dual, false, 1);
+    L.kf = kf; L.sf = sf; L.c2d = cin; L.extra_left = true;
+    return L;
+}
+
+void add_conv2d_expect(fc_engine* e, ConvLayer& L) {
+    e->expected.push_back({L.prefix + ".conv.weight", {L.cout, L.c2d, L.kf, L.k}});
+    e->expected.push_back({L.prefix + ".conv.bias", {L.cout}});
+    e->expected.push_back({L.prefix + ".norm.weight", {L.cout}});
+    e->expected.push_back({L.prefix + ".norm.bias", {L.cout}});
+    e->by_prefix[L.prefix] = &L;
+}
+
+void build_plan_2d(fc_engine* e) {
+    const fc_arch& a = e->arch;
+    const int nf = a.n_filters, nres = a.n_residual_layers;
+    auto name = [](const char* side, int idx, const char* suffix) { return std::string(side) + ".model." + std::to_string(idx) + suffix; };
+    auto add_res = [&](fc_engine::ResBlock& R, const char* side, int idx, int c, int j, int dil) {
+        const int hid = c / a.compress, rk = a.residual_kernel_size;
+        R.shortcut = mk_conv2d(name(side, idx, ".shortcut.conv"), c, c, 1, 1, 1, 1, j > 0);
+        R.block1 = mk_conv2d(name(side, idx, ".block.1.conv"), c, hid, rk, rk, 1, 1, j > 0);
+        R.block1.dil = dil;                                   // dilation (1, dilation_base ** j): time axis only
+        R.block3 = mk_conv2d(name(side, idx, ".block.3.conv"), hid, c, 1, 1, 1, 1, false);
+    };
+    // ---- encoder
+    int idx = 0, mult = 1;
+    e->enc2_first = mk_conv2d(name("encoder", idx, ".conv"), a.input_channels, nf, a.kernel_size, a.kernel_size, 1, 1, false);
+    idx++;
+    e->enc_stages.resize(a.n_ratios);
+    for (int s = 0; s < a.n_ratios; ++s) {
+        const int fr = a.ratios_f[a.n_ratios - 1 - s], tr = a.ratios[a.n_ratios - 1 - s];
+        const int c = mult * nf;
+        auto& S = e->enc_stages[s];
+        S.res.resize(nres);
+        for (int j = 0, dil = 1; j < nres; ++j, dil *= a.dilation_base) { add_res(S.res[j], "encoder", idx, c, j, dil); idx++; }
+        idx++;                                                                    // ELU
+        S.resample = mk_conv2d(name("encoder", idx, ".conv"), c, 2 * c, 2 * fr, 2 * tr, fr, tr, true);
+        idx++;
+        mult *= 2;
+    }
+    idx++;                                                                        // ReshapeModule (squeeze the frequency axis)
+    const int cb = mult * nf;
+    if (a.lstm_layers > 0) { e->enc_lstm.prefix = name("encoder", idx, ".lstm"); e->enc_lstm.H = cb; idx++; }
+    idx++;
+    const bool skip_dual = a.lstm_layers > 0 && a.lstm_skip;
+    e->enc_last = mk_conv(name("encoder", idx, ".conv"), cb, a.dimension, a.last_kernel_size, 1, false, skip_dual, true);
+    // ---- decoder
+    idx = 0;
+    e->dec_first = mk_conv(name("decoder", idx, ".conv"), a.dimension, cb, a.kernel_size, 1, false, false, true);
+    idx++;
+    if (a.lstm_layers > 0) { e->dec_lstm.prefix = name("decoder", idx, ".lstm"); e->dec_lstm.H = cb; idx++; }
+    idx++;                                                                        // ReshapeModule (unsqueeze)
+    e->dec_stages.resize(a.n_ratios);
+    e->dec_up_phases.resize(a.n_ratios);
+    for (int s = 0; s < a.n_ratios; ++s) {
+        const int fr = a.ratios_f[s], tr = a.ratios[s];
+        const int c = mult * nf, c2 = c / 2;
+        auto& S = e->dec_stages[s];
+        idx++;                                                                    // ELU
+        // ConvTranspose2d(c -> c2, (2 fr, 2 tr), stride (fr, tr)): S.resample only carries the checkpoint contract; the launches
+        // are one transposed 1-D GEMM (2 c channels = frequency rows fi - 1, fi) per output-frequency phase
+        S.resample = ConvLayer();
+        S.resample.prefix = name("decoder", idx, ".convtr");
+        S.resample.transposed = true;
+        S.resample.cin = c; S.resample.cout = c2; S.resample.c2d = c; S.resample.kf = 2 * fr; S.resample.sf = fr;
+        S.resample.k = 2 * tr; S.resample.stride = tr;
+        for (int p = 0; p < fr; ++p)
+            e->dec_up_phases[s].push_back(mk_conv(S.resample.prefix + ".phase" + std::to_string(p), 2 * c, c2, 2 * tr, tr, true, false, false));
+        idx++;
+        S.res.resize(nres);
+        for (int j = 0, dil = 1; j < nres; ++j, dil *= a.dilation_base) { add_res(S.res[j], "decoder", idx, c2, j, dil); idx++; }
+        mult /= 2;
+    }
+    idx++;
+    e->dec2_last = mk_conv2d(name("decoder", idx, ".conv"), nf, a.input_channels, a.last_kernel_size, a.last_kernel_size, 1, 1, true);
+    // ---- the STFT and its inverse as GEMMs over the hop-phase view of the signal (weights generated at finalize)
+    const int F = a.n_fft / 2 + 1, taps = ceil_div_i(a.n_fft, a.stft_hop);
+    e->stft = mk_conv("stft", a.stft_hop, 2 * F, taps, 1);
+    e->stft.valid = true; e->stft.has_norm = false; e->stft.synthetic = true;
+    e->istft = mk_conv("istft", 2 * F, a.stft_hop, taps, 1);
+    e->istft.zpadL = taps - 1; e->istft.zpadR = taps - 1; e->istft.has_norm = false; e->istft.synthetic = true;
+    // ---- checkpoint contract, in execution order
+    add_conv2d_expect(e, e->enc2_first);
+    for (auto& S : e->enc_stages) {
+        for (auto& R : S.res) { add_conv2d_expect(e, R.block1); add_conv2d_expect(e, R.block3); add_conv2d_expect(e, R.shortcut); }
+        add_conv2d_expect(e, S.resample);
+    }
+    auto add_lstm = [&](LstmBlock& lb) {
+        if (lb.H == 0) return;
+        lb.layers.resize(a.lstm_layers);
+        for (int l = 0; l < a.lstm_layers; ++l) {
+            const std::string sfx = "_l" + std::to_string(l);
+            lb.layers[l].inproj = mk_conv(lb.prefix + ".inproj" + sfx, lb.H, 4 * lb.H, 1, 1, false, false, true);
+            lb.layers[l].inproj.has_norm = false;
+            e->expected.push_back({lb.prefix + ".weight_ih" + sfx, {4 * lb.H, lb.H}});
+            e->expected.push_back({lb.prefix + ".weight_hh" + sfx, {4 * lb.H, lb.H}});
+            e->expected.push_back({lb.prefix + ".bias_ih" + sfx, {4 * lb.H}});
+            e->expected.push_back({lb.prefix + ".bias_hh" + sfx, {4 * lb.H}});
+        }
+        e->lstm_by_prefix[lb.prefix] = &lb;
+    };
+    add_lstm(e->enc_lstm);
+    add_conv_expect(e, e->enc_last);
+    add_conv_expect(e, e->dec_first);
+    add_lstm(e->dec_lstm);
+    for (auto& S : e->dec_stages) {
+        e->expected.push_back({S.resample.prefix + ".convtr.weight", {S.resample.c2d, S.resample.cout, S.resample.kf, S.resample.k}});
+        e->expected.push_back({S.resample.prefix + ".convtr.bias", {S.resample.cout}});
+        e->expected.push_back({S.resample.prefix + ".norm.weight", {S.resample.cout}});
+        e->expected.push_back({S.resample.prefix + ".norm.bias", {S.resample.cout}});
+        for (auto& R : S.res) { add_conv2d_expect(e, R.block1); add_conv2d_expect(e, R.block3); add_conv2d_expect(e, R.shortcut); }
+    }
+    add_conv2d_expect(e, e->dec2_last);
+    e->expected.push_back({"quantizer.rq.model.embed", {a.num_quantizers, a.codebook_size, a.dimension}});
+}
+
 void build_plan(fc_engine* e) {
+    if (e->arch.model_type == 1) { build_plan_2d(e); return; }
     const fc_arch& a = e->arch;
     const int nf = a.n_filters, nres = a.n_residual_layers;
     auto name = [](const char* side, int idx, const char* suffix) {
@@ -503,6 +636,102 @@ int pack_reshead(fc_engine* e, fc_engine::ResBlock& R) {
     return 0;
 }
 
+
+// ---- STFT-domain codec: weight re-layout ---------------------------------------------------------------------------------------
+// Conv2d weight [cout][C][kf][kt] -> GEMM weight [cout][a * C + ci][kt] (frequency-major layout: rows fo*sf + a are consecutive
+// [C][T] blocks, so tap a of channel ci is GEMM channel a * C + ci)
+int pack_conv2d(fc_engine* e, ConvLayer& L) {
+    const auto& W = e->host[L.prefix + ".conv.weight"].data;
+    const auto& Bv = e->host[L.prefix + ".conv.bias"].data;
+    const int C = L.c2d, kf = L.kf, kt = L.k;
+    std::vector<float> wg((size_t)L.cout * kf * C * kt);
+    for (int m = 0; m < L.cout; ++m)
+        for (int ci = 0; ci < C; ++ci)
+            for (int a = 0; a < kf; ++a)
+                for (int b = 0; b < kt; ++b)
+                    wg[((size_t)m * (kf * C) + (size_t)a * C + ci) * kt + b] = W[(((size_t)m * C + ci) * kf + a) * kt + b];
+    if (pack_gemm(e, L, wg, Bv)) return 1;
+    if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
+    if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
+    return 0;
+}
+
+// ConvTranspose2d weight [C][cout][2 sf][2 st].  Output frequency row fo = q * sf + p receives input rows fi = q (tap a = p) and
+// fi = q - 1 (tap a = p + sf).  Per phase p: a ConvTranspose1d over 2 C channels (first C: row q - 1, then row q -- their order
+// in the zero-haloed input buffer) with weight W1d[r * C + ci][co][bt] = W[ci][co][p + (1 - r) * sf][bt], packed like every other
+// transposed layer (2-tap GEMM over the time phases).
+int pack_convtr2d(fc_engine* e, const ConvLayer& S, std::vector<ConvLayer>& phases) {
+    const auto& W = e->host[S.prefix + ".convtr.weight"].data;
+    const auto& Bv = e->host[S.prefix + ".convtr.bias"].data;
+    const int C = S.c2d, cout = S.cout, kf = S.kf, kt = S.k, sf = S.sf, r = S.stride;
+    for (int p = 0; p < sf; ++p) {
+        ConvLayer& L = phases[p];
+        std::vector<float> wg((size_t)L.M * L.cin * 2), bg(L.M);
+        for (int co = 0; co < cout; ++co)
+            for (int ph = 0; ph < r; ++ph) {
+                const int m = co * r + ph;
+                bg[m] = Bv[co];
+                for (int rr = 0; rr < 2; ++rr)
+                    for (int ci = 0; ci < C; ++ci) {
+                        const int a = p + (1 - rr) * sf;
+                        const float* w = &W[(((size_t)ci * cout + co) * kf + a) * kt];
+                        const size_t c1 = (size_t)rr * C + ci;
+                        wg[((size_t)m * L.cin + c1) * 2 + 0] = w[ph + r];      // tap 0 multiplies x[i-1]
+                        wg[((size_t)m * L.cin + c1) * 2 + 1] = w[ph];          // tap 1 multiplies x[i]
+                    }
+            }
+        if (pack_gemm(e, L, wg, bg)) return 1;
+    }
+    ConvLayer& L0 = phases[0];
+    if (upload(e, e->host[S.prefix + ".norm.weight"].data, &L0.gamma)) return 1;
+    if (upload(e, e->host[S.prefix + ".norm.bias"].data, &L0.beta)) return 1;
+    return 0;
+}
+
+// torch.stft / torch.istft (center, periodic Hann window of n_fft, onesided, not normalised) as conv weights over the hop-phase view
+// xp[j][m] = xpad[m * hop + j]:  X[f][t] = sum_{a, j} w[n] e^{-2 pi i f n / N} xp[j][t + a],  n = a * hop + j  (zero weight for n >= N);
+// ypoly[j][m] = sum_{a, c} Wi[j][c][a] S[c][m - a]  (overlap-add of the windowed inverse DFTs), as a correlation over S zero-padded by
+// taps - 1 frames on both sides: tap a' = taps - 1 - a.
+int pack_dft(fc_engine* e) {
+    const int N = e->arch.n_fft, hop = e->arch.stft_hop, F = N / 2 + 1, taps = ceil_div_i(N, hop);
+    std::vector<double> win(N);
+    for (int n = 0; n < N; ++n) win[n] = 0.5 - 0.5 * cos(2.0 * M_PI * n / N);          // torch.hann_window(N) (periodic)
+    {
+        ConvLayer& L = e->stft;
+        std::vector<float> wg((size_t)2 * F * hop * taps, 0.f), bg(2 * F, 0.f);
+        for (int f = 0; f < F; ++f)
+            for (int j = 0; j < hop; ++j)
+                for (int a = 0; a < taps; ++a) {
+                    const int n = a * hop + j;
+                    if (n >= N) continue;
+                    const double ang = 2.0 * M_PI * (double)(((long long)f * n) % N) / N;
+                    wg[((size_t)f * hop + j) * taps + a] = (float)(win[n] * cos(ang));
+                    wg[((size_t)(F + f) * hop + j) * taps + a] = (float)(-win[n] * sin(ang));
+                }
+        if (pack_gemm(e, L, wg, bg)) return 1;
+    }
+    {
+        ConvLayer& L = e->istft;
+        std::vector<float> wg((size_t)hop * 2 * F * taps, 0.f), bg(hop, 0.f);
+        for (int j = 0; j < hop; ++j)
+            for (int f = 0; f < F; ++f)
+                for (int a = 0; a < taps; ++a) {
+                    const int n = a * hop + j;
+                    if (n >= N) continue;
+                    const double cf = (f == 0 || f == N / 2) ? 1.0 : 2.0;
+                    const double ang = 2.0 * M_PI * (double)(((long long)f * n) % N) / N;
+                    const int ap = taps - 1 - a;
+                    wg[((size_t)j * 2 * F + f) * taps + ap] = (float)(win[n] * cf * cos(ang) / N);
+                    wg[((size_t)j * 2 * F + F + f) * taps + ap] = (float)(-win[n] * cf * sin(ang) / N);
+                }
+        if (pack_gemm(e, L, wg, bg)) return 1;
+    }
+    std::vector<float> w2(N);
+    for (int n = 0; n < N; ++n) w2[n] = (float)((float)win[n] * (float)win[n]);
+    if (upload(e, w2, &e->win2)) return 1;
+    return 0;
+}
+
 int pack_lstm(fc_engine* e, LstmBlock& lb) {
     const int H = lb.H;
     if (H == 0) return 0;
@@ -544,6 +773,8 @@ struct ConvGeom { int Tout, padL, padR, count_T; };
 // SConv1d.forward padding arithmetic (conv.py:243-258, get_extra_padding_for_conv1d :57-64)
 ConvGeom conv_geom(const ConvLayer& L, int T) {
     ConvGeom g;
+    if (L.valid) { g.padL = 0; g.padR = 0; g.Tout = T - L.k + 1; g.count_T = g.Tout; return g; }
+    if (L.zpadL >= 0) { g.padL = L.zpadL; g.padR = L.zpadR; g.Tout = T + g.padL + g.padR - L.k + 1; g.count_T = g.Tout; return g; }
     if (!L.transposed) {
         const int pt = (L.k - 1) * L.dil - (L.stride - 1);      // padding_total (conv.py:247)
         const int num = T - L.k + pt;
@@ -551,6 +782,7 @@ ConvGeom conv_geom(const ConvLayer& L, int T) {
         const int ideal = nfr * L.stride + (L.k - pt);
         const int extra = ideal - T;
         if (L.causal) { g.padL = pt; g.padR = extra; }          // all fixed padding on the left (conv.py:249-251)
+        else if (L.extra_left) { g.padR = pt / 2; g.padL = pt - pt / 2 + extra; }   // SConv2d, time axis (conv.py:376-377)
         else { g.padR = pt / 2 + extra; g.padL = pt - pt / 2; }
         // what nn.Conv1d then produces on the padded input (the reference's frame formula above ignores dilation; with
         // dilation 1 this equals nfr + 1)
@@ -597,6 +829,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
         c.up_r = L.stride; c.trimL = L.causal ? 0 : L.stride - L.stride / 2; c.Tfinal = g.Tout;
     } else {
         c.Tout = g.Tout;
+        if (L.zpadL >= 0) c.pad_zero = 1;
     }
     if (out_override) {
         out.raw = out_override;
@@ -789,13 +1022,272 @@ Act run_decoder(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf) {
     return run_conv(e, cx, e->dec_last, a0, a1, 1, T);
 }
 
+
+// ---- STFT-domain codec: execution over frequency-major activations --------------------------------------------------------------
+struct Act2 {              // raw [B][F + 2*halo][C][T] + pending GroupNorm affine [B][C] (null = final)
+    float* buf = nullptr;
+    float* aff = nullptr;
+    int C = 0, F = 0, T = 0, halo = 0;
+    bool normed = false;
+};
+constexpr int kHalo2 = 3;  // frequency halo rows of every 2-D activation that a kf > 1 conv may read (7x7: 3, 8-row strided: 2, 3x3: 1)
+
+// SConv2d.forward (conv.py:342-381) as ONE launch of the 1-D implicit-GEMM kernel over B * Fo virtual utterances
+Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* x1p, int elu, int out_halo) {
+    const int B = cx.B, C = L.c2d, kf = L.kf, sf = L.sf;
+    Act2 x1 = x1p ? *x1p : Act2();
+    bool dual = x1p != nullptr;
+    const int tot_f = (kf - 1) - (sf - 1), f_after = tot_f / 2, f_before = tot_f - f_after;     // no extra padding on the frequency axis
+    const int Fo = (x0.F + tot_f - kf) / sf + 1;
+    const ConvGeom g = conv_geom(L, x0.T);
+    // layers with several M tiles: materialise the activated input once (as run_conv does), frequency-major with the same halo
+    if (L.Mpad / L.BM >= 3 && (x0.normed || dual || elu)) {
+        Act2 m;
+        m.C = C; m.F = x0.F; m.T = x0.T; m.halo = x0.halo;
+        m.buf = cx.alloc<float>((size_t)B * (m.F + 2 * m.halo) * C * m.T);
+        cx.launches += 2;
+        if (!cx.dry && !cx.err) {
+            hipError_t er = fc::launch_combine2d(x0.buf, x0.aff, x0.halo, dual ? x1.buf : nullptr, dual ? x1.aff : nullptr, x1.halo, elu,
+                                                 e->arch.elu_alpha, B, m.F, C, m.T, m.buf, m.halo, cx.st);
+            if (er == hipSuccess) er = fc::launch_halo_rows(m.buf, B, m.F, m.halo, C, m.T, 0, cx.st);
+            if (er != hipSuccess) { cx.err = 1; g_err = std::string("combine2d launch failed: ") + hipGetErrorString(er); }
+        }
+        x0 = m; x1 = Act2(); elu = 0; dual = false;
+    }
+    const bool dual_eff = dual;
+    Act2 o;
+    o.C = L.cout; o.F = Fo; o.T = g.Tout; o.halo = out_halo;
+    o.buf = cx.alloc<float>((size_t)B * (Fo + 2 * out_halo) * L.cout * g.Tout);
+    if (!cx.dry && (x0.halo < f_before || x0.halo < f_after || (x1.buf && x1.halo != x0.halo))) {
+        cx.err = 1; g_err = "internal: frequency halo too small for " + L.prefix; return o;
+    }
+    fc::ConvLaunch c;
+    const long long rowsz = (long long)C * x0.T;
+    c.s0.ptr = cx.dry ? nullptr : x0.buf + (long long)(x0.halo - f_before) * rowsz;
+    c.s0.aff = x0.aff; c.s0.used = x0.normed ? 3 : 1;
+    if (dual_eff) { c.s1.ptr = cx.dry ? nullptr : x1.buf + (long long)(x1.halo - f_before) * rowsz; c.s1.aff = x1.aff; c.s1.used = x1.normed ? 3 : 1; }
+    c.elu = elu; c.alpha = e->arch.elu_alpha;
+    c.wt = L.wt; c.bias = L.bias; c.koff = L.koff;
+    c.B = B * Fo; c.Cin = L.cin; c.Tin = x0.T; c.M = L.M; c.Tout = g.Tout;
+    c.k = L.gk; c.stride = L.gstride; c.dil = L.dil; c.padL = g.padL; c.padR = g.padR;
+    c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
+    c.Fo = Fo; c.affC = C;
+    c.in_sB0 = (long long)(x0.F + 2 * x0.halo) * rowsz; c.in_sB1 = (long long)sf * rowsz;
+    const long long orow = (long long)L.cout * g.Tout;
+    c.out = cx.dry ? nullptr : o.buf + (long long)out_halo * orow;
+    c.out_sB = (long long)(Fo + 2 * out_halo) * orow; c.out_sF = orow; c.out_sM = g.Tout; c.out_sT = 1;
+    const int nblk = fc::conv_nblk(c);
+    c.partials = cx.alloc<double>((size_t)B * Fo * nblk * 2);
+    o.aff = cx.alloc<float>((size_t)B * L.cout * 2);
+    o.normed = true;
+    const double fl = 2.0 * B * Fo * (double)L.M * L.cin * L.gk * g.Tout;
+    const double by = 4.0 * B * ((double)C * x0.F * x0.T * (dual_eff ? 2 : 1) + (double)L.cout * Fo * g.Tout);
+    cx.conv_flops += fl; cx.conv_bytes += by;
+    cx.launches += out_halo ? 3 : 2; cx.conv_launches += 1;
+    if (cx.dry || cx.err) return o;
+    hipError_t er;
+    {
+        int cls = 0;
+        if (e->profiling) {
+            int mode = 0, nu = 0, row = 0;
+            fc::conv_variant(c, &mode, &nu, &row);
+            char nm[64];
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
+                     row ? "true" : "false");
+            cls = e->prof_class(nm);
+        }
+        ProfSpan sp(e, cx, cls, fl, by);
+        er = fc::launch_conv(c, cx.st);
+    }
+    if (er == hipSuccess)
+        er = fc::launch_gn_finalize(c.partials, nblk * Fo, (double)L.cout * Fo * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps, B, o.aff, cx.st);
+    if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fo, out_halo, L.cout, g.Tout, 0, cx.st);
+    if (er != hipSuccess) { cx.err = 1; g_err = "2-D conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); }
+    return o;
+}
+
+// SEANetResnetBlock2d.forward (seanet_encoder.py:239-240) over the blocks of a stage: returns the two raw branches of the last block
+void run_resblocks2d(fc_engine* e, Ctx& cx, const fc_engine::Stage& S, Act2 a0, const Act2* a1, Act2* sc, Act2* b3) {
+    Act2 prev1;
+    for (const auto& R : S.res) {
+        *sc = run_conv2d(e, cx, R.shortcut, a0, a1, 0, kHalo2);
+        Act2 b1 = run_conv2d(e, cx, R.block1, a0, a1, 1, 0);
+        *b3 = run_conv2d(e, cx, R.block3, b1, nullptr, 1, kHalo2);
+        a0 = *sc; prev1 = *b3; a1 = &prev1;
+    }
+}
+
+// SConvTranspose2d.forward (conv.py:408-447): sf launches (one per output-frequency phase) of the transposed 1-D GEMM over the
+// materialised, zero-haloed input; GroupNorm statistics over the UNTRIMMED (Fin + 1) sf x (Tin + 1) st output
+Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<ConvLayer>& phases, const Act2& x0, const Act2* x1, bool last,
+                  int out_halo) {
+    const int B = cx.B, C = S.c2d, Fin = x0.F, T = x0.T, sf = S.sf, st = S.stride, cout = S.cout;
+    Act2 z;                                                   // ELU(x) with one zero row above and below
+    z.C = C; z.F = Fin; z.T = T; z.halo = 1;
+    z.buf = cx.alloc<float>((size_t)B * (Fin + 2) * C * T);
+    const ConvGeom g = conv_geom(phases[0], T);               // time axis: Tout = T * st, count_T = (T + 1) * st
+    int f_r = sf / 2;
+    const int f_l = sf - f_r;
+    if (last && f_r > 0) f_r -= 1;                            // last_out_padding [(0, 1), (0, 0)] (seanet_decoder.py:279,316)
+    const int Fout = (Fin + 1) * sf - f_l - f_r;
+    Act2 o;
+    o.C = cout; o.F = Fout; o.T = g.Tout; o.halo = out_halo;
+    const long long orow = (long long)cout * g.Tout;
+    o.buf = cx.alloc<float>((size_t)B * (Fout + 2 * out_halo) * orow);
+    fc::ConvLaunch c0;
+    c0.M = phases[0].M; c0.BM = phases[0].BM; c0.BN = phases[0].BN; c0.Tout = T + 1;
+    const int nblk = fc::conv_nblk(c0);
+    const long long part_row = (long long)(Fin + 1) * nblk;
+    double* partials = cx.alloc<double>((size_t)B * sf * part_row * 2);
+    o.aff = cx.alloc<float>((size_t)B * cout * 2);
+    o.normed = true;
+    const double fl = 2.0 * B * (Fin + 1) * (double)phases[0].M * 2 * C * 2 * (T + 1) * sf;
+    const double by = 4.0 * B * ((double)C * Fin * T * (x1 ? 2 : 1) + (double)cout * Fout * g.Tout);
+    cx.conv_flops += fl; cx.conv_bytes += by;
+    cx.launches += sf + 3 + (out_halo ? 1 : 0); cx.conv_launches += sf;
+    if (cx.dry || cx.err) return o;
+    hipError_t er = fc::launch_combine2d(x0.buf, x0.aff, x0.halo, x1 ? x1->buf : nullptr, x1 ? x1->aff : nullptr, x1 ? x1->halo : 0, 1,
+                                         e->arch.elu_alpha, B, Fin, C, T, z.buf, 1, cx.st);
+    if (er == hipSuccess) er = fc::launch_halo_rows(z.buf, B, Fin, 1, C, T, 1, cx.st);
+    for (int p = 0; p < sf && er == hipSuccess; ++p) {
+        const ConvLayer& L = phases[p];
+        fc::ConvLaunch c;
+        c.s0.ptr = z.buf; c.s0.used = 1;
+        c.wt = L.wt; c.bias = L.bias; c.koff = L.koff;
+        c.B = B * (Fin + 1); c.Cin = L.cin; c.Tin = T; c.M = L.M;
+        c.k = L.gk; c.stride = L.gstride; c.dil = 1; c.padL = g.padL; c.padR = g.padR; c.pad_zero = 1;
+        c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
+        c.Tout = T + 1; c.up_r = st; c.trimL = st - st / 2; c.Tfinal = g.Tout;
+        c.Fo = Fin + 1; c.affC = C;
+        c.in_sB0 = (long long)(Fin + 2) * C * T; c.in_sB1 = (long long)C * T;
+        c.out = o.buf + ((long long)out_halo + p - f_l) * orow;      // rows outside [0, Fout) are never stored (store range below)
+        c.out_sB = (long long)(Fout + 2 * out_halo) * orow; c.out_sF = (long long)sf * orow; c.out_sM = g.Tout; c.out_sT = 1;
+        int lo = f_l - p;                                            // q * sf + p - f_l >= 0
+        lo = lo <= 0 ? 0 : (lo + sf - 1) / sf;
+        int hi = (Fout - 1 + f_l - p) >= 0 ? (Fout - 1 + f_l - p) / sf + 1 : 0;   // q * sf + p - f_l <= Fout - 1
+        if (hi > Fin + 1) hi = Fin + 1;
+        c.store_lo = lo; c.store_hi = hi;
+        c.partials = partials + (long long)p * part_row * 2;
+        c.part_sB0 = (long long)sf * part_row;
+        int cls = 0;
+        if (e->profiling) {
+            int mode = 0, nu = 0, row = 0;
+            fc::conv_variant(c, &mode, &nu, &row);
+            char nm[64];
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
+                     row ? "true" : "false");
+            cls = e->prof_class(nm);
+        }
+        ProfSpan sp(e, cx, cls, fl / sf, by / sf);
+        er = fc::launch_conv(c, cx.st);
+    }
+    const ConvLayer& L0 = phases[0];
+    if (er == hipSuccess)
+        er = fc::launch_gn_finalize(partials, (int)(sf * part_row), (double)cout * (Fin + 1) * sf * g.count_T, L0.gamma, L0.beta, cout, e->arch.gn_eps,
+                                    B, o.aff, cx.st);
+    if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fout, out_halo, cout, g.Tout, 0, cx.st);
+    if (er != hipSuccess) { cx.err = 1; g_err = "2-D transposed conv launch failed (" + S.prefix + "): " + hipGetErrorString(er); }
+    return o;
+}
+
+int stft_frames(const fc_engine* e, int T) { return 1 + T / e->arch.stft_hop; }
+
+// FreqCodec._encode_frame (codec_freq.py:330-392, mag_phase) + SEANetEncoder2d.forward: wav -> last conv (raw + affine) at Tf frames
+Act run_encoder_2d(fc_engine* e, Ctx& cx, const float* wav, int T, const float* scale) {
+    const fc_arch& a = e->arch;
+    const int B = cx.B, hop = a.stft_hop, F = a.n_fft / 2 + 1, Tp = stft_frames(e, T), taps = ceil_div_i(a.n_fft, hop), Mp = Tp + taps - 1;
+    float* xp = cx.alloc<float>((size_t)B * hop * Mp);
+    cx.launches += 3;
+    if (!cx.dry && !cx.err) {
+        if (T <= a.n_fft / 2) { cx.err = 1; g_err = "utterance shorter than n_fft/2 + 1 samples (torch.stft reflect padding needs more)"; }
+        else if (fc::launch_polyphase_in(wav, a.audio_normalize ? scale : nullptr, B, T, hop, a.n_fft, Mp, xp, cx.st) != hipSuccess) {
+            cx.err = 1; g_err = "polyphase launch failed";
+        }
+    }
+    fc::Src sx; sx.ptr = xp; sx.used = 1;
+    Act spec = run_conv(e, cx, e->stft, sx, fc::Src(), 0, Mp);                     // [B][2F][Tp]: re rows, then im rows
+    Act2 feats;
+    feats.C = a.input_channels; feats.F = F; feats.T = Tp; feats.halo = kHalo2;
+    feats.buf = cx.alloc<float>((size_t)B * (F + 2 * kHalo2) * feats.C * Tp);
+    if (!cx.dry && !cx.err) {
+        hipError_t er = fc::launch_stft_feats(spec.raw, B, F, Tp, (long long)2 * F * Tp, kHalo2, feats.buf, cx.st);
+        if (er == hipSuccess) er = fc::launch_halo_rows(feats.buf, B, F, kHalo2, feats.C, Tp, 0, cx.st);
+        if (er != hipSuccess) { cx.err = 1; g_err = std::string("stft feature launch failed: ") + hipGetErrorString(er); }
+    }
+    Act2 x = run_conv2d(e, cx, e->enc2_first, feats, nullptr, 0, kHalo2);
+    for (size_t si = 0; si < e->enc_stages.size(); ++si) {
+        auto& S = e->enc_stages[si];
+        Act2 sc, b3;
+        run_resblocks2d(e, cx, S, x, nullptr, &sc, &b3);
+        x = run_conv2d(e, cx, S.resample, sc, &b3, 1, si + 1 == e->enc_stages.size() ? 0 : kHalo2);
+    }
+    if (!cx.dry && !cx.err && x.F != 1) { cx.err = 1; g_err = "the 2-D encoder must reduce the frequency axis to one bin (n_fft / ratios mismatch)"; }
+    Act x1;                                                                        // ReshapeModule: [B][1][C][T] is [B][C][T]
+    x1.raw = x.buf; x1.aff = x.aff; x1.C = x.C; x1.T = x.T; x1.normed = x.normed;
+    if (e->enc_lstm.H) {
+        Act y = run_lstm(e, cx, e->enc_lstm, x1, x1.T);
+        if (a.lstm_skip) return run_conv(e, cx, e->enc_last, src_of(y), src_of(x1), 1, x1.T);
+        return run_conv(e, cx, e->enc_last, src_of(y), fc::Src(), 1, x1.T);
+    }
+    return run_conv(e, cx, e->enc_last, src_of(x1), fc::Src(), 1, x1.T);
+}
+
+// SEANetDecoder2d.forward + FreqCodec._decode_frame (codec_freq.py:409-448, mag_phase): z [B][D][Tf] -> wav [B][out_len]
+void run_decoder_2d(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf, const float* scale, int out_len, float* wav) {
+    const fc_arch& a = e->arch;
+    const int B = cx.B, hop = a.stft_hop, F = a.n_fft / 2 + 1, taps = ceil_div_i(a.n_fft, hop);
+    fc::Src s; s.ptr = z_bdt; s.used = 1;
+    Act x = run_conv(e, cx, e->dec_first, s, fc::Src(), 0, Tf);
+    Act2 a0, a1;
+    bool has1 = false;
+    auto as2 = [](const Act& t) { Act2 r; r.buf = t.raw; r.aff = t.aff; r.C = t.C; r.F = 1; r.T = t.T; r.halo = 0; r.normed = t.normed; return r; };
+    a0 = as2(x);
+    if (e->dec_lstm.H) {
+        Act y = run_lstm(e, cx, e->dec_lstm, x, x.T);
+        a0 = as2(y);
+        if (a.lstm_skip) { a1 = as2(x); has1 = true; }
+    }
+    for (size_t si = 0; si < e->dec_stages.size(); ++si) {
+        auto& S = e->dec_stages[si];
+        Act2 up = run_convtr2d(e, cx, S.resample, e->dec_up_phases[si], a0, has1 ? &a1 : nullptr, si + 1 == e->dec_stages.size(), kHalo2);
+        Act2 sc, b3;
+        run_resblocks2d(e, cx, S, up, nullptr, &sc, &b3);
+        a0 = sc; a1 = b3; has1 = true;
+    }
+    Act2 last = run_conv2d(e, cx, e->dec2_last, a0, &a1, 1, 0);                     // [B][F][3][Tp2] raw + GroupNorm(1, 3) affine
+    const int Tp2 = last.T, Mp2 = Tp2 + taps - 1;
+    float* spec = cx.alloc<float>((size_t)B * 2 * F * Tp2);
+    cx.launches += 2;
+    if (!cx.dry && !cx.err) {
+        if (last.F != F) { cx.err = 1; g_err = "internal: decoder frequency rows != n_fft / 2 + 1"; }
+        else if (out_len > hop * (Tp2 - 1)) { cx.err = 1; g_err = "out_len exceeds the inverse STFT's length stft_hop * (frames - 1)"; }
+        else if (fc::launch_spec_from_dec(last.buf, last.aff, B, F, Tp2, 0, spec, cx.st) != hipSuccess) { cx.err = 1; g_err = "spectrum launch failed"; }
+    }
+    fc::Src ss; ss.ptr = spec; ss.used = 1;
+    Act yp = run_conv(e, cx, e->istft, ss, fc::Src(), 0, Tp2);                      // [B][hop][Mp2]
+    if (!cx.dry && !cx.err) {
+        if (yp.T != Mp2) { cx.err = 1; g_err = "internal: inverse-STFT GEMM length"; }
+        else if (fc::launch_istft_finish(yp.raw, e->win2, B, hop, a.n_fft, Mp2, Tp2, scale, out_len, wav, cx.st) != hipSuccess) {
+            cx.err = 1; g_err = "istft finish launch failed";
+        }
+    }
+}
+
 int total_hop(const fc_engine* e) {
-    int h = 1;
+    int h = e->arch.model_type == 1 ? e->arch.stft_hop : 1;
     for (int i = 0; i < e->arch.n_ratios; ++i) h *= e->arch.ratios[i];
     return h;
 }
 
+int decoded_samples(const fc_engine* e, int Tf) {
+    if (e->arch.model_type != 1) return Tf * total_hop(e);
+    int tp = Tf;
+    for (int i = 0; i < e->arch.n_ratios; ++i) tp *= e->arch.ratios[i];
+    return e->arch.stft_hop * (tp - 1);                                   // torch.istft, center = True
+}
+
 int frames_for(const fc_engine* e, int T) {
+    if (e->arch.model_type == 1) T = stft_frames(e, T);
     for (int i = e->arch.n_ratios - 1; i >= 0; --i) T = ceil_div_i(T, e->arch.ratios[i]);
     return T;
 }
@@ -812,7 +1304,7 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
             if (fc::launch_volume(wav, B, T, sc, cx.st) != hipSuccess) return fail("volume kernel launch failed");
         }
     }
-    Act last = run_encoder(e, cx, wav, T, sc);
+    Act last = e->arch.model_type == 1 ? run_encoder_2d(e, cx, wav, T, sc) : run_encoder(e, cx, wav, T, sc);
     float* emb = enc_out ? enc_out : cx.alloc<float>((size_t)B * Tf * D);
     float* qbdt = cx.alloc<float>((size_t)B * D * Tf);
     cx.launches += 2;
@@ -832,6 +1324,10 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
 }
 
 int do_decode(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf, const float* scale, int out_len, float* wav) {
+    if (e->arch.model_type == 1) {
+        run_decoder_2d(e, cx, z_bdt, Tf, scale, out_len, wav);
+        return cx.err;
+    }
     Act last = run_decoder(e, cx, z_bdt, Tf);
     cx.launches++;
     if (!cx.dry && !cx.err) {
@@ -899,6 +1395,23 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (arch->lstm_layers > FC_LSTM_MAX_LAYERS) return fail("too many LSTM layers");
     for (int i = 0; i < arch->n_ratios; ++i)
         if (arch->ratios[i] < 1) return fail("ratios must be >= 1");
+    if (arch->model_type != 0 && arch->model_type != 1) return fail("fc_arch.model_type must be 0 (encodec) or 1 (freq_codec, mag_phase)");
+    if (arch->model_type == 1) {
+        if (arch->norm_type != 0 || arch->causal) return fail("freq_codec: only the GroupNorm, non-causal recipe is built");
+        if (arch->input_channels != 3) return fail("freq_codec: input_channels must be 3 (log-magnitude, phase re, phase im)");
+        if (arch->n_fft < 64 || (arch->n_fft & (arch->n_fft - 1)) || arch->stft_hop < 1 || arch->stft_hop > arch->n_fft)
+            return fail("freq_codec: n_fft must be a power of two >= 64 and 1 <= stft_hop <= n_fft");
+        if (arch->stft_hop % 2) return fail("freq_codec: stft_hop must be even");
+        if (arch->dilation_base != 1 && arch->n_residual_layers > 1) return fail("freq_codec: dilated residual stacks are not built for the 2-D nets");
+        int f = arch->n_fft / 2 + 1;
+        for (int i = arch->n_ratios - 1; i >= 0; --i) {
+            const int fr = arch->ratios_f[i];
+            if (fr < 1) return fail("freq_codec: ratios_f must be >= 1");
+            const int tot = (2 * fr - 1) - (fr - 1);
+            f = (f + tot - 2 * fr) / fr + 1;
+        }
+        if (f != 1) return fail("freq_codec: the frequency ratios must reduce n_fft / 2 + 1 bins to exactly one");
+    }
     fc_engine* e = new fc_engine();
     e->arch = *arch;
     e->device = device;
@@ -982,9 +1495,27 @@ int fc_engine_finalize(fc_engine* e) {
     HIP_TRY(hipGetDeviceProperties(&prop, e->device));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
         return fail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    if (e->arch.model_type == 1) {
+        if (pack_conv2d(e, e->enc2_first) || pack_conv2d(e, e->dec2_last)) return 1;
+        for (auto& S : e->enc_stages) {
+            for (auto& R : S.res)
+                if (pack_conv2d(e, R.shortcut) || pack_conv2d(e, R.block1) || pack_conv2d(e, R.block3)) return 1;
+            if (pack_conv2d(e, S.resample)) return 1;
+        }
+        for (size_t si = 0; si < e->dec_stages.size(); ++si) {
+            auto& S = e->dec_stages[si];
+            for (auto& R : S.res)
+                if (pack_conv2d(e, R.shortcut) || pack_conv2d(e, R.block1) || pack_conv2d(e, R.block3)) return 1;
+            if (pack_convtr2d(e, S.resample, e->dec_up_phases[si])) return 1;
+        }
+        if (pack_conv(e, e->enc_last) || pack_conv(e, e->dec_first)) return 1;
+        if (pack_dft(e)) return 1;
+    }
     std::vector<ConvLayer*> convs = {&e->enc_first, &e->enc_last, &e->dec_first, &e->dec_last};
+    if (e->arch.model_type == 1) convs.clear();
     for (auto* st : {&e->enc_stages, &e->dec_stages})
         for (auto& S : *st) {
+            if (e->arch.model_type == 1) break;
             for (auto& R : S.res) { convs.push_back(&R.shortcut); convs.push_back(&R.block1); convs.push_back(&R.block3); }
             convs.push_back(&S.resample);
         }
@@ -993,7 +1524,7 @@ int fc_engine_finalize(fc_engine* e) {
     for (auto* stg : {&e->enc_stages, &e->dec_stages})
         for (auto& S : *stg)
             for (auto& R : S.res)
-                if (pack_reshead(e, R)) return 1;
+                if (e->arch.model_type == 0 && pack_reshead(e, R)) return 1;
     for (ConvLayer* L : convs)
         if (pack_conv(e, *L)) return 1;
     if (pack_lstm(e, e->enc_lstm)) return 1;
@@ -1041,6 +1572,7 @@ int fc_engine_finalize(fc_engine* e) {
 
 int fc_engine_hop_length(const fc_engine* e) { return e ? total_hop(e) : 0; }
 int fc_engine_frames(const fc_engine* e, int n_samples) { return e ? frames_for(e, n_samples) : 0; }
+int fc_engine_decoded_samples(const fc_engine* e, int n_frames) { return e ? decoded_samples(e, n_frames) : 0; }
 
 size_t fc_engine_workspace_bytes(const fc_engine* ce, int B, int T) {
     fc_engine* e = const_cast<fc_engine*>(ce);
@@ -1053,7 +1585,7 @@ size_t fc_engine_workspace_bytes(const fc_engine* ce, int B, int T) {
     cx.alloc<float>((size_t)B * Tf * D);           // quantized when the caller does not want it
     cx.alloc<float>((size_t)B * Tf * D);           // emb for decode_codes
     cx.alloc<float>((size_t)B * Tf * D);           // transposed copy for decode_emb
-    do_decode(e, cx, nullptr, Tf, nullptr, Tf * total_hop(e), nullptr);
+    do_decode(e, cx, nullptr, Tf, nullptr, decoded_samples(e, Tf), nullptr);
     return cx.off + 4096;
 }
 
@@ -1117,7 +1649,8 @@ int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int 
     float* qbdt = nullptr;
     if (do_encode(e, cx, wav, T, n_q, codes, quantized, sub_quants, sc, nullptr, &qbdt)) return 1;
     const int Tf = frames_for(e, T);
-    return do_decode(e, cx, qbdt, Tf, (use_scale && e->arch.audio_normalize) ? sc : nullptr, T, recon);
+    const int dec_len = decoded_samples(e, Tf);                     // recon is [B, min(T, decoded samples)] (the reference's recon[:, :, :T])
+    return do_decode(e, cx, qbdt, Tf, (use_scale && e->arch.audio_normalize) ? sc : nullptr, T < dec_len ? T : dec_len, recon);
 }
 
 int fc_rvq_encode(fc_engine* e, const float* x, int N, int n_q, int64_t* codes, float* quantized, void* workspace,

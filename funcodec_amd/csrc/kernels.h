@@ -34,6 +34,12 @@ struct ConvLaunch {
     double* partials = nullptr;   // [B][nblk][2] (sum, sumsq) or null
     int BM = 128, BN = 128, CC = 2, nchunk = 1;   // tiling chosen at pack time
     int row = 0;                  // stride-1 row staging (conv_row_ok() at pack time)
+    // 2-D nets in frequency-major layout (kernels of conv_kernel.h, "two-level batch addressing"); defaults = 1-D layer
+    int Fo = 1;                   // virtual utterances per real utterance (B = real utterances x Fo)
+    int affC = 0;                 // channels of the affine tables (0: = Cin)
+    long long in_sB0 = 0, in_sB1 = 0;     // 0: in_sB0 = Cin * Tin
+    long long out_sF = 0, part_sB0 = 0;   // 0: part_sB0 = Fo * conv_nblk()
+    int store_lo = 0, store_hi = 1 << 30;
     const float* w_plain = nullptr;   // [Cin][k] device copy for single-output-channel layers (FMA kernel), else null
     float bias_host0 = 0.f;           // bias[0] of such a layer
 };
@@ -64,6 +70,16 @@ struct ResHeadLaunch {
 bool reshead_ok(int C, int hid, int k_sc, int k_b1, int dil, int stride);
 int reshead_ntiles(int T);
 hipError_t launch_reshead(const ResHeadLaunch& c, hipStream_t st);
+
+// ---- STFT-domain codec (freq_kernels.hip): frequency-major 2-D activations [B][F + 2*halo][C][T]
+hipError_t launch_polyphase_in(const float* wav, const float* div, int B, int T, int hop, int n_fft, int Mp, float* xp, hipStream_t st);
+hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, float* feats, hipStream_t st);
+hipError_t launch_halo_rows(float* buf, int B, int F, int halo, int C, int T, int zero, hipStream_t st);
+hipError_t launch_combine2d(const float* s0, const float* aff0, int h0, const float* s1, const float* aff1, int h1, int elu, float alpha,
+                            int B, int F, int C, int T, float* dst, int hd, hipStream_t st);
+hipError_t launch_spec_from_dec(const float* dec, const float* aff, int B, int F, int Tp, int halo, float* spec, hipStream_t st);
+hipError_t launch_istft_finish(const float* ypoly, const float* win2, int B, int hop, int n_fft, int Mp, int Tp, const float* mul, int out_len,
+                               float* wav, hipStream_t st);
 
 // Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)
 hipError_t launch_gn_finalize(const double* partials, int nblk, double count, const float* gamma,

@@ -29,6 +29,13 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.src1 = c.s1.ptr; a.aff1 = c.s1.aff;
     a.wt = c.wt; a.bias = c.bias; a.out = c.out; a.partials = c.partials;
     a.out_sB = c.out_sB; a.out_sM = c.out_sM; a.out_sT = c.out_sT;
+    a.Fo = c.Fo < 1 ? 1 : c.Fo;
+    a.affC = c.affC > 0 ? c.affC : c.Cin;
+    a.in_sB0 = c.in_sB0 ? c.in_sB0 : (long long)c.Cin * c.Tin;
+    a.in_sB1 = c.in_sB1;
+    a.out_sF = c.out_sF;
+    a.part_sB0 = c.part_sB0 ? c.part_sB0 : (long long)a.Fo * conv_nblk(c);
+    a.store_lo = c.store_lo; a.store_hi = c.store_hi;
     a.B = c.B; a.Cin = c.Cin; a.Tin = c.Tin; a.M = c.M; a.Tout = c.Tout;
     a.k = c.k; a.stride = c.stride; a.padL = c.padL; a.padR = c.padR; a.pad_zero = c.pad_zero;
     a.dil = c.dil;
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
 }
 
 bool conv_cout1_ok(const ConvLaunch& c) {
-    return c.w_plain && c.M == 1 && c.stride == 1 && c.dil == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
+    return c.w_plain && c.Fo <= 1 && c.M == 1 && c.stride == 1 && c.dil == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
            (c.k == 7 || c.k == 3 || c.k == 5) && c.padL + c.padR == c.k - 1;
 }
 

@@ -78,6 +78,12 @@ class CodecEngine:
         a.causal = int(arch.causal)
         a.n_residual_layers = arch.n_residual_layers
         a.dilation_base = arch.dilation_base
+        a.model_type = {"encodec": 0, "freq_codec": 1}[arch.model_type]
+        a.input_channels = arch.input_channels
+        a.n_fft = arch.n_fft
+        a.stft_hop = arch.stft_hop
+        for i, r in enumerate(arch.ratios_f):
+            a.ratios_f[i] = int(r)
         h = C.c_void_p()
         self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
         self._h = h
@@ -150,6 +156,10 @@ class CodecEngine:
 
     def frames(self, n_samples: int) -> int:
         return self.lib.fc_engine_frames(self._h, n_samples)
+
+    def decoded_samples(self, n_frames: int) -> int:
+        """Samples the decoder emits for n_frames frames (n_frames * hop; stft_hop * (2-D time frames - 1) for freq_codec)."""
+        return self.lib.fc_engine_decoded_samples(self._h, n_frames)
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         key = (B, T)
@@ -229,7 +239,7 @@ class CodecEngine:
         quant = torch.empty((B, Tf, D), dtype=torch.float32, device=dev)
         subq = torch.empty((n_q, B, D, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
         scale = torch.empty((B,), dtype=torch.float32, device=dev) if self.arch.audio_normalize else None
-        recon = torch.empty((B, 1, T), dtype=torch.float32, device=dev)
+        recon = torch.empty((B, 1, min(T, self.decoded_samples(Tf))), dtype=torch.float32, device=dev)   # like recon[:, :, :T] of the reference
         ws = self._workspace(B, T)
         self._check(self.lib.fc_encode_decode(self._h, _ptr(wav), B, T, n_q, int(use_scale), _ptr(codes), _ptr(quant),
                                               _ptr(subq), _ptr(scale), _ptr(recon), _ptr(ws), ws.numel(), self._stream()))
@@ -244,10 +254,10 @@ class CodecEngine:
         if B > self.micro_batch:
             parts = [self.decode_codes(tokens[i:i + self.micro_batch]) for i in range(0, B, self.micro_batch)]
             return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
-        L = Tf * self.hop_length
+        L = self.decoded_samples(Tf)
         wav = torch.empty((B, 1, L), dtype=torch.float32, device=self.device)
         emb = torch.empty((B, Tf, self.arch.dimension), dtype=torch.float32, device=self.device)
-        ws = self._workspace(B, L)
+        ws = self._workspace(B, Tf * self.hop_length)
         self._check(self.lib.fc_decode_codes(self._h, _ptr(tokens), B, Tf, n_q, L, _ptr(wav), _ptr(emb), _ptr(ws), ws.numel(),
                                              self._stream()))
         return wav, emb
@@ -263,11 +273,11 @@ class CodecEngine:
             return torch.cat([self.decode_emb(emb[i:i + self.micro_batch],
                                               None if scale is None else scale.reshape(-1)[i:i + self.micro_batch], out_len)
                               for i in range(0, B, self.micro_batch)], 0)
-        L = Tf * self.hop_length
+        L = self.decoded_samples(Tf)
         out_len = L if out_len is None else int(out_len)
         sc = None if scale is None else self._dev(scale.reshape(-1), torch.float32)
         wav = torch.empty((B, 1, out_len), dtype=torch.float32, device=self.device)
-        ws = self._workspace(B, L)
+        ws = self._workspace(B, Tf * self.hop_length)
         self._check(self.lib.fc_decode_emb(self._h, _ptr(emb), _ptr(sc), B, Tf, out_len, _ptr(wav), _ptr(ws), ws.numel(),
                                            self._stream()))
         return wav

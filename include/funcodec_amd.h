@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define FC_MAX_RATIOS 8
-#define FC_ABI_VERSION 3
+#define FC_ABI_VERSION 4
 
 typedef struct fc_engine fc_engine;
 
@@ -59,6 +59,13 @@ typedef struct fc_arch {
     int32_t causal;                 /* 1: all conv padding on the left, transposed convs trimmed on the right only */
     int32_t n_residual_layers;      /* residual blocks per stage (1 in the encodec recipes, 3 in the SoundStream recipe) */
     int32_t dilation_base;          /* block j of a stage dilates its k=3 conv by dilation_base**j (seanet_encoder.py:127-133) */
+    /* ABI version 4: the STFT-domain codec (FreqCodec, funcodec/models/codec_freq.py:123-210; SEANetEncoder2d / SEANetDecoder2d,
+     * funcodec/models/encoder/seanet_encoder.py:252-363, decoder/seanet_decoder.py:244-360).  model_type 0 ignores the rest. */
+    int32_t model_type;             /* 0 = encodec (time domain), 1 = freq_codec with codec_domain [mag_phase, mag_phase] */
+    int32_t input_channels;         /* encoder input / decoder output channels of the 2-D nets (3: log-magnitude, phase re, im) */
+    int32_t n_fft;                  /* 512  (model_conf.domain_conf.n_fft) */
+    int32_t stft_hop;               /* 160  (model_conf.domain_conf.hop_length) */
+    int32_t ratios_f[FC_MAX_RATIOS];/* frequency ratios of the 2-D stages, decoder order (ratios[] holds the time ratios) */
 } fc_arch;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
@@ -86,6 +93,9 @@ int  fc_engine_finalize(fc_engine* e);
 int    fc_engine_hop_length(const fc_engine* e);
 /* frames emitted for n_samples: ceil at every encoder stride (SConv1d extra padding, conv.py:57-64). */
 int    fc_engine_frames(const fc_engine* e, int n_samples);
+/* samples the decoder emits for n_frames frames: n_frames * hop for the time-domain codec; stft_hop * (frames * time ratios - 1) for
+ * the STFT-domain codec (torch.istft with center=True).  Upper bound of `out_len` of the decode entry points. */
+int    fc_engine_decoded_samples(const fc_engine* e, int n_frames);
 /* bytes of caller-provided device scratch needed by any call with batch B and T samples (or Tf*hop). */
 size_t fc_engine_workspace_bytes(const fc_engine* e, int B, int T);
 
@@ -105,7 +115,7 @@ int fc_encode(fc_engine* e, const float* wav, int B, int T, int n_q,
 
 /* Encodec.inference_decoding_emb (codec_basic.py:804-836) = _decode_frame (:398-408) + SEANetDecoder.forward.
  *   emb   dev f32 [B,Tf,D];  scale dev f32 [B] or NULL (multiplied in when non-NULL, :406-407)
- *   wav   dev f32 [B,out_len], out_len <= Tf*hop (the first out_len samples are written) */
+ *   wav   dev f32 [B,out_len], out_len <= fc_engine_decoded_samples(Tf) (the first out_len samples are written) */
 int fc_decode_emb(fc_engine* e, const float* emb, const float* scale, int B, int Tf, int out_len,
                   float* wav, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -114,7 +124,8 @@ int fc_decode_emb(fc_engine* e, const float* emb, const float* scale, int B, int
 int fc_decode_codes(fc_engine* e, const int64_t* codes, int B, int Tf, int n_q, int out_len,
                     float* wav, float* emb_out, void* workspace, size_t workspace_bytes, void* stream);
 
-/* Encodec.inference (codec_basic.py:670-718): encode + decode in one enqueue; recon [B,T]. */
+/* Encodec.inference (codec_basic.py:670-718) / FreqCodec.inference (codec_freq.py): encode + decode in one enqueue;
+ * recon [B, min(T, fc_engine_decoded_samples(frames))] (= the reference's recon[:, :, :T]; always T for model_type 0). */
 int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int use_scale,
                      int64_t* codes, float* quantized, float* sub_quants, float* scale, float* recon,
                      void* workspace, size_t workspace_bytes, void* stream);

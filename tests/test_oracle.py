@@ -57,7 +57,7 @@ def test_c_oracle_rvq_matches_the_use_ddp_false_reference_quantiser():
 @pytest.mark.parametrize("name", [n for n, c in MAN["cases"].items() if c.get("kind") == "freq"])
 def test_freq_oracle_matches_reference_golden(name):
     """FreqCodec (STFT-domain 2-D SEANet): the restatement oracle/freq_oracle.py against the real reference's
-    outputs.  Oracle-first step for that row: the engine does not run this path yet (config.py refuses `model: freq_codec`)."""
+    outputs (the engine is held to the same fixtures in tests/test_gpu_parity.py)."""
     from freq_oracle import FreqOracle
     from freq_synth import freq_recipe_config, make_freq_state_dict
     c = MAN["cases"][name]
@@ -74,8 +74,12 @@ def test_freq_oracle_matches_reference_golden(name):
     else:
         assert rep["frames_bad"] <= max(1, rep["frames"] // 50)
     from funcodec_amd.config import arch_from_config
-    with pytest.raises(NotImplementedError):
-        arch_from_config(cfg)                      # refused, not mis-decoded, until the kernels exist
+    arch = arch_from_config(cfg)
+    assert (arch.model_type, arch.ratios, arch.ratios_f, arch.hop_length) == ("freq_codec", (1, 1, 2, 1), (4, 4, 4, 4), 320)
+    assert arch.frames_for(c["samples"]) == g["indices"].shape[2]
+    for key, bad in (("encoder", "encodec_seanet_encoder"), ("model_conf", dict(cfg["model_conf"], codec_domain=["stft", "stft"]))):
+        with pytest.raises(NotImplementedError):
+            arch_from_config(dict(cfg, **{key: bad}))      # other FreqCodec flavours are refused, not mis-decoded
 
 
 @pytest.mark.parametrize("name", SEG)
