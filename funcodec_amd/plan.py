@@ -24,6 +24,8 @@ class ConvOp:
     stride: int = 1
     role: str = ""       # "first" | "shortcut" | "block1" | "block3" | "down" | "up" | "last" | "lstm"
     dilation: int = 1
+    kf: int = 0          # 2-D layers (freq_codec): kernel / stride along frequency; 0 = a 1-D layer
+    sf: int = 1
 
 
 def encoder_plan(a: ArchSpec) -> List[ConvOp]:
@@ -83,15 +85,77 @@ def decoder_plan(a: ArchSpec) -> List[ConvOp]:
     return ops
 
 
+def encoder_plan_2d(a: ArchSpec) -> List[ConvOp]:
+    """SEANetEncoder2d (seanet_encoder.py:252-363): 2-D convs over [frequency, time] down to one frequency bin, then the
+    1-D LSTM and last conv.  `k` / `stride` hold the TIME extent, `kf` / `sf` the frequency extent."""
+    ops: List[ConvOp] = []
+    idx, mult = 0, 1
+    ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", a.input_channels, a.n_filters, a.kernel_size, 1, "first", kf=a.kernel_size))
+    idx += 1
+    for fr, tr in zip(reversed(a.ratios_f), reversed(a.ratios)):
+        c = mult * a.n_filters
+        hid = c // a.compress
+        for j in range(a.n_residual_layers):
+            p = f"encoder.model.{idx}"
+            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c, c, 1, 1, "shortcut", kf=1))
+            ops.append(ConvOp("conv", f"{p}.block.1.conv", c, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j, kf=a.residual_kernel_size))
+            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c, 1, 1, "block3", kf=1))
+            idx += 1
+        idx += 1          # ELU
+        ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", c, 2 * c, 2 * tr, tr, "down", kf=2 * fr, sf=fr))
+        idx += 1
+        mult *= 2
+    idx += 1              # ReshapeModule
+    c = mult * a.n_filters
+    if a.lstm_layers > 0:
+        ops.append(ConvOp("lstm", f"encoder.model.{idx}.lstm", c, c, role="lstm"))
+        idx += 1
+    idx += 1              # ELU
+    ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", c, a.dimension, a.last_kernel_size, 1, "last"))
+    return ops
+
+
+def decoder_plan_2d(a: ArchSpec) -> List[ConvOp]:
+    """SEANetDecoder2d (seanet_decoder.py:244-360)."""
+    ops: List[ConvOp] = []
+    idx, mult = 0, 2 ** len(a.ratios)
+    c = mult * a.n_filters
+    ops.append(ConvOp("conv", f"decoder.model.{idx}.conv", a.dimension, c, a.kernel_size, 1, "first"))
+    idx += 1
+    if a.lstm_layers > 0:
+        ops.append(ConvOp("lstm", f"decoder.model.{idx}.lstm", c, c, role="lstm"))
+        idx += 1
+    idx += 1              # ReshapeModule
+    for fr, tr in zip(a.ratios_f, a.ratios):
+        c = mult * a.n_filters
+        idx += 1          # ELU
+        ops.append(ConvOp("convtr", f"decoder.model.{idx}.convtr", c, c // 2, 2 * tr, tr, "up", kf=2 * fr, sf=fr))
+        idx += 1
+        c2 = c // 2
+        hid = c2 // a.compress
+        for j in range(a.n_residual_layers):
+            p = f"decoder.model.{idx}"
+            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c2, c2, 1, 1, "shortcut", kf=1))
+            ops.append(ConvOp("conv", f"{p}.block.1.conv", c2, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j, kf=a.residual_kernel_size))
+            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c2, 1, 1, "block3", kf=1))
+            idx += 1
+        mult //= 2
+    idx += 1              # ELU
+    ops.append(ConvOp("conv", f"decoder.model.{idx}.conv", a.n_filters, a.input_channels, a.last_kernel_size, 1, "last", kf=a.last_kernel_size))
+    return ops
+
+
 def expected_tensors(a: ArchSpec) -> Dict[str, Tuple[int, ...]]:
     """Every checkpoint tensor the hot path consumes: key -> shape (reference layout)."""
     out: Dict[str, Tuple[int, ...]] = {}
     gn = a.norm == "time_group_norm"
     wn = a.norm == "weight_norm"      # torch.nn.utils.weight_norm: weight = weight_v * (weight_g / ||weight_v||), norm over dims != 0
-    for op in encoder_plan(a) + decoder_plan(a):
+    ops = encoder_plan_2d(a) + decoder_plan_2d(a) if a.model_type == "freq_codec" else encoder_plan(a) + decoder_plan(a)
+    for op in ops:
         if op.kind in ("conv", "convtr"):
             inner = op.kind
-            wshape = (op.cout, op.cin, op.k) if op.kind == "conv" else (op.cin, op.cout, op.k)
+            kk = (op.kf, op.k) if op.kf else (op.k,)          # Conv2d weights are [out, in, k_frequency, k_time]
+            wshape = (op.cout, op.cin) + kk if op.kind == "conv" else (op.cin, op.cout) + kk
             if wn:
                 out[f"{op.key}.{inner}.weight_g"] = (wshape[0], 1, 1)
                 out[f"{op.key}.{inner}.weight_v"] = wshape

@@ -11,11 +11,13 @@ import numpy as np
 
 def freq_recipe_config(name: str) -> Dict[str, Any]:
     """`freqmp`: egs/LibriTTS/codec/conf/freqcodec_mag_phase_16k_n32_600k_step.yaml:1-59 (16.2 M parameters);
-    `tinyfreq`: the same shape with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
-    tiny = name == "tinyfreq"
-    if name not in ("freqmp", "tinyfreq"):
+    `freqmp640`: ..._ds640.yaml (time ratios 2,1,2,1, 640 samples per frame);
+    `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
+    tiny = name.startswith("tinyfreq")
+    if name not in ("freqmp", "tinyfreq", "freqmp640", "tinyfreq640"):
         raise KeyError(name)
-    ratios = [[4, 1], [4, 1], [4, 2], [4, 1]]
+    ds640 = name.endswith("640")
+    ratios = [[4, 2], [4, 1], [4, 2], [4, 1]] if ds640 else [[4, 1], [4, 1], [4, 2], [4, 1]]
     enc = {"ratios": ratios, "norm": "time_group_norm", "norm_params": {"num_groups": 1}, "causal": False, "dilation_base": 1}
     dec = dict(enc, channels=3)
     if tiny:
@@ -27,7 +29,7 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
         "quantizer": "costume_quantizer",
         "quantizer_conf": {"codebook_size": 64 if tiny else 1024, "num_quantizers": 4 if tiny else 32, "ema_decay": 0.99,
                            "kmeans_init": True, "sampling_rate": 16000, "quantize_dropout": True,
-                           "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 320},
+                           "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 640 if ds640 else 320},
         "decoder": "encodec_seanet_decoder_2d", "decoder_conf": dec,
         "discriminator": "multiple_disc", "discriminator_conf": {"disc_conf_list": []},
         "model": "freq_codec",

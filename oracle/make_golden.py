@@ -86,6 +86,9 @@ SLIM = {"ds640_b2_t160000", "ds640_wav_jamendo_0027"}
 FREQ_CASES = [
     ("tinyfreq_b2_t2000", "tinyfreq", 3, "tones", 81, 2, 2000),
     ("freqmp_b1_t16000", "freqmp", 0, "noise", 82, 1, 16000),
+    # ..._ds640.yaml shape (time ratios 2,1,2,1); 3100 samples = an EVEN number of STFT frames, where the decoder emits fewer
+    # samples than the input had and the reference's recon[:, :, :T] comes out shorter than T
+    ("tinyfreq640_b2_t3100", "tinyfreq640", 5, "tones", 83, 2, 3100),
 ]
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [
@@ -274,6 +277,10 @@ def main():
                                            frames=int(idx[0].shape[2]),
                                            note="torchaudio Spectrogram / InverseSpectrogram restated over torch.stft / istft (oracle/ref_shim.py)")
             print(f"[golden] {name}: FreqCodec idx{tuple(idx[0].shape)} recon{tuple(recon.shape)} oracle==reference OK")
+            if cfg_name == "freqmp":              # checkpoint key list of the real FreqCodec model (format pin)
+                keys = {k: list(v.shape) for k, v in ref_sd.items() if k.startswith(("encoder.", "decoder.", "quantizer."))}
+                with open(os.path.join(GOLD, "state_dict_keys_freqmp.json"), "wt") as f:
+                    json.dump(keys, f, indent=0, sort_keys=True)
         if only is not None:
             old = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
             old["cases"].update(manifest["cases"])

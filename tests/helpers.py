@@ -44,6 +44,30 @@ def oracle_for(cfg_name, seed, decay=1.0):
     return Oracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
 
 
+@functools.lru_cache(maxsize=4)
+def freq_state_for(cfg_name, seed):
+    """FreqCodec cases: recipe config, ArchSpec and the seeded 2-D checkpoint (oracle/freq_synth.py)."""
+    from freq_synth import freq_recipe_config, make_freq_state_dict
+    cfg = freq_recipe_config(cfg_name)
+    return cfg, arch_from_config(cfg), make_freq_state_dict(cfg, seed)
+
+
+@functools.lru_cache(maxsize=4)
+def freq_engine_for(cfg_name, seed):
+    from funcodec_amd.model import EncodecMI355X
+    cfg, arch, sd = freq_state_for(cfg_name, seed)
+    m = EncodecMI355X(arch, "cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m
+
+
+@functools.lru_cache(maxsize=4)
+def freq_oracle_for(cfg_name, seed):
+    from freq_oracle import FreqOracle
+    cfg, arch, sd = freq_state_for(cfg_name, seed)
+    return FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
+
+
 def audio(B, T, seed, kind="noise"):
     """Test audio of a golden case: seeded synthetic audio, or (kind "wav:<name>") one of the reference's own demo
     recordings committed under tests/golden/wav/ (decoded like the product's reader: PCM16 / 2^15)."""

@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 MAN = manifest()
 E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
+FREQ = [n for n, c in MAN["cases"].items() if c.get("kind") == "freq"]
 
 # tolerances (north_star): integer codec indices bit-exact; waveforms within 1e-4 RMS
 WAV_RMS_TOL = 1e-4
@@ -495,6 +496,105 @@ def _prefix_before(flip_frames, Tf, hop, b):
     its convolutions reach a few frames back): the reconstruction must still match there."""
     ts = [n - b * Tf for n in flip_frames if b * Tf <= n < (b + 1) * Tf]
     return None if not ts else max(0, (min(ts) - 8) * hop)
+
+
+# ---- FreqCodec: STFT-domain codec over the 2-D SEANet (SURVEY.md §8f rank 2) -------------------------
+@pytest.mark.parametrize("name", FREQ)
+def test_freq_codec_against_reference_golden(name):
+    """FreqCodec.inference / inference_decoding / inference_decoding_emb (codec_freq.py:668-834) against the real reference's
+    outputs: bit-exact indices and quantised embeddings, waveform within 1e-4 RMS; the reconstruction is as long as the
+    reference's (shorter than the input when the utterance has an even number of STFT frames)."""
+    from helpers import freq_engine_for, freq_state_for
+    c = MAN["cases"][name]
+    m = freq_engine_for(c["config"], c["weight_seed"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    g = golden(name)
+    r = m.engine.encode(wav, c["n_q"], want_enc_out=True)
+    assert rms(r["enc_out"], g["encoder_out"]) < 1e-4
+    assert float(((r["scale"].cpu() - torch.from_numpy(g["scale"])).abs() / torch.from_numpy(g["scale"])).max()) < 1e-5
+    rep = index_report(r["codes"], g["indices"].astype(np.int64))
+    if rep["mismatched_indices"]:
+        _assert_flips_are_near_ties(freq_state_for(c["config"], c["weight_seed"])[2]["quantizer.rq.model.embed"], g["encoder_out"],
+                                    g["indices"].astype(np.int64), r["codes"], got_enc=r["enc_out"], max_frames=1)
+    else:
+        assert rms(r["quantized"], g["quantized"]) == 0.0
+    r2 = m.engine.encode_decode(wav, c["n_q"], use_scale=True)
+    m.engine.check_status()
+    assert torch.equal(r2["codes"], r["codes"])
+    assert tuple(r2["recon"].shape) == g["recon"].shape                 # (B, 1, min(T, decoded samples))
+    if not rep["mismatched_indices"]:
+        assert rms(r2["recon"], g["recon"]) < WAV_RMS_TOL * float(np.sqrt((g["recon"] ** 2).mean())) * 10
+    tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
+    w2, emb = m.engine.decode_codes(tok)
+    assert rms(emb, g["quantized"]) == 0.0
+    w3 = m.engine.decode_emb(torch.from_numpy(g["quantized"]))
+    assert w2.shape[-1] == m.engine.decoded_samples(g["indices"].shape[2]) and torch.equal(w2, w3)
+    n = g["recon"].shape[-1]
+    sc = torch.from_numpy(g["scale"]).view(-1, 1, 1)
+    assert rms(w2.cpu()[:, :, :n] * sc, g["recon"]) < WAV_RMS_TOL * float(np.sqrt((g["recon"] ** 2).mean())) * 10
+
+
+@pytest.mark.parametrize("cfg_name,seed,B,T,kind,bw,use_scale", [
+    ("tinyfreq", 11, 3, 1777, "tones", None, True),        # odd length, 12 STFT frames (even -> recon shorter than the input)
+    ("tinyfreq", 11, 1, 400, "noise", 2000, False),        # 3 STFT frames, 2 code frames; reduced bit width; no rescale
+    ("tinyfreq640", 12, 2, 5000, "noise", None, True),     # time ratios 2,1,2,1
+    ("freqmp", 2, 2, 8000, "tones", 4000, True),           # the recipe shape
+])
+def test_freq_codec_against_oracle_fresh_inputs(cfg_name, seed, B, T, kind, bw, use_scale):
+    from helpers import freq_engine_for, freq_oracle_for
+    m, orc = freq_engine_for(cfg_name, seed), freq_oracle_for(cfg_name, seed)
+    wav = audio(B, T, 2000 + T, kind)
+    o = orc.inference(wav, bit_width=bw, use_scale=use_scale)
+    ret = m.inference(wav.cuda().unsqueeze(1), bit_width=bw, use_scale=use_scale)
+    m.engine.check_status()
+    rep = index_report(ret["code_indices"][0], o["code_indices"][0])
+    assert ret["recon_speech"].shape == o["recon_speech"].shape
+    assert (ret["code_embeddings"][0][1] is None) == (not use_scale)
+    if rep["frames_bad"]:
+        _assert_flips_are_near_ties(orc.embed, o["encoder_out"], o["code_indices"][0], ret["code_indices"][0], max_frames=1)
+    else:
+        ref_rms = float(o["recon_speech"].double().pow(2).mean().sqrt())
+        assert rms(ret["recon_speech"], o["recon_speech"]) < 1e-3 * ref_rms
+        assert rms(ret["code_embeddings"][0][0], o["code_embeddings"][0][0]) == 0.0
+        assert rms(ret["sub_quants"][0], o["sub_quants"][0]) == 0.0
+
+
+def test_freq_codec_batch_independence_and_determinism():
+    """Each utterance of a batch is its own STFT image / GroupNorm statistics / LSTM state: rows of a batched call equal the
+    single-utterance calls bit for bit, twice."""
+    from helpers import freq_engine_for
+    m = freq_engine_for("freqmp", 2)
+    wav = audio(5, 24000, 77, "tones").cuda()
+    a = m.engine.encode_decode(wav, 32)
+    b = m.engine.encode_decode(wav, 32)
+    assert torch.equal(a["codes"], b["codes"]) and torch.equal(a["recon"], b["recon"])
+    for i in (0, 4):
+        one = m.engine.encode_decode(wav[i:i + 1], 32)
+        assert torch.equal(one["codes"][:, 0], a["codes"][:, i]) and torch.equal(one["recon"][0], a["recon"][i])
+    m.engine.check_status()
+
+
+def test_freq_codec_speech2token_dropin(tmp_path):
+    """The reference's own entry point over a FreqCodec config.yaml + model.pth pair."""
+    import yaml
+    from helpers import freq_state_for, freq_oracle_for
+    from funcodec_amd.bin.codec_inference import Speech2Token
+    cfg, arch, sd = freq_state_for("tinyfreq", 11)
+    with open(tmp_path / "config.yaml", "wt") as f:
+        yaml.safe_dump(cfg, f)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp_path / "model.pth")
+    s2t = Speech2Token(str(tmp_path / "config.yaml"), str(tmp_path / "model.pth"), device="cuda")
+    orc = freq_oracle_for("tinyfreq", 11)
+    wav = audio(2, 3200, 5, "tones")
+    idx, embs, recon, subs = s2t(wav, run_mod="inference")
+    o = orc.inference(wav, None, True)
+    assert torch.equal(idx[0].cpu(), o["code_indices"][0]) and recon.shape == o["recon_speech"].shape
+    assert rms(recon, o["recon_speech"]) < 1e-3 * float(o["recon_speech"].pow(2).mean().sqrt())
+    tok = idx[0].permute(1, 2, 0).contiguous()
+    _, _, w2, _ = s2t(tok, run_mod="decode")
+    _, _, w3, _ = s2t(embs[0][0], run_mod="decode_emb")
+    assert torch.equal(w2, w3) and w2.shape[-1] == s2t.model.engine.decoded_samples(tok.shape[1])
+    assert s2t.model.quantizer.encoder_hop_length == 320
 
 
 # ---- the drop-in API ------------------------------------------------------------------------------

@@ -46,6 +46,21 @@ def test_checkpoint_contract_matches_reference_keys(name):
     assert unused == {"quantizer.rq.model.inited", "quantizer.rq.model.cluster_size", "quantizer.rq.model.embed_avg"}
 
 
+def test_freq_codec_checkpoint_contract_matches_reference_keys():
+    """FreqCodec (2-D SEANet): Conv2d weights [out, in, k_frequency, k_time], same key scheme."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
+    from freq_synth import freq_recipe_config
+    arch = arch_from_config(freq_recipe_config("freqmp"))
+    ref = json.load(open(os.path.join(GOLD, "state_dict_keys_freqmp.json")))
+    want = expected_tensors(arch)
+    assert CodecEngine(arch).expected_tensors() == want
+    assert want["encoder.model.6.conv.conv.weight"] == (128, 64, 8, 4) and want["decoder.model.4.convtr.convtr.weight"] == (512, 256, 8, 2)
+    for k, shape in want.items():
+        assert tuple(ref[k]) == tuple(shape), (k, ref.get(k), shape)
+    assert {k for k in ref if k not in want} == {"quantizer.rq.model.inited", "quantizer.rq.model.cluster_size", "quantizer.rq.model.embed_avg"}
+
+
 def test_arch_from_recipe_configs():
     a = arch_from_config(recipe_config("ds640"))
     assert a.ratios == (8, 5, 4, 2, 2) and a.hop_length == 640 and a.bottleneck_channels == 1024

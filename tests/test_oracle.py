@@ -75,7 +75,9 @@ def test_freq_oracle_matches_reference_golden(name):
         assert rep["frames_bad"] <= max(1, rep["frames"] // 50)
     from funcodec_amd.config import arch_from_config
     arch = arch_from_config(cfg)
-    assert (arch.model_type, arch.ratios, arch.ratios_f, arch.hop_length) == ("freq_codec", (1, 1, 2, 1), (4, 4, 4, 4), 320)
+    ds640 = c["config"].endswith("640")
+    assert (arch.model_type, arch.ratios, arch.ratios_f, arch.hop_length) == \
+        ("freq_codec", (2, 1, 2, 1) if ds640 else (1, 1, 2, 1), (4, 4, 4, 4), 640 if ds640 else 320)
     assert arch.frames_for(c["samples"]) == g["indices"].shape[2]
     for key, bad in (("encoder", "encodec_seanet_encoder"), ("model_conf", dict(cfg["model_conf"], codec_domain=["stft", "stft"]))):
         with pytest.raises(NotImplementedError):
