@@ -10,6 +10,8 @@ synthetic 10 s / 16 kHz audio on the 16k-nq32ds640 architecture:
   N = 1: BASELINE.json configs[1], 16 x 10 s in ONE engine call;
   N > 1: BASELINE.json configs[2], 128 utterances per GPU (1024 at N = 8) walked in micro-batches of 32 (every op of the path is
          per-utterance, results do not depend on the micro-batch), the int64 code indices all-gathered over RCCL inside the step.
+`--workload freqcodec` is a SIDE measurement of the next scope row (BASELINE.json configs[3]: the STFT-domain FreqCodec recipe, 64 x 10 s
+on one GPU); the contract metric stays the default.
 Inputs are resident in HBM when timing starts.  The timed region runs WITHOUT the in-engine HIP-event brackets; the per-kernel
 table (and with it `roofline`) comes from a second, separate pass of the same step.  Rank 0 prints ONE JSON line.
 """
@@ -57,16 +59,29 @@ def physical_cores() -> int:
     return os.cpu_count() or 1
 
 
+def is_freq() -> bool:
+    return CONFIG.startswith(("freqmp", "tinyfreq"))
+
+
+def synthetic_state(cfg, arch):
+    from funcodec_amd.synth import make_freq_state_dict, make_state_dict
+    return make_freq_state_dict(cfg, 0) if is_freq() else make_state_dict(arch, 0)
+
+
 def cpu_baseline(utts: int = MICRO_BATCH):
     """the CPU PyTorch path on Config B's batch (16 x 10 s), 1 warm-up + median of 3, thread count stated.
     What runs is the oracle (ATen-CPU restatement of the reference path, pinned bit-exact against the real reference in the
     build container; the reference itself cannot travel to the GPU box) -> kind "port"."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from torch_oracle import Oracle
     from funcodec_amd.config import arch_from_config, recipe_config
-    from funcodec_amd.synth import make_state_dict, synthetic_audio
+    from funcodec_amd.synth import synthetic_audio
     cfg = recipe_config(CONFIG)
-    sd = make_state_dict(arch_from_config(cfg), 0)
+    sd = synthetic_state(cfg, arch_from_config(cfg))
+    if is_freq():
+        from freq_oracle import FreqOracle as Oracle
+        utts = min(utts, 4)                           # bounded sample: the 2-D net costs ~10x the 1-D one per audio second on CPU
+    else:
+        from torch_oracle import Oracle
     orc = Oracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
     default_threads = torch.get_num_threads()
     cores = physical_cores()
@@ -97,8 +112,9 @@ def cpu_baseline(utts: int = MICRO_BATCH):
             "runs_s": [round(r, 3) for r in runs], "median_s": round(med, 3),
             "probe_audio_s_per_s": {str(k): round(2 * SAMPLES / 16000.0 / v, 2) for k, v in probe.items()},
             "seconds": round(time.perf_counter() - t_all, 1),
-            "sample": f"oracle/torch_oracle.py (same ATen CPU kernels as the reference's PyTorch path), the FULL benchmark batch "
-                      f"({utts} x 10 s, ds640, n_q=32, run_mod=inference), 1 warm-up + median of 3 at {best} threads (best of a "
+            "sample": f"oracle/{'freq_oracle' if is_freq() else 'torch_oracle'}.py (same ATen CPU kernels as the reference's PyTorch path), "
+                      + ("a bounded sample of the benchmark batch " if is_freq() else "the FULL benchmark batch ") +
+                      f"({utts} x 10 s, {CONFIG}, n_q=32, run_mod=inference), 1 warm-up + median of 3 at {best} threads (best of a "
                       f"2-utterance probe over physical-core / 32 / 16 threads)"}
 
 
@@ -153,7 +169,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-event-profile", action="store_true", help="skip the separate per-kernel HIP-event pass (no `roofline`)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the separate per-kernel pass")
+    ap.add_argument("--workload", choices=("encodec", "freqcodec"), default="encodec",
+                    help="encodec = the contract metric (BASELINE.json configs[1] / [2]); freqcodec = side measurement of configs[3]")
     args = ap.parse_args()
+    global CONFIG, MICRO_BATCH
+    if args.workload == "freqcodec" and not is_freq():
+        CONFIG = "freqmp"
+    if is_freq() and not os.environ.get("FC_BENCH_MICRO"):
+        MICRO_BATCH = 64                                   # configs[3]: batch 64 in one engine call
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -173,17 +196,17 @@ def main():
     from funcodec_amd.config import arch_from_config, recipe_config
     from funcodec_amd.model import EncodecMI355X
     from funcodec_amd.parallel import gather_codes, shard_range
-    from funcodec_amd.synth import make_state_dict, synthetic_audio
+    from funcodec_amd.synth import synthetic_audio
 
     cfg = recipe_config(CONFIG)
     arch = arch_from_config(cfg)
     model = EncodecMI355X(arch, f"cuda:{local_rank}")
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(arch, 0).items()})
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state(cfg, arch).items()})
     eng = model.engine
     eng.micro_batch = max(eng.micro_batch, MICRO_BATCH)      # one engine call per bench micro-batch
 
     # N = 1: Config B (16 utterances, one engine call).  N > 1: Config C (128 utterances per GPU, micro-batches of 16).
-    utts_per_gpu = int(os.environ.get("FC_BENCH_UTTS", MICRO_BATCH if world == 1 else 128))
+    utts_per_gpu = int(os.environ.get("FC_BENCH_UTTS", MICRO_BATCH if world == 1 else 128))     # freqcodec: 64 (configs[3])
     total_utts = utts_per_gpu * world
     lo, hi = shard_range(total_utts, rank, world)
     shard_sizes = [shard_range(total_utts, r, world)[1] - shard_range(total_utts, r, world)[0] for r in range(world)]
@@ -250,8 +273,12 @@ def main():
             "ms_per_step": round(step_s * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE.json configs[1]: " if world == 1 else "BASELINE.json configs[2]: ") +
-                                   f"encodec 16k-nq32ds640 (57.6M, synthetic seeded checkpoint), run_mod=inference (encode + 32-stage RVQ "
+            "config": {"workload": (("BASELINE.json configs[3] shape: freqcodec mag_phase 16k recipe (egs/LibriTTS/codec/conf/"
+                                    "freqcodec_mag_phase_16k_n32_600k_step.yaml, 16.2M + codebooks, synthetic seeded checkpoint; the released "
+                                    "gr1 config.yaml is not in the reference tree), STFT -> 2-D SEANet -> RVQ -> 2-D SEANet -> iSTFT, ") if is_freq() else
+                                   (("BASELINE.json configs[1]: " if world == 1 else "BASELINE.json configs[2]: ") +
+                                    "encodec 16k-nq32ds640 (57.6M, synthetic seeded checkpoint), ")) +
+                                   f"run_mod=inference (encode + 32-stage RVQ "
                                    f"+ decode), {utts_per_gpu} x 10 s utterances per GPU in micro-batches of {MICRO_BATCH}, n_q=32",
                        "utterances_per_gpu": utts_per_gpu, "samples_per_utterance": SAMPLES, "micro_batch": MICRO_BATCH,
                        "global_utterances": total_utts,

@@ -290,7 +290,39 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
 # Values follow egs/LibriTTS/codec/conf/encodec_16k_n32_600k_step_ds640.yaml:1-53 (ds640) and the
 # class-default ratios of SEANetEncoder (seanet_encoder.py:92) for ds320.
 # ----------------------------------------------------------------------------------------------
+def freq_recipe_config(name: str) -> Dict[str, Any]:
+    """`freqmp`: egs/LibriTTS/codec/conf/freqcodec_mag_phase_16k_n32_600k_step.yaml:1-59 (16.2 M parameters);
+    `freqmp640`: ..._ds640.yaml (time ratios 2,1,2,1, 640 samples per frame);
+    `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
+    tiny = name.startswith("tinyfreq")
+    if name not in ("freqmp", "tinyfreq", "freqmp640", "tinyfreq640"):
+        raise KeyError(name)
+    ds640 = name.endswith("640")
+    ratios = [[4, 2], [4, 1], [4, 2], [4, 1]] if ds640 else [[4, 1], [4, 1], [4, 2], [4, 1]]
+    enc = {"ratios": ratios, "norm": "time_group_norm", "norm_params": {"num_groups": 1}, "causal": False, "dilation_base": 1}
+    dec = dict(enc, channels=3)
+    if tiny:
+        enc.update(n_filters=4, dimension=16)
+        dec.update(n_filters=4)
+    return {
+        "input_size": 3, "sampling_rate": 16000,
+        "encoder": "encodec_seanet_encoder_2d", "encoder_conf": enc,
+        "quantizer": "costume_quantizer",
+        "quantizer_conf": {"codebook_size": 64 if tiny else 1024, "num_quantizers": 4 if tiny else 32, "ema_decay": 0.99,
+                           "kmeans_init": True, "sampling_rate": 16000, "quantize_dropout": True,
+                           "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 640 if ds640 else 320},
+        "decoder": "encodec_seanet_decoder_2d", "decoder_conf": dec,
+        "discriminator": "multiple_disc", "discriminator_conf": {"disc_conf_list": []},
+        "model": "freq_codec",
+        "model_conf": {"odim": 16 if tiny else 128, "multi_spectral_window_powers_of_two": [], "target_sample_hz": 16000,
+                       "audio_normalize": True, "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None,
+                       "codec_domain": ["mag_phase", "mag_phase"]},
+    }
+
+
 def recipe_config(name: str) -> Dict[str, Any]:
+    if name.startswith(("freqmp", "tinyfreq")):
+        return freq_recipe_config(name)
     if name == "ds320seg":   # ds320 run in the segmented overlap-add mode (0.5 s frames, 10 % overlap)
         cfg = recipe_config("ds320")
         cfg["model_conf"]["segment_dur"] = 0.5

@@ -651,6 +651,7 @@ int pack_conv2d(fc_engine* e, ConvLayer& L) {
                 for (int b = 0; b < kt; ++b)
                     wg[((size_t)m * (kf * C) + (size_t)a * C + ci) * kt + b] = W[(((size_t)m * C + ci) * kf + a) * kt + b];
     if (pack_gemm(e, L, wg, Bv)) return 1;
+    if (L.cout <= 4 && L.stride == 1 && L.sf == 1 && upload(e, wg, &L.w_plain)) return 1;      // [cout][kf * C][kt]: FMA kernel, no MFMA tile
     if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
     if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
     return 0;
@@ -863,7 +864,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
             char nm[64];
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1,
                      L.BM >= 128 ? 2 : 4, mode, nu, row ? "true" : "false");
-            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s>", c.k, c.s1.ptr ? "true" : "false");
+            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s, %d>", c.k, c.s1.ptr ? "true" : "false", c.M);
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);
@@ -1071,7 +1072,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
     c.B = B * Fo; c.Cin = L.cin; c.Tin = x0.T; c.M = L.M; c.Tout = g.Tout;
     c.k = L.gk; c.stride = L.gstride; c.dil = L.dil; c.padL = g.padL; c.padR = g.padR;
     c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
-    c.Fo = Fo; c.affC = C;
+    c.Fo = Fo; c.affC = C; c.w_plain = L.w_plain;
     c.in_sB0 = (long long)(x0.F + 2 * x0.halo) * rowsz; c.in_sB1 = (long long)sf * rowsz;
     const long long orow = (long long)L.cout * g.Tout;
     c.out = cx.dry ? nullptr : o.buf + (long long)out_halo * orow;
@@ -1094,6 +1095,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
             char nm[64];
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
                      row ? "true" : "false");
+            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s, %d>", c.k, c.s1.ptr ? "true" : "false", c.M);
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);
@@ -1176,6 +1178,7 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
             char nm[64];
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
                      row ? "true" : "false");
+            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s, %d>", c.k, c.s1.ptr ? "true" : "false", c.M);
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl / sf, by / sf);

@@ -165,8 +165,8 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
 }
 
 // =================================================================================================
-// 1b. Single-output-channel stride-1 conv (the decoder's last layer, 32 -> 1, k = 7): HBM-bound, and a 32-row MFMA tile
-//     would do 32x the necessary matrix work -> plain FMAs.  One workgroup = 1024 output samples of one utterance;
+// 1b. Stride-1 conv with 1..4 output channels (the decoder's last layer: 32 -> 1, k = 7; FreqCodec's last Conv2d: 7 rows x 32
+//     channels -> 3): a 32-row MFMA tile would do 8..32x the necessary matrix work -> plain FMAs.  One workgroup = 1024 output samples of one utterance;
 //     the (GroupNorm apply, residual add, ELU)'d input is staged 8 channels at a time into LDS ([8][1032], 16-byte
 //     loads and stores on interior tiles), every thread owns 4 consecutive outputs and reads its 4+k-1 slab columns
 //     with three 16-byte LDS loads per channel; the k weights of a channel come through scalar loads.  Same epilogue
@@ -174,28 +174,34 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
 // =================================================================================================
 struct Cout1Args {
     const float *src0, *aff0, *src1, *aff1;    // [B][Cin][T], per-(b,c) affine or null
-    const float* w;                            // [Cin][k]
-    float bias;
-    float* out;                                // [B][T]
+    const float* w;                            // [M][Cin][k]
+    const float* bias;                         // [M] device
+    float* out;                                // [B][M][T]
     double* partials;                          // [B][ntiles][2] or null
     int Cin, T, k, padL, Leff, elu;
     float alpha;
+    // two-level batch (2-D convs over frequency-major activations, see ConvArgs): b = breal * Fo + fo
+    int Fo, affC;
+    long long in_sB0, in_sB1, out_sB, out_sF, out_sM, part_sB0;
 };
 constexpr int C1_TN = 1024, C1_CH = 8, C1_ROW = 1032;
 
-template <int K, bool DUAL>
+template <int K, bool DUAL, int MO>
 __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     __shared__ __attribute__((aligned(16))) float Xs[C1_CH][C1_ROW];
     __shared__ double red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = blockIdx.x, b = blockIdx.y;
+    const int breal = p.Fo > 1 ? b / p.Fo : b, fo = p.Fo > 1 ? b - breal * p.Fo : 0;
     const int t0 = tile * C1_TN, tbase = t0 - p.padL;
     const bool interior = tbase >= 0 && tbase + C1_ROW <= p.T;
-    const float* s0 = p.src0 + (size_t)b * p.Cin * p.T;
-    const float* s1 = DUAL ? p.src1 + (size_t)b * p.Cin * p.T : s0;
-    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)b * p.Cin : nullptr;
-    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)b * p.Cin : nullptr;
+    const size_t in_off = (size_t)breal * p.in_sB0 + (size_t)fo * p.in_sB1;
+    const float* s0 = p.src0 + in_off;
+    const float* s1 = DUAL ? p.src1 + in_off : s0;
+    const bool wrap = p.affC != p.Cin;         // virtual channel = frequency row * affC + real channel
+    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)breal * p.affC : nullptr;
+    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)breal * p.affC : nullptr;
     // edge tiles: source index (reflect padding, conv.py:82-99) and validity of this thread's columns, once per tile
     int esrc[5]; unsigned emask = 0;
     if (!interior) {
@@ -217,7 +223,11 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
         if (p.elu) v = elu_f(v, p.alpha);
         return v;
     };
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[MO][4];
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
     for (int c0 = 0; c0 < p.Cin; c0 += C1_CH) {
         // ---- stage 8 channels
 #pragma unroll
@@ -226,8 +236,9 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
             const bool cok = c < p.Cin;
             const float* r0 = s0 + (size_t)(cok ? c : 0) * p.T;
             const float* r1 = s1 + (size_t)(cok ? c : 0) * p.T;
-            const float2 A = a0 ? a0[cok ? c : 0] : make_float2(1.f, 0.f);
-            const float2 A1 = a1 ? a1[cok ? c : 0] : make_float2(1.f, 0.f);
+            const int ca = !cok ? 0 : wrap ? c % p.affC : c;
+            const float2 A = a0 ? a0[ca] : make_float2(1.f, 0.f);
+            const float2 A1 = a1 ? a1[ca] : make_float2(1.f, 0.f);
             f32x4 v;
             if (interior) {
                 const f32x4 x0 = *(const f32x4u*)(r0 + tbase + 4 * tid);
@@ -265,30 +276,37 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
             const f32x4 q1 = *(const f32x4*)&Xs[r][4 * tid + 4];
             const f32x4 q2 = *(const f32x4*)&Xs[r][4 * tid + 8];
             const float x[12] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3], q2[0], q2[1], q2[2], q2[3]};
-            const float* wr = p.w + (size_t)c * K;                     // uniform address: scalar loads
 #pragma unroll
-            for (int kk = 0; kk < K; ++kk) {
-                const float wv = wr[kk];
+            for (int m = 0; m < MO; ++m) {
+                const float* wr = p.w + ((size_t)m * p.Cin + c) * K;   // uniform address: scalar loads
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, x[j + kk], acc[j]);
+                for (int kk = 0; kk < K; ++kk) {
+                    const float wv = wr[kk];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(wv, x[j + kk], acc[m][j]);
+                }
             }
         }
         __syncthreads();
     }
     // ---- epilogue: bias, store, statistics of the valid outputs
     float s1v = 0.f, s2v = 0.f;
-    float o[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        o[j] = acc[j] + p.bias;
-        const int n = t0 + 4 * tid + j;
-        if (n < p.T) { s1v += o[j]; s2v = fmaf(o[j], o[j], s2v); }
+    for (int m = 0; m < MO; ++m) {
+        float o[4];
+        const float bm = p.bias[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = acc[m][j] + bm;
+            const int n = t0 + 4 * tid + j;
+            if (n < p.T) { s1v += o[j]; s2v = fmaf(o[j], o[j], s2v); }
+        }
+        float* orow = p.out + (size_t)breal * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.out_sM + t0 + 4 * tid;
+        if (t0 + 4 * tid + 3 < p.T) *(f32x4u*)orow = (f32x4){o[0], o[1], o[2], o[3]};
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (t0 + 4 * tid + j < p.T) orow[j] = o[j];
     }
-    float* orow = p.out + (size_t)b * p.T + t0 + 4 * tid;
-    if (t0 + 4 * tid + 3 < p.T) *(f32x4u*)orow = (f32x4){o[0], o[1], o[2], o[3]};
-    else
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (t0 + 4 * tid + j < p.T) orow[j] = o[j];
     if (p.partials) {
         double d1 = (double)s1v, d2 = (double)s2v;
 #pragma unroll
@@ -299,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
         if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
         __syncthreads();
         if (tid == 0) {
-            const size_t slot = ((size_t)b * gridDim.x + tile) * 2;
+            const size_t slot = ((size_t)breal * p.part_sB0 + (size_t)fo * gridDim.x + tile) * 2;
             p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
             p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
         }
@@ -307,23 +325,32 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
 }
 
 bool conv_cout1_ok(const ConvLaunch& c) {
-    return c.w_plain && c.Fo <= 1 && c.M == 1 && c.stride == 1 && c.dil == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
+    return c.w_plain && c.M >= 1 && c.M <= 4 && c.store_lo <= 0 && c.store_hi >= c.Fo && c.stride == 1 && c.dil == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
            (c.k == 7 || c.k == 3 || c.k == 5) && c.padL + c.padR == c.k - 1;
 }
 
 static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
     Cout1Args a;
     a.src0 = c.s0.ptr; a.aff0 = c.s0.aff; a.src1 = c.s1.ptr; a.aff1 = c.s1.aff;
-    a.w = c.w_plain; a.bias = c.bias_host0; a.out = c.out; a.partials = c.partials;
+    a.w = c.w_plain; a.bias = c.bias; a.out = c.out; a.partials = c.partials;
     a.Cin = c.Cin; a.T = c.Tin; a.k = c.k; a.padL = c.padL;
+    a.Fo = c.Fo > 1 ? c.Fo : 1; a.affC = c.affC > 0 ? c.affC : c.Cin;
+    a.in_sB0 = c.in_sB0 ? c.in_sB0 : (long long)c.Cin * c.Tin; a.in_sB1 = c.in_sB1;
+    a.out_sB = c.out_sB; a.out_sF = c.out_sF; a.out_sM = c.out_sM;
+    a.part_sB0 = c.part_sB0 ? c.part_sB0 : (long long)a.Fo * ceil_div(c.Tout, C1_TN);
     const int maxpad = c.padL > c.padR ? c.padL : c.padR;
     a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
     a.elu = c.elu; a.alpha = c.alpha;
+    if (c.B > 65535) return hipErrorInvalidValue;
     dim3 grid(ceil_div(c.Tout, C1_TN), c.B), block(256);
+#define FC_C1M(KK, MM)                                                                                  \
+    case MM:                                                                                            \
+        if (c.s1.ptr) hipLaunchKernelGGL((conv_cout1_kernel<KK, true, MM>), grid, block, 0, st, a);     \
+        else hipLaunchKernelGGL((conv_cout1_kernel<KK, false, MM>), grid, block, 0, st, a);             \
+        break;
 #define FC_C1(KK)                                                                                       \
     case KK:                                                                                            \
-        if (c.s1.ptr) hipLaunchKernelGGL((conv_cout1_kernel<KK, true>), grid, block, 0, st, a);         \
-        else hipLaunchKernelGGL((conv_cout1_kernel<KK, false>), grid, block, 0, st, a);                 \
+        switch (c.M) { FC_C1M(KK, 1) FC_C1M(KK, 2) FC_C1M(KK, 3) FC_C1M(KK, 4) default: return hipErrorInvalidValue; } \
         break;
     switch (c.k) {
         FC_C1(3)
@@ -332,6 +359,7 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
         default: return hipErrorInvalidValue;
     }
 #undef FC_C1
+#undef FC_C1M
     return hipGetLastError();
 }
 

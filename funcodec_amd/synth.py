@@ -97,6 +97,92 @@ def synthetic_audio(batch: int, n_samples: int, seed: int = 1234, kind: str = "n
     return out.astype(np.float32)
 
 
+# ---- FreqCodec (2-D SEANet) checkpoints: same idea, Conv2d / ConvTranspose2d weight shapes -----------------------------
+def freq_plan(cfg: Dict[str, Any]) -> list:
+    """(kind, key prefix, weight shape) of every conv / convtr / lstm of the two 2-D nets, in Sequential order."""
+    enc, dec = cfg["encoder_conf"], cfg["decoder_conf"]
+    nf, dim = enc.get("n_filters", 32), enc.get("dimension", 128)
+    ks, lks, rks = enc.get("kernel_size", 7), enc.get("last_kernel_size", 7), enc.get("residual_kernel_size", 3)
+    ratios = [tuple(r) for r in enc["ratios"]]
+    nres, compress = enc.get("n_residual_layers", 1), enc.get("compress", 2)
+    ops: list = []
+    idx, mult = 0, 1
+    ops.append(("conv", f"encoder.model.{idx}.conv", (nf, cfg["input_size"], ks, ks)))
+    idx += 1
+    for fr, tr in reversed(ratios):
+        c = mult * nf
+        for _ in range(nres):
+            ops.append(("conv", f"encoder.model.{idx}.block.1.conv", (c // compress, c, rks, rks)))
+            ops.append(("conv", f"encoder.model.{idx}.block.3.conv", (c, c // compress, 1, 1)))
+            ops.append(("conv", f"encoder.model.{idx}.shortcut.conv", (c, c, 1, 1)))
+            idx += 1
+        idx += 1
+        ops.append(("conv", f"encoder.model.{idx}.conv", (2 * c, c, 2 * fr, 2 * tr)))
+        idx += 1
+        mult *= 2
+    idx += 1                                          # ReshapeModule
+    cb = mult * nf
+    ops.append(("lstm", f"encoder.model.{idx}.lstm", (cb,)))
+    idx += 2
+    ops.append(("conv", f"encoder.model.{idx}.conv", (dim, cb, lks)))
+    idx = 0
+    ops.append(("conv", f"decoder.model.{idx}.conv", (cb, dim, ks)))
+    idx += 1
+    ops.append(("lstm", f"decoder.model.{idx}.lstm", (cb,)))
+    idx += 2                                          # + ReshapeModule
+    for fr, tr in ratios:
+        c = mult * nf
+        idx += 1
+        ops.append(("convtr", f"decoder.model.{idx}.convtr", (c, c // 2, 2 * fr, 2 * tr)))
+        idx += 1
+        for _ in range(nres):
+            c2 = c // 2
+            ops.append(("conv", f"decoder.model.{idx}.block.1.conv", (c2 // compress, c2, rks, rks)))
+            ops.append(("conv", f"decoder.model.{idx}.block.3.conv", (c2, c2 // compress, 1, 1)))
+            ops.append(("conv", f"decoder.model.{idx}.shortcut.conv", (c2, c2, 1, 1)))
+            idx += 1
+        mult //= 2
+    idx += 1
+    ops.append(("conv", f"decoder.model.{idx}.conv", (dec.get("channels", 1), nf, lks, lks)))
+    return ops
+
+
+def make_freq_state_dict(cfg: Dict[str, Any], seed: int = 0) -> Dict[str, np.ndarray]:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd: Dict[str, np.ndarray] = {}
+
+    def uni(shape, bound):
+        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    for kind, key, shape in freq_plan(cfg):
+        if kind == "lstm":
+            h = shape[0]
+            b = 1.0 / np.sqrt(h)
+            for l in range(2):
+                sd[f"{key}.weight_ih_l{l}"] = uni((4 * h, h), b)
+                sd[f"{key}.weight_hh_l{l}"] = uni((4 * h, h), b)
+                sd[f"{key}.bias_ih_l{l}"] = uni((4 * h,), b)
+                sd[f"{key}.bias_hh_l{l}"] = uni((4 * h,), b)
+            continue
+        inner = "conv" if kind == "conv" else "convtr"
+        cout = shape[0] if kind == "conv" else shape[1]
+        fan_in = int(np.prod(shape[1:])) if kind == "conv" else int(shape[1] * np.prod(shape[2:]))
+        b = 1.0 / np.sqrt(fan_in)
+        sd[f"{key}.{inner}.weight"] = uni(shape, b)
+        sd[f"{key}.{inner}.bias"] = uni((cout,), b)
+        sd[f"{key}.norm.weight"] = (1.0 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
+        sd[f"{key}.norm.bias"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    q = cfg["quantizer_conf"]
+    nq, K, D = q["num_quantizers"], q["codebook_size"], cfg["encoder_conf"].get("dimension", 128)
+    embed = rng.standard_normal((nq, K, D)).astype(np.float32)
+    pfx = "quantizer.rq.model"
+    sd[f"{pfx}.inited"] = np.ones((nq, 1), np.float32)
+    sd[f"{pfx}.cluster_size"] = np.ones((nq, K), np.float32)
+    sd[f"{pfx}.embed"] = embed
+    sd[f"{pfx}.embed_avg"] = embed.copy()
+    return sd
+
+
 def write_checkpoint(out_dir: str, config: Dict[str, Any], state: Dict[str, np.ndarray]) -> (str, str):
     """Write ``config.yaml`` + ``model.pth`` exactly like a released FunCodec model directory."""
     import torch
@@ -113,5 +199,7 @@ def write_checkpoint(out_dir: str, config: Dict[str, Any], state: Dict[str, np.n
 def make_checkpoint(out_dir: str, name: str = "ds640", seed: int = 0,
                     codebook_sigma_decay: float = 1.0) -> (str, str):
     cfg = recipe_config(name)
+    if cfg.get("model") == "freq_codec":
+        return write_checkpoint(out_dir, cfg, make_freq_state_dict(cfg, seed))
     arch = arch_from_config(cfg)
     return write_checkpoint(out_dir, cfg, make_state_dict(arch, seed, codebook_sigma_decay))

@@ -1,124 +1,5 @@
-"""TEST INFRASTRUCTURE ONLY.  Seeded synthetic FreqCodec checkpoints in the reference's state_dict layout
-(SEANetEncoder2d / SEANetDecoder2d, funcodec/models/encoder/seanet_encoder.py:252-363, decoder/seanet_decoder.py:244-360) and
-the recipe configs of the FreqCodec golden cases.  Pure numpy, so the same tensors are re-created wherever the fixtures are
-checked.  (The 1-D product path has its own generator, funcodec_amd/synth.py.)"""
-from __future__ import annotations
-
-from typing import Any, Dict, List, Tuple
-
-import numpy as np
-
-
-def freq_recipe_config(name: str) -> Dict[str, Any]:
-    """`freqmp`: egs/LibriTTS/codec/conf/freqcodec_mag_phase_16k_n32_600k_step.yaml:1-59 (16.2 M parameters);
-    `freqmp640`: ..._ds640.yaml (time ratios 2,1,2,1, 640 samples per frame);
-    `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
-    tiny = name.startswith("tinyfreq")
-    if name not in ("freqmp", "tinyfreq", "freqmp640", "tinyfreq640"):
-        raise KeyError(name)
-    ds640 = name.endswith("640")
-    ratios = [[4, 2], [4, 1], [4, 2], [4, 1]] if ds640 else [[4, 1], [4, 1], [4, 2], [4, 1]]
-    enc = {"ratios": ratios, "norm": "time_group_norm", "norm_params": {"num_groups": 1}, "causal": False, "dilation_base": 1}
-    dec = dict(enc, channels=3)
-    if tiny:
-        enc.update(n_filters=4, dimension=16)
-        dec.update(n_filters=4)
-    return {
-        "input_size": 3, "sampling_rate": 16000,
-        "encoder": "encodec_seanet_encoder_2d", "encoder_conf": enc,
-        "quantizer": "costume_quantizer",
-        "quantizer_conf": {"codebook_size": 64 if tiny else 1024, "num_quantizers": 4 if tiny else 32, "ema_decay": 0.99,
-                           "kmeans_init": True, "sampling_rate": 16000, "quantize_dropout": True,
-                           "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 640 if ds640 else 320},
-        "decoder": "encodec_seanet_decoder_2d", "decoder_conf": dec,
-        "discriminator": "multiple_disc", "discriminator_conf": {"disc_conf_list": []},
-        "model": "freq_codec",
-        "model_conf": {"odim": 16 if tiny else 128, "multi_spectral_window_powers_of_two": [], "target_sample_hz": 16000,
-                       "audio_normalize": True, "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None,
-                       "codec_domain": ["mag_phase", "mag_phase"]},
-    }
-
-
-def freq_plan(cfg: Dict[str, Any]) -> List[Tuple[str, str, Tuple[int, ...]]]:
-    """(kind, key prefix, weight shape) of every conv / convtr / lstm of the two 2-D nets, in Sequential order."""
-    enc, dec = cfg["encoder_conf"], cfg["decoder_conf"]
-    nf, dim = enc.get("n_filters", 32), enc.get("dimension", 128)
-    ks, lks, rks = enc.get("kernel_size", 7), enc.get("last_kernel_size", 7), enc.get("residual_kernel_size", 3)
-    ratios = [tuple(r) for r in enc["ratios"]]
-    nres, compress = enc.get("n_residual_layers", 1), enc.get("compress", 2)
-    ops: List[Tuple[str, str, Tuple[int, ...]]] = []
-    idx, mult = 0, 1
-    ops.append(("conv", f"encoder.model.{idx}.conv", (nf, cfg["input_size"], ks, ks)))
-    idx += 1
-    for fr, tr in reversed(ratios):
-        c = mult * nf
-        for _ in range(nres):
-            ops.append(("conv", f"encoder.model.{idx}.block.1.conv", (c // compress, c, rks, rks)))
-            ops.append(("conv", f"encoder.model.{idx}.block.3.conv", (c, c // compress, 1, 1)))
-            ops.append(("conv", f"encoder.model.{idx}.shortcut.conv", (c, c, 1, 1)))
-            idx += 1
-        idx += 1
-        ops.append(("conv", f"encoder.model.{idx}.conv", (2 * c, c, 2 * fr, 2 * tr)))
-        idx += 1
-        mult *= 2
-    idx += 1                                          # ReshapeModule
-    cb = mult * nf
-    ops.append(("lstm", f"encoder.model.{idx}.lstm", (cb,)))
-    idx += 2
-    ops.append(("conv", f"encoder.model.{idx}.conv", (dim, cb, lks)))
-    idx = 0
-    ops.append(("conv", f"decoder.model.{idx}.conv", (cb, dim, ks)))
-    idx += 1
-    ops.append(("lstm", f"decoder.model.{idx}.lstm", (cb,)))
-    idx += 2                                          # + ReshapeModule
-    for fr, tr in ratios:
-        c = mult * nf
-        idx += 1
-        ops.append(("convtr", f"decoder.model.{idx}.convtr", (c, c // 2, 2 * fr, 2 * tr)))
-        idx += 1
-        for _ in range(nres):
-            c2 = c // 2
-            ops.append(("conv", f"decoder.model.{idx}.block.1.conv", (c2 // compress, c2, rks, rks)))
-            ops.append(("conv", f"decoder.model.{idx}.block.3.conv", (c2, c2 // compress, 1, 1)))
-            ops.append(("conv", f"decoder.model.{idx}.shortcut.conv", (c2, c2, 1, 1)))
-            idx += 1
-        mult //= 2
-    idx += 1
-    ops.append(("conv", f"decoder.model.{idx}.conv", (dec.get("channels", 1), nf, lks, lks)))
-    return ops
-
-
-def make_freq_state_dict(cfg: Dict[str, Any], seed: int = 0) -> Dict[str, np.ndarray]:
-    rng = np.random.Generator(np.random.PCG64(seed))
-    sd: Dict[str, np.ndarray] = {}
-
-    def uni(shape, bound):
-        return rng.uniform(-bound, bound, size=shape).astype(np.float32)
-
-    for kind, key, shape in freq_plan(cfg):
-        if kind == "lstm":
-            h = shape[0]
-            b = 1.0 / np.sqrt(h)
-            for l in range(2):
-                sd[f"{key}.weight_ih_l{l}"] = uni((4 * h, h), b)
-                sd[f"{key}.weight_hh_l{l}"] = uni((4 * h, h), b)
-                sd[f"{key}.bias_ih_l{l}"] = uni((4 * h,), b)
-                sd[f"{key}.bias_hh_l{l}"] = uni((4 * h,), b)
-            continue
-        inner = "conv" if kind == "conv" else "convtr"
-        cout = shape[0] if kind == "conv" else shape[1]
-        fan_in = int(np.prod(shape[1:])) if kind == "conv" else int(shape[1] * np.prod(shape[2:]))
-        b = 1.0 / np.sqrt(fan_in)
-        sd[f"{key}.{inner}.weight"] = uni(shape, b)
-        sd[f"{key}.{inner}.bias"] = uni((cout,), b)
-        sd[f"{key}.norm.weight"] = (1.0 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
-        sd[f"{key}.norm.bias"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
-    q = cfg["quantizer_conf"]
-    nq, K, D = q["num_quantizers"], q["codebook_size"], cfg["encoder_conf"].get("dimension", 128)
-    embed = rng.standard_normal((nq, K, D)).astype(np.float32)
-    pfx = "quantizer.rq.model"
-    sd[f"{pfx}.inited"] = np.ones((nq, 1), np.float32)
-    sd[f"{pfx}.cluster_size"] = np.ones((nq, K), np.float32)
-    sd[f"{pfx}.embed"] = embed
-    sd[f"{pfx}.embed_avg"] = embed.copy()
-    return sd
+"""TEST INFRASTRUCTURE ONLY.  The seeded FreqCodec checkpoints and recipe configs of the FreqCodec golden cases live with the
+product's other synthetic-checkpoint helpers (funcodec_amd/synth.py, funcodec_amd/config.py: bench.py needs them too and may
+not import oracle/); this module keeps the names the oracle-side scripts use."""
+from funcodec_amd.config import freq_recipe_config  # noqa: F401
+from funcodec_amd.synth import freq_plan, make_freq_state_dict  # noqa: F401

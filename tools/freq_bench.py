@@ -16,6 +16,7 @@ m.load_state_dict({k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, 
 m.engine.micro_batch = MB
 T = int(SEC * 16000)
 wav = torch.from_numpy(synthetic_audio(B, T, 1, "tones")).cuda()
+print("workspace GB", m.engine.lib.fc_engine_workspace_bytes(m.engine._h, min(B, MB), T) / 1e9, flush=True)
 for _ in range(2):
     m.engine.encode_decode(wav, arch.num_quantizers)
 torch.cuda.synchronize()
