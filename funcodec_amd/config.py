@@ -57,6 +57,10 @@ class ArchSpec:
     ratios_f: Tuple[int, ...] = ()
     n_fft: int = 512
     stft_hop: int = 160
+    # grouped 2-D convs (seanet_encoder.py:224,234,321; seanet_decoder.py:219,229,324): <= 0 = dense
+    enc_conv_group_ratio: int = -1
+    dec_conv_group_ratio: int = -1
+    dec_tr_conv_group_ratio: int = -1
 
     @property
     def segment_length(self) -> Optional[int]:
@@ -148,7 +152,7 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
             raise _unsupported(f"{which}.norm/causal", (conf.get("norm", "weight_norm"), conf.get("causal", False)), "GroupNorm non-causal only")
         if dict(conf.get("norm_params", {}) or {}).get("num_groups", 1) != 1:
             raise _unsupported(f"{which}.norm_params.num_groups", conf["norm_params"]["num_groups"])
-        for key, ok in (("conv_group_ratio", -1), ("tr_conv_group_ratio", -1), ("true_skip", False), ("pad_mode", "reflect"),
+        for key, ok in (("true_skip", False), ("pad_mode", "reflect"),
                         ("activation", "ELU"), ("seq_model", "lstm"), ("final_activation", None), ("trim_right_ratio", 1.0)):
             if conf.get(key, ok) != ok:
                 raise _unsupported(f"{which}.{key}", conf[key])
@@ -193,7 +197,14 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
         use_ddp=bool(q.get("use_ddp", True)), norm="time_group_norm", causal=False, segment_dur=None,
         model_type="freq_codec", n_fft=int(dc.get("n_fft", 512)), stft_hop=int(dc.get("hop_length", 160)),
+        enc_conv_group_ratio=int(enc.get("conv_group_ratio", -1)), dec_conv_group_ratio=int(dec.get("conv_group_ratio", -1)),
+        dec_tr_conv_group_ratio=int(dec.get("tr_conv_group_ratio", -1)),
     )
+    from .plan import encoder_plan_2d, decoder_plan_2d
+    for op in encoder_plan_2d(arch) + decoder_plan_2d(arch):      # torch.nn.Conv2d's own constraints on `groups`
+        if op.groups < 1 or op.cin % op.groups or op.cout % op.groups:
+            raise _unsupported("conv_group_ratio", (arch.enc_conv_group_ratio, arch.dec_conv_group_ratio, arch.dec_tr_conv_group_ratio),
+                               f"{op.key}: {op.groups} groups do not divide {op.cin} -> {op.cout} channels")
     f = arch.n_fft // 2 + 1
     for fr in reversed(arch.ratios_f):
         f = (f + fr - 2 * fr) // fr + 1          # SConv2d, kernel 2 fr, stride fr: padding_total = fr, no extra padding in frequency
@@ -294,6 +305,10 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     """`freqmp`: egs/LibriTTS/codec/conf/freqcodec_mag_phase_16k_n32_600k_step.yaml:1-59 (16.2 M parameters);
     `freqmp640`: ..._ds640.yaml (time ratios 2,1,2,1, 640 samples per frame);
     `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
+    gr = -1
+    if "gr" in name:                                  # e.g. "freqmpgr1", "tinyfreqgr2": conv_group_ratio = tr_conv_group_ratio = N
+        name, grs = name.split("gr")
+        gr = int(grs)
     tiny = name.startswith("tinyfreq")
     if name not in ("freqmp", "tinyfreq", "freqmp640", "tinyfreq640"):
         raise KeyError(name)
@@ -304,6 +319,12 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     if tiny:
         enc.update(n_filters=4, dimension=16)
         dec.update(n_filters=4)
+    if gr > 0:
+        if tiny:                                      # 8 base filters: every grouped layer keeps >= 2 groups
+            enc.update(n_filters=8)
+            dec.update(n_filters=8)
+        enc.update(conv_group_ratio=gr)
+        dec.update(conv_group_ratio=gr, tr_conv_group_ratio=gr)
     return {
         "input_size": 3, "sampling_rate": 16000,
         "encoder": "encodec_seanet_encoder_2d", "encoder_conf": enc,

@@ -53,6 +53,7 @@ struct ConvLayer {
     bool valid = false;         // no padding at all (the STFT GEMM)
     int zpadL = -1, zpadR = -1; // explicit ZERO padding (the inverse-STFT GEMM); -1: reference padding rules
     bool synthetic = false;     // weights generated at finalize (DFT matrices), not part of the checkpoint
+    int groups = 1;             // grouped Conv2d / ConvTranspose2d (conv_group_ratio > 0): dense block-diagonal weight at finalize
     // GEMM view
     int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
     int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
@@ -227,14 +228,17 @@ void choose_tiling(ConvLayer& L);
 
 // ---- STFT-domain codec: SEANetEncoder2d / SEANetDecoder2d (seanet_encoder.py:252-363, seanet_decoder.py:244-360) ---------------
 // Same Sequential indexing as the reference; every Conv2d is planned as a 1-D GEMM over kf * C channels (frequency-major layout).
-ConvLayer mk_conv2d(const std::string& prefix, int cin, int cout, int kf, int kt, int sf, int st, bool dual) {
+// `groups` > 1 (conv_group_ratio > 0): the layer still runs as the dense GEMM over a block-diagonal weight built at finalize (the
+// zero products add exactly nothing: same result as the grouped conv accumulated in the same order)
+ConvLayer mk_conv2d(const std::string& prefix, int cin, int cout, int kf, int kt, int sf, int st, bool dual, int groups = 1) {
     ConvLayer L = mk_conv(prefix, kf * cin, cout, kt, st, false, dual, false, 1);
-    L.kf = kf; L.sf = sf; L.c2d = cin; L.extra_left = true;
+    L.kf = kf; L.sf = sf; L.c2d = cin; L.extra_left = true; L.groups = groups;
     return L;
 }
+inline int group_count(int n, int ratio) { return ratio > 0 ? n / 2 / ratio : 1; }
 
 void add_conv2d_expect(fc_engine* e, ConvLayer& L) {
-    e->expected.push_back({L.prefix + ".conv.weight", {L.cout, L.c2d, L.kf, L.k}});
+    e->expected.push_back({L.prefix + ".conv.weight", {L.cout, L.c2d / (L.groups > 0 ? L.groups : 1), L.kf, L.k}});   // groups < 1 is refused at create
     e->expected.push_back({L.prefix + ".conv.bias", {L.cout}});
     e->expected.push_back({L.prefix + ".norm.weight", {L.cout}});
     e->expected.push_back({L.prefix + ".norm.bias", {L.cout}});
@@ -247,10 +251,11 @@ void build_plan_2d(fc_engine* e) {
     auto name = [](const char* side, int idx, const char* suffix) { return std::string(side) + ".model." + std::to_string(idx) + suffix; };
     auto add_res = [&](fc_engine::ResBlock& R, const char* side, int idx, int c, int j, int dil) {
         const int hid = c / a.compress, rk = a.residual_kernel_size;
-        R.shortcut = mk_conv2d(name(side, idx, ".shortcut.conv"), c, c, 1, 1, 1, 1, j > 0);
-        R.block1 = mk_conv2d(name(side, idx, ".block.1.conv"), c, hid, rk, rk, 1, 1, j > 0);
+        const int gr = side[0] == 'e' ? a.enc_conv_group_ratio : a.dec_conv_group_ratio;
+        R.shortcut = mk_conv2d(name(side, idx, ".shortcut.conv"), c, c, 1, 1, 1, 1, j > 0, group_count(c, gr));
+        R.block1 = mk_conv2d(name(side, idx, ".block.1.conv"), c, hid, rk, rk, 1, 1, j > 0, group_count(hid, gr));
         R.block1.dil = dil;                                   // dilation (1, dilation_base ** j): time axis only
-        R.block3 = mk_conv2d(name(side, idx, ".block.3.conv"), hid, c, 1, 1, 1, 1, false);
+        R.block3 = mk_conv2d(name(side, idx, ".block.3.conv"), hid, c, 1, 1, 1, 1, false, group_count(hid, gr));
     };
     // ---- encoder
     int idx = 0, mult = 1;
@@ -264,7 +269,7 @@ void build_plan_2d(fc_engine* e) {
         S.res.resize(nres);
         for (int j = 0, dil = 1; j < nres; ++j, dil *= a.dilation_base) { add_res(S.res[j], "encoder", idx, c, j, dil); idx++; }
         idx++;                                                                    // ELU
-        S.resample = mk_conv2d(name("encoder", idx, ".conv"), c, 2 * c, 2 * fr, 2 * tr, fr, tr, true);
+        S.resample = mk_conv2d(name("encoder", idx, ".conv"), c, 2 * c, 2 * fr, 2 * tr, fr, tr, true, group_count(c, a.enc_conv_group_ratio));
         idx++;
         mult *= 2;
     }
@@ -293,7 +298,7 @@ void build_plan_2d(fc_engine* e) {
         S.resample.prefix = name("decoder", idx, ".convtr");
         S.resample.transposed = true;
         S.resample.cin = c; S.resample.cout = c2; S.resample.c2d = c; S.resample.kf = 2 * fr; S.resample.sf = fr;
-        S.resample.k = 2 * tr; S.resample.stride = tr;
+        S.resample.k = 2 * tr; S.resample.stride = tr; S.resample.groups = group_count(c, a.dec_tr_conv_group_ratio);
         for (int p = 0; p < fr; ++p)
             e->dec_up_phases[s].push_back(mk_conv(S.resample.prefix + ".phase" + std::to_string(p), 2 * c, c2, 2 * tr, tr, true, false, false));
         idx++;
@@ -334,7 +339,7 @@ void build_plan_2d(fc_engine* e) {
     add_conv_expect(e, e->dec_first);
     add_lstm(e->dec_lstm);
     for (auto& S : e->dec_stages) {
-        e->expected.push_back({S.resample.prefix + ".convtr.weight", {S.resample.c2d, S.resample.cout, S.resample.kf, S.resample.k}});
+        e->expected.push_back({S.resample.prefix + ".convtr.weight", {S.resample.c2d, S.resample.cout / (S.resample.groups > 0 ? S.resample.groups : 1), S.resample.kf, S.resample.k}});
         e->expected.push_back({S.resample.prefix + ".convtr.bias", {S.resample.cout}});
         e->expected.push_back({S.resample.prefix + ".norm.weight", {S.resample.cout}});
         e->expected.push_back({S.resample.prefix + ".norm.bias", {S.resample.cout}});
@@ -644,12 +649,15 @@ int pack_conv2d(fc_engine* e, ConvLayer& L) {
     const auto& W = e->host[L.prefix + ".conv.weight"].data;
     const auto& Bv = e->host[L.prefix + ".conv.bias"].data;
     const int C = L.c2d, kf = L.kf, kt = L.k;
-    std::vector<float> wg((size_t)L.cout * kf * C * kt);
+    const int cpg = C / L.groups, opg = L.cout / L.groups;        // grouped: weight [cout][C / groups][kf][kt], block-diagonal when dense
+    std::vector<float> wg((size_t)L.cout * kf * C * kt, 0.f);
     for (int m = 0; m < L.cout; ++m)
-        for (int ci = 0; ci < C; ++ci)
+        for (int cl = 0; cl < cpg; ++cl) {
+            const int ci = (m / opg) * cpg + cl;
             for (int a = 0; a < kf; ++a)
                 for (int b = 0; b < kt; ++b)
-                    wg[((size_t)m * (kf * C) + (size_t)a * C + ci) * kt + b] = W[(((size_t)m * C + ci) * kf + a) * kt + b];
+                    wg[((size_t)m * (kf * C) + (size_t)a * C + ci) * kt + b] = W[(((size_t)m * cpg + cl) * kf + a) * kt + b];
+        }
     if (pack_gemm(e, L, wg, Bv)) return 1;
     if (L.cout <= 4 && L.stride == 1 && L.sf == 1 && upload(e, wg, &L.w_plain)) return 1;      // [cout][kf * C][kt]: FMA kernel, no MFMA tile
     if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
@@ -665,17 +673,18 @@ int pack_convtr2d(fc_engine* e, const ConvLayer& S, std::vector<ConvLayer>& phas
     const auto& W = e->host[S.prefix + ".convtr.weight"].data;
     const auto& Bv = e->host[S.prefix + ".convtr.bias"].data;
     const int C = S.c2d, cout = S.cout, kf = S.kf, kt = S.k, sf = S.sf, r = S.stride;
+    const int cpg = C / S.groups, opg = cout / S.groups;          // grouped: weight [C][cout / groups][kf][kt]
     for (int p = 0; p < sf; ++p) {
         ConvLayer& L = phases[p];
-        std::vector<float> wg((size_t)L.M * L.cin * 2), bg(L.M);
+        std::vector<float> wg((size_t)L.M * L.cin * 2, 0.f), bg(L.M);
         for (int co = 0; co < cout; ++co)
             for (int ph = 0; ph < r; ++ph) {
                 const int m = co * r + ph;
                 bg[m] = Bv[co];
                 for (int rr = 0; rr < 2; ++rr)
-                    for (int ci = 0; ci < C; ++ci) {
+                    for (int ci = (co / opg) * cpg; ci < (co / opg + 1) * cpg; ++ci) {
                         const int a = p + (1 - rr) * sf;
-                        const float* w = &W[(((size_t)ci * cout + co) * kf + a) * kt];
+                        const float* w = &W[(((size_t)ci * opg + co % opg) * kf + a) * kt];
                         const size_t c1 = (size_t)rr * C + ci;
                         wg[((size_t)m * L.cin + c1) * 2 + 0] = w[ph + r];      // tap 0 multiplies x[i-1]
                         wg[((size_t)m * L.cin + c1) * 2 + 1] = w[ph];          // tap 1 multiplies x[i]
@@ -1419,6 +1428,21 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     e->arch = *arch;
     e->device = device;
     build_plan(e);
+    if (arch->model_type == 1) {          // torch.nn.Conv2d / ConvTranspose2d constraints on `groups` (conv_group_ratio > 0)
+        std::vector<const ConvLayer*> ls;
+        for (auto* st : {&e->enc_stages, &e->dec_stages})
+            for (auto& S : *st) {
+                for (auto& R : S.res) { ls.push_back(&R.shortcut); ls.push_back(&R.block1); ls.push_back(&R.block3); }
+                ls.push_back(&S.resample);
+            }
+        for (const ConvLayer* L : ls)
+            if (L->groups < 1 || L->c2d % L->groups || L->cout % L->groups) {
+                const std::string msg = "freq_codec: conv_group_ratio gives " + std::to_string(L->groups) + " groups for " + L->prefix + " (" +
+                                        std::to_string(L->c2d) + " -> " + std::to_string(L->cout) + " channels)";
+                delete e;
+                return fail(msg);
+            }
+    }
     *out = e;
     return 0;
 }

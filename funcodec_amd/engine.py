@@ -84,6 +84,8 @@ class CodecEngine:
         a.stft_hop = arch.stft_hop
         for i, r in enumerate(arch.ratios_f):
             a.ratios_f[i] = int(r)
+        a.enc_conv_group_ratio, a.dec_conv_group_ratio = arch.enc_conv_group_ratio, arch.dec_conv_group_ratio
+        a.dec_tr_conv_group_ratio = arch.dec_tr_conv_group_ratio
         h = C.c_void_p()
         self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
         self._h = h

@@ -26,6 +26,7 @@ class ConvOp:
     dilation: int = 1
     kf: int = 0          # 2-D layers (freq_codec): kernel / stride along frequency; 0 = a 1-D layer
     sf: int = 1
+    groups: int = 1      # grouped 2-D convs (conv_group_ratio > 0)
 
 
 def encoder_plan(a: ArchSpec) -> List[ConvOp]:
@@ -90,6 +91,8 @@ def encoder_plan_2d(a: ArchSpec) -> List[ConvOp]:
     1-D LSTM and last conv.  `k` / `stride` hold the TIME extent, `kf` / `sf` the frequency extent."""
     ops: List[ConvOp] = []
     idx, mult = 0, 1
+    gr = a.enc_conv_group_ratio
+    grp = lambda n: n // 2 // gr if gr > 0 else 1
     ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", a.input_channels, a.n_filters, a.kernel_size, 1, "first", kf=a.kernel_size))
     idx += 1
     for fr, tr in zip(reversed(a.ratios_f), reversed(a.ratios)):
@@ -97,12 +100,13 @@ def encoder_plan_2d(a: ArchSpec) -> List[ConvOp]:
         hid = c // a.compress
         for j in range(a.n_residual_layers):
             p = f"encoder.model.{idx}"
-            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c, c, 1, 1, "shortcut", kf=1))
-            ops.append(ConvOp("conv", f"{p}.block.1.conv", c, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j, kf=a.residual_kernel_size))
-            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c, 1, 1, "block3", kf=1))
+            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c, c, 1, 1, "shortcut", kf=1, groups=grp(c)))
+            ops.append(ConvOp("conv", f"{p}.block.1.conv", c, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j,
+                              kf=a.residual_kernel_size, groups=grp(hid)))
+            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c, 1, 1, "block3", kf=1, groups=grp(hid)))
             idx += 1
         idx += 1          # ELU
-        ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", c, 2 * c, 2 * tr, tr, "down", kf=2 * fr, sf=fr))
+        ops.append(ConvOp("conv", f"encoder.model.{idx}.conv", c, 2 * c, 2 * tr, tr, "down", kf=2 * fr, sf=fr, groups=grp(c)))
         idx += 1
         mult *= 2
     idx += 1              # ReshapeModule
@@ -119,6 +123,8 @@ def decoder_plan_2d(a: ArchSpec) -> List[ConvOp]:
     """SEANetDecoder2d (seanet_decoder.py:244-360)."""
     ops: List[ConvOp] = []
     idx, mult = 0, 2 ** len(a.ratios)
+    gr, trgr = a.dec_conv_group_ratio, a.dec_tr_conv_group_ratio
+    grp = lambda n: n // 2 // gr if gr > 0 else 1
     c = mult * a.n_filters
     ops.append(ConvOp("conv", f"decoder.model.{idx}.conv", a.dimension, c, a.kernel_size, 1, "first"))
     idx += 1
@@ -129,15 +135,17 @@ def decoder_plan_2d(a: ArchSpec) -> List[ConvOp]:
     for fr, tr in zip(a.ratios_f, a.ratios):
         c = mult * a.n_filters
         idx += 1          # ELU
-        ops.append(ConvOp("convtr", f"decoder.model.{idx}.convtr", c, c // 2, 2 * tr, tr, "up", kf=2 * fr, sf=fr))
+        ops.append(ConvOp("convtr", f"decoder.model.{idx}.convtr", c, c // 2, 2 * tr, tr, "up", kf=2 * fr, sf=fr,
+                          groups=c // 2 // trgr if trgr > 0 else 1))
         idx += 1
         c2 = c // 2
         hid = c2 // a.compress
         for j in range(a.n_residual_layers):
             p = f"decoder.model.{idx}"
-            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c2, c2, 1, 1, "shortcut", kf=1))
-            ops.append(ConvOp("conv", f"{p}.block.1.conv", c2, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j, kf=a.residual_kernel_size))
-            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c2, 1, 1, "block3", kf=1))
+            ops.append(ConvOp("conv", f"{p}.shortcut.conv", c2, c2, 1, 1, "shortcut", kf=1, groups=grp(c2)))
+            ops.append(ConvOp("conv", f"{p}.block.1.conv", c2, hid, a.residual_kernel_size, 1, "block1", a.dilation_base ** j,
+                              kf=a.residual_kernel_size, groups=grp(hid)))
+            ops.append(ConvOp("conv", f"{p}.block.3.conv", hid, c2, 1, 1, "block3", kf=1, groups=grp(hid)))
             idx += 1
         mult //= 2
     idx += 1              # ELU
@@ -155,7 +163,8 @@ def expected_tensors(a: ArchSpec) -> Dict[str, Tuple[int, ...]]:
         if op.kind in ("conv", "convtr"):
             inner = op.kind
             kk = (op.kf, op.k) if op.kf else (op.k,)          # Conv2d weights are [out, in, k_frequency, k_time]
-            wshape = (op.cout, op.cin) + kk if op.kind == "conv" else (op.cin, op.cout) + kk
+            # torch layouts: Conv [out, in / groups, ...], ConvTranspose [in, out / groups, ...]
+            wshape = (op.cout, op.cin // op.groups) + kk if op.kind == "conv" else (op.cin, op.cout // op.groups) + kk
             if wn:
                 out[f"{op.key}.{inner}.weight_g"] = (wshape[0], 1, 1)
                 out[f"{op.key}.{inner}.weight_v"] = wshape

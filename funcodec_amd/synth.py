@@ -105,6 +105,8 @@ def freq_plan(cfg: Dict[str, Any]) -> list:
     ks, lks, rks = enc.get("kernel_size", 7), enc.get("last_kernel_size", 7), enc.get("residual_kernel_size", 3)
     ratios = [tuple(r) for r in enc["ratios"]]
     nres, compress = enc.get("n_residual_layers", 1), enc.get("compress", 2)
+    egr, dgr, trgr = enc.get("conv_group_ratio", -1), dec.get("conv_group_ratio", -1), dec.get("tr_conv_group_ratio", -1)
+    grp = lambda n, r: n // 2 // r if r > 0 else 1          # groups of a grouped 2-D conv (seanet_encoder.py:224,234,321)
     ops: list = []
     idx, mult = 0, 1
     ops.append(("conv", f"encoder.model.{idx}.conv", (nf, cfg["input_size"], ks, ks)))
@@ -112,12 +114,13 @@ def freq_plan(cfg: Dict[str, Any]) -> list:
     for fr, tr in reversed(ratios):
         c = mult * nf
         for _ in range(nres):
-            ops.append(("conv", f"encoder.model.{idx}.block.1.conv", (c // compress, c, rks, rks)))
-            ops.append(("conv", f"encoder.model.{idx}.block.3.conv", (c, c // compress, 1, 1)))
-            ops.append(("conv", f"encoder.model.{idx}.shortcut.conv", (c, c, 1, 1)))
+            h = c // compress
+            ops.append(("conv", f"encoder.model.{idx}.block.1.conv", (h, c // grp(h, egr), rks, rks)))
+            ops.append(("conv", f"encoder.model.{idx}.block.3.conv", (c, h // grp(h, egr), 1, 1)))
+            ops.append(("conv", f"encoder.model.{idx}.shortcut.conv", (c, c // grp(c, egr), 1, 1)))
             idx += 1
         idx += 1
-        ops.append(("conv", f"encoder.model.{idx}.conv", (2 * c, c, 2 * fr, 2 * tr)))
+        ops.append(("conv", f"encoder.model.{idx}.conv", (2 * c, c // grp(c, egr), 2 * fr, 2 * tr)))
         idx += 1
         mult *= 2
     idx += 1                                          # ReshapeModule
@@ -133,13 +136,14 @@ def freq_plan(cfg: Dict[str, Any]) -> list:
     for fr, tr in ratios:
         c = mult * nf
         idx += 1
-        ops.append(("convtr", f"decoder.model.{idx}.convtr", (c, c // 2, 2 * fr, 2 * tr)))
+        ops.append(("convtr", f"decoder.model.{idx}.convtr", (c, c // 2 // grp(c, trgr), 2 * fr, 2 * tr)))
         idx += 1
         for _ in range(nres):
             c2 = c // 2
-            ops.append(("conv", f"decoder.model.{idx}.block.1.conv", (c2 // compress, c2, rks, rks)))
-            ops.append(("conv", f"decoder.model.{idx}.block.3.conv", (c2, c2 // compress, 1, 1)))
-            ops.append(("conv", f"decoder.model.{idx}.shortcut.conv", (c2, c2, 1, 1)))
+            h = c2 // compress
+            ops.append(("conv", f"decoder.model.{idx}.block.1.conv", (h, c2 // grp(h, dgr), rks, rks)))
+            ops.append(("conv", f"decoder.model.{idx}.block.3.conv", (c2, h // grp(h, dgr), 1, 1)))
+            ops.append(("conv", f"decoder.model.{idx}.shortcut.conv", (c2, c2 // grp(c2, dgr), 1, 1)))
             idx += 1
         mult //= 2
     idx += 1
@@ -165,7 +169,7 @@ def make_freq_state_dict(cfg: Dict[str, Any], seed: int = 0) -> Dict[str, np.nda
                 sd[f"{key}.bias_hh_l{l}"] = uni((4 * h,), b)
             continue
         inner = "conv" if kind == "conv" else "convtr"
-        cout = shape[0] if kind == "conv" else shape[1]
+        cout = shape[0] if kind == "conv" else shape[0] // 2        # every ConvTranspose2d of the net halves the channels
         fan_in = int(np.prod(shape[1:])) if kind == "conv" else int(shape[1] * np.prod(shape[2:]))
         b = 1.0 / np.sqrt(fan_in)
         sd[f"{key}.{inner}.weight"] = uni(shape, b)

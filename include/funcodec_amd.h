@@ -66,6 +66,11 @@ typedef struct fc_arch {
     int32_t n_fft;                  /* 512  (model_conf.domain_conf.n_fft) */
     int32_t stft_hop;               /* 160  (model_conf.domain_conf.hop_length) */
     int32_t ratios_f[FC_MAX_RATIOS];/* frequency ratios of the 2-D stages, decoder order (ratios[] holds the time ratios) */
+    /* grouped 2-D convs (seanet_encoder.py:224,234,321; seanet_decoder.py:219,229,324): <= 0 = dense (the recipe), else the layer has
+     * groups = min(in, out) / 2 / ratio (res-block convs), channels / 2 / ratio (shortcut, strided / transposed convs) */
+    int32_t enc_conv_group_ratio;   /* encoder_conf.conv_group_ratio */
+    int32_t dec_conv_group_ratio;   /* decoder_conf.conv_group_ratio */
+    int32_t dec_tr_conv_group_ratio;/* decoder_conf.tr_conv_group_ratio */
 } fc_arch;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

@@ -60,7 +60,7 @@ def sconv2d(x, w, b, gamma, beta, stride: Tuple[int, int], eps: float, dilation:
     t_after = tot_t // 2
     t_before = tot_t - t_after + extra_t          # NB: the reference adds the extra padding on the LEFT of the time axis here (:377)
     x = pad2d_reflect(x, (t_before, t_after), (f_before, f_after))
-    y = F.conv2d(x, w, b, stride=stride, dilation=dilation)
+    y = F.conv2d(x, w, b, stride=stride, dilation=dilation, groups=x.shape[1] // w.shape[1])     # conv_group_ratio > 0: grouped
     return y if gamma is None else F.group_norm(y, 1, gamma, beta, eps)
 
 
@@ -68,7 +68,7 @@ def sconvtr2d(x, w, b, gamma, beta, stride: Tuple[int, int], eps: float, out_pad
     """SConvTranspose2d.forward conv.py:408-447 (non-causal): ConvTranspose2d -> GroupNorm on the untrimmed output -> unpad2d,
     the trims reduced by `out_padding` ([(freq_left, freq_right), (time_left, time_right)])."""
     kf, kt = w.shape[-2:]
-    y = F.conv_transpose2d(x, w, b, stride=stride)
+    y = F.conv_transpose2d(x, w, b, stride=stride, groups=b.shape[0] // w.shape[1])             # tr_conv_group_ratio > 0
     if gamma is not None:
         y = F.group_norm(y, 1, gamma, beta, eps)
     pf, pt = kf - stride[0], kt - stride[1]

@@ -89,6 +89,8 @@ FREQ_CASES = [
     # ..._ds640.yaml shape (time ratios 2,1,2,1); 3100 samples = an EVEN number of STFT frames, where the decoder emits fewer
     # samples than the input had and the reference's recon[:, :, :T] comes out shorter than T
     ("tinyfreq640_b2_t3100", "tinyfreq640", 5, "tones", 83, 2, 3100),
+    # conv_group_ratio = tr_conv_group_ratio = 1 (the "gr1" of the released FreqCodec models): grouped Conv2d / ConvTranspose2d
+    ("tinyfreqgr1_b2_t2500", "tinyfreqgr1", 7, "tones", 84, 2, 2500),
 ]
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [

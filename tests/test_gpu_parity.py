@@ -539,6 +539,7 @@ def test_freq_codec_against_reference_golden(name):
     ("tinyfreq", 11, 1, 400, "noise", 2000, False),        # 3 STFT frames, 2 code frames; reduced bit width; no rescale
     ("tinyfreq640", 12, 2, 5000, "noise", None, True),     # time ratios 2,1,2,1
     ("freqmp", 2, 2, 8000, "tones", 4000, True),           # the recipe shape
+    ("freqmpgr8", 6, 1, 6000, "noise", None, True),        # grouped Conv2d / ConvTranspose2d (conv_group_ratio 8)
 ])
 def test_freq_codec_against_oracle_fresh_inputs(cfg_name, seed, B, T, kind, bw, use_scale):
     from helpers import freq_engine_for, freq_oracle_for

@@ -61,6 +61,26 @@ def test_freq_codec_checkpoint_contract_matches_reference_keys():
     assert {k for k in ref if k not in want} == {"quantizer.rq.model.inited", "quantizer.rq.model.cluster_size", "quantizer.rq.model.embed_avg"}
 
 
+@pytest.mark.parametrize("name", ["tinyfreqgr1", "freqmpgr8", "freqmp640gr1"])
+def test_freq_codec_grouped_conv_contract(name):
+    """conv_group_ratio / tr_conv_group_ratio > 0 (the "gr" of the released FreqCodec models): the engine, the host plan and the
+    seeded checkpoint (which the real reference loaded for the golden) agree on the grouped weight shapes."""
+    from funcodec_amd.synth import make_freq_state_dict
+    cfg = recipe_config(name)
+    arch = arch_from_config(cfg)
+    want = expected_tensors(arch)
+    assert CodecEngine(arch).expected_tensors() == want
+    sd = make_freq_state_dict(cfg, 0)
+    for k, shape in want.items():
+        assert sd[k].shape == shape, (k, sd[k].shape, shape)
+    if name == "freqmpgr8":                       # groups = channels / 2 / 8
+        assert want["encoder.model.3.conv.conv.weight"] == (64, 16, 8, 2) and want["decoder.model.4.convtr.convtr.weight"] == (512, 8, 8, 2)
+    bad = recipe_config("tinyfreq")
+    bad["encoder_conf"]["conv_group_ratio"] = 8                # 4 // 2 // 8 = 0 groups
+    with pytest.raises(NotImplementedError):
+        arch_from_config(bad)
+
+
 def test_arch_from_recipe_configs():
     a = arch_from_config(recipe_config("ds640"))
     assert a.ratios == (8, 5, 4, 2, 2) and a.hop_length == 640 and a.bottleneck_channels == 1024
