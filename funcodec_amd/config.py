@@ -156,12 +156,18 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
                         ("activation", "ELU"), ("seq_model", "lstm"), ("final_activation", None), ("trim_right_ratio", 1.0)):
             if conf.get(key, ok) != ok:
                 raise _unsupported(f"{which}.{key}", conf[key])
-    if list(m.get("codec_domain", ["time", "time"])) != ["mag_phase", "mag_phase"]:
+    domain = list(m.get("codec_domain", ["time", "time"]))
+    if domain != ["mag_phase", "mag_phase"]:
+        # mag_angle was built and measured in round 2, then removed: torch.angle of the first STFT frame (reflect padding makes it
+        # exactly symmetric: every bin's imaginary part is rounding noise) and of the DC / Nyquist rows flips between 0 / +pi / -pi
+        # with the FFT implementation, so no golden of the reference can be reproduced by ANY other float implementation
         raise _unsupported("model_conf.codec_domain", m.get("codec_domain"), "only [mag_phase, mag_phase] is built")
+    n_in = 3
     if m.get("bypass_quantizer", False):
         raise _unsupported("model_conf.bypass_quantizer", True)
-    if cfg.get("input_size", 1) != 3 or dec.get("channels", 1) != 3:
-        raise _unsupported("input_size/channels", (cfg.get("input_size", 1), dec.get("channels", 1)), "3 = log-magnitude, phase re, phase im")
+    if cfg.get("input_size", 1) != n_in or dec.get("channels", 1) != n_in:
+        raise _unsupported("input_size/channels", (cfg.get("input_size", 1), dec.get("channels", 1)),
+                           "mag_phase: 3 (log-magnitude, phase re, phase im); mag_angle: 2 (log-magnitude, angle)")
 
     def shared(key, default):
         a, b = enc.get(key, default), dec.get(key, default)
@@ -178,13 +184,12 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     if int(shared("n_residual_layers", 1)) != 1 and int(shared("dilation_base", 2)) != 1:
         raise _unsupported("n_residual_layers/dilation_base", (enc.get("n_residual_layers"), enc.get("dilation_base")))
     dc = dict(m.get("domain_conf", {}) or {})
-    seg = m["segment_dur"] if "segment_dur" in m else 1.0
-    if seg is not None:
-        raise _unsupported("model_conf.segment_dur", seg, "segmented mode is not built for freq_codec")
+    seg = m["segment_dur"] if "segment_dur" in m else 1.0                     # FreqCodec.__init__ defaults (codec_freq.py:142-143)
+    ov = m["overlap_ratio"] if "overlap_ratio" in m else 0.01
     act_params = dict(shared("activation_params", {"alpha": 1.0}) or {})
     norm_params = dict(shared("norm_params", {}) or {})
     arch = ArchSpec(
-        sample_rate=int(m.get("target_sample_hz", 24000)), input_channels=3,
+        sample_rate=int(m.get("target_sample_hz", 24000)), input_channels=n_in,
         audio_normalize=bool(m.get("audio_normalize", False)),            # FreqCodec.__init__ default is False (codec_freq.py:141)
         n_filters=int(shared("n_filters", 32)), dimension=dimension,
         ratios=tuple(int(r[1]) for r in ratios2), ratios_f=tuple(int(r[0]) for r in ratios2),
@@ -195,11 +200,16 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         elu_alpha=float(act_params.get("alpha", 1.0)), gn_eps=float(norm_params.get("eps", 1e-5)),
         codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=dimension, num_quantizers=int(q.get("num_quantizers", 8)),
         encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
-        use_ddp=bool(q.get("use_ddp", True)), norm="time_group_norm", causal=False, segment_dur=None,
+        use_ddp=bool(q.get("use_ddp", True)), norm="time_group_norm", causal=False,
+        segment_dur=None if seg is None else float(seg), overlap_ratio=0.01 if ov is None else float(ov),
         model_type="freq_codec", n_fft=int(dc.get("n_fft", 512)), stft_hop=int(dc.get("hop_length", 160)),
         enc_conv_group_ratio=int(enc.get("conv_group_ratio", -1)), dec_conv_group_ratio=int(dec.get("conv_group_ratio", -1)),
         dec_tr_conv_group_ratio=int(dec.get("tr_conv_group_ratio", -1)),
     )
+    if arch.segment_dur is not None and not (arch.segment_dur > 0 and 0 <= arch.overlap_ratio < 1):
+        raise _unsupported("model_conf.segment_dur/overlap_ratio", (arch.segment_dur, arch.overlap_ratio))
+    if arch.segment_length is not None and arch.segment_length <= arch.n_fft // 2:
+        raise _unsupported("model_conf.segment_dur", arch.segment_dur, "segments must be longer than n_fft / 2 samples (torch.stft reflect padding)")
     from .plan import encoder_plan_2d, decoder_plan_2d
     for op in encoder_plan_2d(arch) + decoder_plan_2d(arch):      # torch.nn.Conv2d's own constraints on `groups`
         if op.groups < 1 or op.cin % op.groups or op.cout % op.groups:
@@ -305,6 +315,10 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     """`freqmp`: egs/LibriTTS/codec/conf/freqcodec_mag_phase_16k_n32_600k_step.yaml:1-59 (16.2 M parameters);
     `freqmp640`: ..._ds640.yaml (time ratios 2,1,2,1, 640 samples per frame);
     `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
+    seg = name.endswith("seg")                        # FreqCodec._encode / _decode in segmented mode: 0.15 s frames, 10 % overlap
+    name = name[:-3] if seg else name
+    angle = name.endswith("ang")                      # freqcodec_mag_angle_16k_n32_600k_step.yaml (refused by arch_from_config)
+    name = name[:-3] if angle else name
     gr = -1
     if "gr" in name:                                  # e.g. "freqmpgr1", "tinyfreqgr2": conv_group_ratio = tr_conv_group_ratio = N
         name, grs = name.split("gr")
@@ -315,7 +329,7 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     ds640 = name.endswith("640")
     ratios = [[4, 2], [4, 1], [4, 2], [4, 1]] if ds640 else [[4, 1], [4, 1], [4, 2], [4, 1]]
     enc = {"ratios": ratios, "norm": "time_group_norm", "norm_params": {"num_groups": 1}, "causal": False, "dilation_base": 1}
-    dec = dict(enc, channels=3)
+    dec = dict(enc, channels=2 if angle else 3)
     if tiny:
         enc.update(n_filters=4, dimension=16)
         dec.update(n_filters=4)
@@ -326,7 +340,7 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
         enc.update(conv_group_ratio=gr)
         dec.update(conv_group_ratio=gr, tr_conv_group_ratio=gr)
     return {
-        "input_size": 3, "sampling_rate": 16000,
+        "input_size": 2 if angle else 3, "sampling_rate": 16000,
         "encoder": "encodec_seanet_encoder_2d", "encoder_conf": enc,
         "quantizer": "costume_quantizer",
         "quantizer_conf": {"codebook_size": 64 if tiny else 1024, "num_quantizers": 4 if tiny else 32, "ema_decay": 0.99,
@@ -336,8 +350,8 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
         "discriminator": "multiple_disc", "discriminator_conf": {"disc_conf_list": []},
         "model": "freq_codec",
         "model_conf": {"odim": 16 if tiny else 128, "multi_spectral_window_powers_of_two": [], "target_sample_hz": 16000,
-                       "audio_normalize": True, "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None,
-                       "codec_domain": ["mag_phase", "mag_phase"]},
+                       "audio_normalize": True, "use_power_spec_loss": True, "segment_dur": 0.15 if seg else None,
+                       "overlap_ratio": 0.1 if seg else None, "codec_domain": ["mag_angle", "mag_angle"] if angle else ["mag_phase", "mag_phase"]},
     }
 
 

@@ -706,6 +706,9 @@ int pack_dft(fc_engine* e) {
     const int N = e->arch.n_fft, hop = e->arch.stft_hop, F = N / 2 + 1, taps = ceil_div_i(N, hop);
     std::vector<double> win(N);
     for (int n = 0; n < N; ++n) win[n] = 0.5 - 0.5 * cos(2.0 * M_PI * n / N);          // torch.hann_window(N) (periodic)
+    // twiddles with EXACT zeros at the quarter periods: the DC and Nyquist rows then have an exactly zero imaginary part, like an FFT's
+    auto tw_cos = [&](long long k) { k %= N; return (k % (N / 2)) == N / 4 ? 0.0 : cos(2.0 * M_PI * (double)k / N); };
+    auto tw_sin = [&](long long k) { k %= N; return (k % (N / 2)) == 0 ? 0.0 : sin(2.0 * M_PI * (double)k / N); };
     {
         ConvLayer& L = e->stft;
         std::vector<float> wg((size_t)2 * F * hop * taps, 0.f), bg(2 * F, 0.f);
@@ -714,9 +717,9 @@ int pack_dft(fc_engine* e) {
                 for (int a = 0; a < taps; ++a) {
                     const int n = a * hop + j;
                     if (n >= N) continue;
-                    const double ang = 2.0 * M_PI * (double)(((long long)f * n) % N) / N;
-                    wg[((size_t)f * hop + j) * taps + a] = (float)(win[n] * cos(ang));
-                    wg[((size_t)(F + f) * hop + j) * taps + a] = (float)(-win[n] * sin(ang));
+                    const long long k = (long long)f * n;
+                    wg[((size_t)f * hop + j) * taps + a] = (float)(win[n] * tw_cos(k));
+                    wg[((size_t)(F + f) * hop + j) * taps + a] = tw_sin(k) == 0.0 ? 0.f : (float)(-win[n] * tw_sin(k));
                 }
         if (pack_gemm(e, L, wg, bg)) return 1;
     }
@@ -729,10 +732,10 @@ int pack_dft(fc_engine* e) {
                     const int n = a * hop + j;
                     if (n >= N) continue;
                     const double cf = (f == 0 || f == N / 2) ? 1.0 : 2.0;
-                    const double ang = 2.0 * M_PI * (double)(((long long)f * n) % N) / N;
+                    const long long k = (long long)f * n;
                     const int ap = taps - 1 - a;
-                    wg[((size_t)j * 2 * F + f) * taps + ap] = (float)(win[n] * cf * cos(ang) / N);
-                    wg[((size_t)j * 2 * F + F + f) * taps + ap] = (float)(-win[n] * cf * sin(ang) / N);
+                    wg[((size_t)j * 2 * F + f) * taps + ap] = (float)(win[n] * cf * tw_cos(k) / N);
+                    wg[((size_t)j * 2 * F + F + f) * taps + ap] = tw_sin(k) == 0.0 ? 0.f : (float)(-win[n] * cf * tw_sin(k) / N);
                 }
         if (pack_gemm(e, L, wg, bg)) return 1;
     }

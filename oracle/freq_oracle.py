@@ -187,6 +187,22 @@ class FreqOracle(Oracle):
         """FreqCodec.inference codec_freq.py (one frame: segment_dur null)."""
         if speech.dim() == 2:
             speech = speech.unsqueeze(1)
+        m = self.cfg.get("model_conf", {})
+        if (m["segment_dur"] if "segment_dur" in m else 1.0) is not None:      # FreqCodec._encode / _decode codec_freq.py:303-328,390-404
+            seg = int(m.get("segment_dur", 1.0) * int(m.get("target_sample_hz", 24000)))
+            ov = 0.01 if m.get("overlap_ratio", 0.01) is None else m.get("overlap_ratio", 0.01)
+            stride = max(1, int((1 - ov) * seg))
+            T = speech.shape[-1]
+            idxs, embs, subs_all, recons, encs, scales = [], [], [], [], [], []
+            for off in range(0, T, stride):
+                emb, scale, _ = self.encode_frame(speech[:, :, off:off + seg])
+                quant, idx, subs = self.rvq_forward(emb, self.n_q_for(bit_width))
+                idxs.append(idx); embs.append((quant, scale if use_scale else None)); subs_all.append(subs)
+                encs.append(emb); scales.append(scale)
+                if need_recon:
+                    recons.append(self.decode_frame(quant, scale if use_scale else None)[0])
+            recon = self.linear_overlap_add(recons, stride)[:, :, :T] if need_recon else None
+            return dict(code_indices=idxs, code_embeddings=embs, recon_speech=recon, sub_quants=subs_all, encoder_out=encs, scale=scales)
         emb, scale, feats = self.encode_frame(speech)
         quant, idx, subs = self.rvq_forward(emb, self.n_q_for(bit_width))
         recon, dec_out = None, None

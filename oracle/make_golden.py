@@ -91,6 +91,8 @@ FREQ_CASES = [
     ("tinyfreq640_b2_t3100", "tinyfreq640", 5, "tones", 83, 2, 3100),
     # conv_group_ratio = tr_conv_group_ratio = 1 (the "gr1" of the released FreqCodec models): grouped Conv2d / ConvTranspose2d
     ("tinyfreqgr1_b2_t2500", "tinyfreqgr1", 7, "tones", 84, 2, 2500),
+    # segmented mode (FreqCodec._encode / _decode with model_conf.segment_dur: 2400-sample frames, stride 2160, triangle overlap-add)
+    ("tinyfreqseg_b2_t6000", "tinyfreqseg", 8, "tones", 85, 2, 6000),
 ]
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [
@@ -263,10 +265,24 @@ def main():
                     assert k in sd, f"reference key {k} missing from the synthetic checkpoint"
             x = torch.from_numpy(synthetic_audio(B, T, aseed, akind))
             idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=None, use_scale=True, run_mod="inference")
-            with torch.no_grad():
-                emb_ref, scale_ref = s2t.model._encode_frame(x.unsqueeze(1))
             orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
             o = orc.inference(x, None, True)
+            if cfg["model_conf"]["segment_dur"] is not None:
+                assert len(idx) > 1
+                for f in range(len(idx)):
+                    assert torch.equal(o["code_indices"][f], idx[f]), f"{name}: frame {f} indices"
+                    assert torch.equal(o["code_embeddings"][f][0], embs[f][0]) and torch.equal(o["code_embeddings"][f][1], embs[f][1])
+                assert torch.equal(o["recon_speech"], recon), f"{name}: oracle recon != reference"
+                np.savez_compressed(os.path.join(GOLD, name + ".npz"), recon=recon.numpy(),
+                                    **{f"indices_{f}": idx[f].numpy().astype(np.int16) for f in range(len(idx))},
+                                    **{f"scale_{f}": embs[f][1].numpy() for f in range(len(idx))})
+                manifest["cases"][name] = dict(kind="freqseg", config=cfg_name, weight_seed=wseed, codebook_decay=1.0, audio_kind=akind,
+                                               audio_seed=aseed, batch=B, samples=T, bit_width=None, n_q=int(idx[0].shape[0]),
+                                               frames=[int(i.shape[2]) for i in idx])
+                print(f"[golden] {name}: FreqCodec segmented, {len(idx)} frames {[tuple(i.shape) for i in idx]} oracle==reference OK")
+                continue
+            with torch.no_grad():
+                emb_ref, scale_ref = s2t.model._encode_frame(x.unsqueeze(1))
             assert torch.equal(o["encoder_out"], emb_ref), f"{name}: oracle encoder != reference"
             assert torch.equal(o["code_indices"][0], idx[0]), f"{name}: oracle indices != reference"
             assert torch.equal(o["code_embeddings"][0][0], embs[0][0]), f"{name}: oracle quantized != reference"

@@ -12,7 +12,7 @@ from helpers import (audio, engine_for, golden, index_report, manifest, oracle_f
 
 pytestmark = pytest.mark.gpu
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 FREQ = [n for n, c in MAN["cases"].items() if c.get("kind") == "freq"]
 
@@ -532,6 +532,27 @@ def test_freq_codec_against_reference_golden(name):
     n = g["recon"].shape[-1]
     sc = torch.from_numpy(g["scale"]).view(-1, 1, 1)
     assert rms(w2.cpu()[:, :, :n] * sc, g["recon"]) < WAV_RMS_TOL * float(np.sqrt((g["recon"] ** 2).mean())) * 10
+
+
+@pytest.mark.parametrize("name", [n for n, c in MAN["cases"].items() if c.get("kind") == "freqseg"])
+def test_freq_codec_segmented_mode_against_reference_golden(name):
+    """FreqCodec._encode / _decode with model_conf.segment_dur (codec_freq.py:303-328,390-404): per-frame STFT codec + the triangle
+    overlap-add, against the real reference run in that mode."""
+    from helpers import freq_engine_for
+    c = MAN["cases"][name]
+    m = freq_engine_for(c["config"], c["weight_seed"])
+    assert m.arch.segment_length == 2400 and m.arch.segment_stride == 2160
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    g = golden(name)
+    r = m.inference(wav.unsqueeze(1), bit_width=None, use_scale=True)
+    m.engine.check_status()
+    assert len(r["code_indices"]) == len(c["frames"])
+    for f, idx in enumerate(r["code_indices"]):
+        assert idx.shape == (c["n_q"], c["batch"], c["frames"][f])
+        assert index_report(idx, g[f"indices_{f}"].astype(np.int64))["mismatched_indices"] == 0, f
+        assert np.allclose(r["code_embeddings"][f][1].cpu().numpy(), g[f"scale_{f}"], rtol=1e-5)
+    assert tuple(r["recon_speech"].shape) == g["recon"].shape
+    assert rms(r["recon_speech"], g["recon"]) < 1e-3 * float(np.sqrt((g["recon"] ** 2).mean()))
 
 
 @pytest.mark.parametrize("cfg_name,seed,B,T,kind,bw,use_scale", [

@@ -7,7 +7,7 @@ import torch
 from helpers import audio, golden, index_report, manifest, oracle_for, rms
 
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 SAME_BUILD = torch.__version__ == MAN["torch"]
 
@@ -79,9 +79,31 @@ def test_freq_oracle_matches_reference_golden(name):
     assert (arch.model_type, arch.ratios, arch.ratios_f, arch.hop_length) == \
         ("freq_codec", (2, 1, 2, 1) if ds640 else (1, 1, 2, 1), (4, 4, 4, 4), 640 if ds640 else 320)
     assert arch.frames_for(c["samples"]) == g["indices"].shape[2]
-    for key, bad in (("encoder", "encodec_seanet_encoder"), ("model_conf", dict(cfg["model_conf"], codec_domain=["stft", "stft"]))):
+    for key, bad in (("encoder", "encodec_seanet_encoder"), ("model_conf", dict(cfg["model_conf"], codec_domain=["mag_angle", "mag_angle"])),
+                     ("input_size", 1)):
         with pytest.raises(NotImplementedError):
             arch_from_config(dict(cfg, **{key: bad}))      # other FreqCodec flavours are refused, not mis-decoded
+
+
+@pytest.mark.parametrize("name", [n for n, c in MAN["cases"].items() if c.get("kind") == "freqseg"])
+def test_freq_oracle_segmented_mode_matches_reference_golden(name):
+    """FreqCodec with model_conf.segment_dur set (codec_freq.py:303-328,390-404): per-frame codec + triangle overlap-add."""
+    from freq_oracle import FreqOracle
+    from freq_synth import freq_recipe_config, make_freq_state_dict
+    c = MAN["cases"][name]
+    cfg = freq_recipe_config(c["config"])
+    orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, c["weight_seed"]).items()})
+    g = golden(name)
+    o = orc.inference(audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"]), None, True)
+    assert [int(i.shape[2]) for i in o["code_indices"]] == c["frames"]
+    assert rms(o["recon_speech"], g["recon"]) < 1e-4
+    exact = SAME_BUILD and torch.get_num_threads() == MAN["threads"]
+    for f, idx in enumerate(o["code_indices"]):
+        rep = index_report(idx, g[f"indices_{f}"].astype(np.int64))
+        assert rep["mismatched_indices"] == 0 if exact else rep["frames_bad"] <= 1
+    from funcodec_amd.config import arch_from_config
+    a = arch_from_config(cfg)
+    assert a.segment_length == 2400 and a.segment_stride == 2160
 
 
 @pytest.mark.parametrize("name", SEG)
