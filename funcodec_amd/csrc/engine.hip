@@ -659,7 +659,7 @@ int pack_conv2d(fc_engine* e, ConvLayer& L) {
                     wg[((size_t)m * (kf * C) + (size_t)a * C + ci) * kt + b] = W[(((size_t)m * cpg + cl) * kf + a) * kt + b];
         }
     if (pack_gemm(e, L, wg, Bv)) return 1;
-    if (L.cout <= 4 && L.stride == 1 && L.sf == 1 && upload(e, wg, &L.w_plain)) return 1;      // [cout][kf * C][kt]: FMA kernel, no MFMA tile
+    if (L.cout <= 4 && L.stride == 1 && L.sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && upload(e, wg, &L.w_plain)) return 1;      // [cout][kf * C][kt]: FMA kernel, no MFMA tile
     if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
     if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
     return 0;
@@ -876,7 +876,8 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
             char nm[64];
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1,
                      L.BM >= 128 ? 2 : 4, mode, nu, row ? "true" : "false");
-            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s, %d>", c.k, c.s1.ptr ? "true" : "false", c.M);
+            if (fc::conv_cout1_ok(c))
+                snprintf(nm, sizeof(nm), "%s<%d, %s, %d>", fc::conv_fewout_rows(c) ? "conv_fewout_rows_kernel" : "conv_cout1_kernel", c.k, c.s1.ptr ? "true" : "false", c.M);
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);
@@ -1054,7 +1055,10 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
     const int Fo = (x0.F + tot_f - kf) / sf + 1;
     const ConvGeom g = conv_geom(L, x0.T);
     // layers with several M tiles: materialise the activated input once (as run_conv does), frequency-major with the same halo
-    if (L.Mpad / L.BM >= 3 && (x0.normed || dual || elu)) {
+    // the few-output FMA kernel re-stages every input row for each of the kf output rows that read it: activate once instead
+    static const int few_mat = getenv("FC_FEWOUT_MAT") ? atoi(getenv("FC_FEWOUT_MAT")) : 1;
+    const bool few_out = few_mat && L.cout <= 4 && L.stride == 1 && sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && kf > 1;   // = pack_conv2d's w_plain rule
+    if ((L.Mpad / L.BM >= 3 || few_out) && (x0.normed || dual || elu)) {
         Act2 m;
         m.C = C; m.F = x0.F; m.T = x0.T; m.halo = x0.halo;
         m.buf = cx.alloc<float>((size_t)B * (m.F + 2 * m.halo) * C * m.T);
@@ -1107,7 +1111,8 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
             char nm[64];
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
                      row ? "true" : "false");
-            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s, %d>", c.k, c.s1.ptr ? "true" : "false", c.M);
+            if (fc::conv_cout1_ok(c))
+                snprintf(nm, sizeof(nm), "%s<%d, %s, %d>", fc::conv_fewout_rows(c) ? "conv_fewout_rows_kernel" : "conv_cout1_kernel", c.k, c.s1.ptr ? "true" : "false", c.M);
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);
@@ -1190,7 +1195,8 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
             char nm[64];
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
                      row ? "true" : "false");
-            if (fc::conv_cout1_ok(c)) snprintf(nm, sizeof(nm), "conv_cout1_kernel<%d, %s, %d>", c.k, c.s1.ptr ? "true" : "false", c.M);
+            if (fc::conv_cout1_ok(c))
+                snprintf(nm, sizeof(nm), "%s<%d, %s, %d>", fc::conv_fewout_rows(c) ? "conv_fewout_rows_kernel" : "conv_cout1_kernel", c.k, c.s1.ptr ? "true" : "false", c.M);
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl / sf, by / sf);

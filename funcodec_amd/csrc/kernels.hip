@@ -82,8 +82,11 @@ std::vector<int> conv_koff_table(int k, int stride, int dil, int CC, int BN, int
 int conv_wbuf_floats(int k, int CC, int BM) { return ((((k * CC + 7) & ~7) * BM + 1023) / 1024) * 1024; }
 
 bool conv_cout1_ok(const ConvLaunch& c);
+// outputs per workgroup of the few-output FMA kernels: the LDS form (1024) on short rows / 2-D layers, the streaming form (992) else
+static int conv_fewout_tile(const ConvLaunch& c) { return (c.Fo > 1 || c.Tout < 8192) ? 1024 : 992; }
+bool conv_fewout_rows(const ConvLaunch& c) { return conv_fewout_tile(c) == 1024; }
 int conv_nblk(const ConvLaunch& c) {
-    if (conv_cout1_ok(c)) return ceil_div(c.Tout, 1024);     // single-output-channel kernel: one partial per 1024 samples
+    if (conv_cout1_ok(c)) return ceil_div(c.Tout, conv_fewout_tile(c));      // few-output FMA kernels: one partial per workgroup
     return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM);
 }
 
@@ -166,11 +169,8 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
 
 // =================================================================================================
 // 1b. Stride-1 conv with 1..4 output channels (the decoder's last layer: 32 -> 1, k = 7; FreqCodec's last Conv2d: 7 rows x 32
-//     channels -> 3): a 32-row MFMA tile would do 8..32x the necessary matrix work -> plain FMAs.  One workgroup = 1024 output samples of one utterance;
-//     the (GroupNorm apply, residual add, ELU)'d input is staged 8 channels at a time into LDS ([8][1032], 16-byte
-//     loads and stores on interior tiles), every thread owns 4 consecutive outputs and reads its 4+k-1 slab columns
-//     with three 16-byte LDS loads per channel; the k weights of a channel come through scalar loads.  Same epilogue
-//     contract as the MFMA kernel: raw output + fp64 (sum, sum of squares) partial per tile.
+//     channels -> 3): a 32-row MFMA tile would do 8..32x the necessary matrix work -> plain FMAs, weights through scalar loads.
+//     Same epilogue contract as the MFMA kernel: raw output + fp64 (sum, sum of squares) partial per workgroup (992 outputs).
 // =================================================================================================
 struct Cout1Args {
     const float *src0, *aff0, *src1, *aff1;    // [B][Cin][T], per-(b,c) affine or null
@@ -183,32 +183,40 @@ struct Cout1Args {
     // two-level batch (2-D convs over frequency-major activations, see ConvArgs): b = breal * Fo + fo
     int Fo, affC;
     long long in_sB0, in_sB1, out_sB, out_sF, out_sM, part_sB0;
+    int ablate;          // FC_ABLATE env (profiling aid): 1 no FMAs, 2 no stores, 4 no global loads, 8 no prologue math
 };
-constexpr int C1_TN = 1024, C1_CH = 8, C1_ROW = 1032;
+// LDS form for SHORT rows (the 2-D nets: ~1 000 samples per frequency row, many input channels): one workgroup = 1024 outputs of one
+// (virtual) utterance, the prologue'd input staged 8 channels at a time into LDS ([8][1032]), every thread owns 4 consecutive outputs and
+// reads its 4 + k - 1 slab columns with three 16-byte LDS loads per channel; the next chunk's global loads are in flight while the
+// current one is multiplied.  (Measured on FreqCodec's last Conv2d, 224 -> 3 channels: 2.1 ms per launch against 3.5 ms for the
+// streaming form below, which wins on the long 1-D rows: 187 vs 225 us.)
+constexpr int C1L_TN = 1024, C1L_CH = 8, C1L_ROW = 1032;
 
 template <int K, bool DUAL, int MO>
-__global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
+__global__ __launch_bounds__(256) void conv_fewout_rows_kernel(const Cout1Args p) {
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    __shared__ __attribute__((aligned(16))) float Xs[C1_CH][C1_ROW];
+    __shared__ __attribute__((aligned(16))) float Xs[C1L_CH][C1L_ROW];
     __shared__ double red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int breal = p.Fo > 1 ? b / p.Fo : b, fo = p.Fo > 1 ? b - breal * p.Fo : 0;
-    const int t0 = tile * C1_TN, tbase = t0 - p.padL;
-    const bool interior = tbase >= 0 && tbase + C1_ROW <= p.T;
+    const int t0 = tile * C1L_TN, tbase = t0 - p.padL;
     const size_t in_off = (size_t)breal * p.in_sB0 + (size_t)fo * p.in_sB1;
     const float* s0 = p.src0 + in_off;
     const float* s1 = DUAL ? p.src1 + in_off : s0;
     const bool wrap = p.affC != p.Cin;         // virtual channel = frequency row * affC + real channel
     const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)breal * p.affC : nullptr;
     const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)breal * p.affC : nullptr;
-    // edge tiles: source index (reflect padding, conv.py:82-99) and validity of this thread's columns, once per tile
+    // source index (reflect padding, conv.py:82-99) and validity of this thread's 4 main columns + (threads 0..7) one tail column.
+    // A thread whose 4 main columns are plain in-range samples takes one 16-byte load per row instead of four gathers.
+    const int g0 = tbase + 4 * tid;
+    const bool vec_ok = g0 >= 0 && g0 + 3 < p.T;
     int esrc[5]; unsigned emask = 0;
-    if (!interior) {
+    {
         const int refl = 2 * (p.Leff - 1);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            const int col = j < 4 ? 4 * tid + j : 1024 + tid;          // 4 main columns + (threads 0..7) one tail column
+            const int col = j < 4 ? 4 * tid + j : 1024 + tid;
             const int g = tbase + col;
             int src = g < 0 ? -g : g;
             src = src >= p.Leff ? refl - src : src;
@@ -218,6 +226,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
         }
     }
     auto act = [&](float v, float w, float2 A, float2 A1) __attribute__((always_inline)) {
+        if (p.ablate & 8) return v;
         v = fmaf(v, A.x, A.y);
         if (DUAL) v = v + fmaf(w, A1.x, A1.y);
         if (p.elu) v = elu_f(v, p.alpha);
@@ -228,50 +237,59 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
     for (int m = 0; m < MO; ++m)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
-    for (int c0 = 0; c0 < p.Cin; c0 += C1_CH) {
-        // ---- stage 8 channels
+    // raw values of the chunk being loaded: the loads of chunk c+1 are in flight while chunk c is multiplied out of LDS
+    f32x4 raw0[C1L_CH], raw1[DUAL ? C1L_CH : 1];
+    float rt0[C1L_CH], rt1[DUAL ? C1L_CH : 1];
+    auto load_chunk = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < C1_CH; ++r) {
+        for (int r = 0; r < C1L_CH; ++r) {
+            const int c = c0 + r < p.Cin ? c0 + r : p.Cin - 1;            // clamped: unconditional loads
+            const float* r0 = s0 + (size_t)c * p.T;
+            const float* r1 = s1 + (size_t)c * p.T;
+            if (p.ablate & 4) {
+                raw0[r] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
+                if (DUAL) raw1[r] = raw0[r];
+            } else if (vec_ok) {
+                raw0[r] = *(const f32x4u*)(r0 + g0);
+                if (DUAL) raw1[r] = *(const f32x4u*)(r1 + g0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    raw0[r][j] = r0[esrc[j]];
+                    if (DUAL) raw1[r][j] = r1[esrc[j]];
+                }
+            }
+            if (tid < 8) {
+                rt0[r] = r0[esrc[4]];
+                if (DUAL) rt1[r] = r1[esrc[4]];
+            }
+        }
+    };
+    const unsigned vmask = vec_ok ? 0xFu | (emask & 0x10u) : emask;
+    load_chunk(0);
+    for (int c0 = 0; c0 < p.Cin; c0 += C1L_CH) {
+        // ---- activate + stage 8 channels
+#pragma unroll
+        for (int r = 0; r < C1L_CH; ++r) {
             const int c = c0 + r;
             const bool cok = c < p.Cin;
-            const float* r0 = s0 + (size_t)(cok ? c : 0) * p.T;
-            const float* r1 = s1 + (size_t)(cok ? c : 0) * p.T;
             const int ca = !cok ? 0 : wrap ? c % p.affC : c;
             const float2 A = a0 ? a0[ca] : make_float2(1.f, 0.f);
             const float2 A1 = a1 ? a1[ca] : make_float2(1.f, 0.f);
             f32x4 v;
-            if (interior) {
-                const f32x4 x0 = *(const f32x4u*)(r0 + tbase + 4 * tid);
-                const f32x4 x1 = DUAL ? (f32x4)(*(const f32x4u*)(r1 + tbase + 4 * tid)) : x0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = cok ? act(x0[j], x1[j], A, A1) : 0.f;
-                if (tid < 2) {                                         // tail columns 1024..1031
-                    const f32x4 y0 = *(const f32x4u*)(r0 + tbase + 1024 + 4 * tid);
-                    const f32x4 y1 = DUAL ? (f32x4)(*(const f32x4u*)(r1 + tbase + 1024 + 4 * tid)) : y0;
-                    f32x4 u;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) u[j] = cok ? act(y0[j], y1[j], A, A1) : 0.f;
-                    *(f32x4*)&Xs[r][1024 + 4 * tid] = u;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float x0 = r0[esrc[j]], x1 = DUAL ? r1[esrc[j]] : 0.f;
-                    v[j] = (cok && ((emask >> j) & 1u)) ? act(x0, x1, A, A1) : 0.f;
-                }
-                if (tid < 8) {
-                    const float x0 = r0[esrc[4]], x1 = DUAL ? r1[esrc[4]] : 0.f;
-                    Xs[r][1024 + tid] = (cok && ((emask >> 4) & 1u)) ? act(x0, x1, A, A1) : 0.f;
-                }
-            }
+            for (int j = 0; j < 4; ++j)
+                v[j] = (cok && ((vmask >> j) & 1u)) ? act(raw0[r][j], DUAL ? raw1[r][j] : 0.f, A, A1) : 0.f;
             *(f32x4*)&Xs[r][4 * tid] = v;
+            if (tid < 8) Xs[r][1024 + tid] = (cok && ((vmask >> 4) & 1u)) ? act(rt0[r], DUAL ? rt1[r] : 0.f, A, A1) : 0.f;
         }
         __syncthreads();
-        // ---- 4 outputs per thread: out[n] += sum_c sum_kk w[c][kk] * x[c][n + kk]
+        if (c0 + C1L_CH < p.Cin) load_chunk(c0 + C1L_CH);
+        // ---- 4 outputs per thread and output channel: out[m][n] += sum_c sum_kk w[m][c][kk] * x[c][n + kk]
 #pragma unroll
-        for (int r = 0; r < C1_CH; ++r) {
+        for (int r = 0; r < C1L_CH; ++r) {
             const int c = c0 + r;
-            if (c >= p.Cin) break;                                     // uniform
+            if (c >= p.Cin || (p.ablate & 1)) break;                   // uniform
             const f32x4 q0 = *(const f32x4*)&Xs[r][4 * tid];
             const f32x4 q1 = *(const f32x4*)&Xs[r][4 * tid + 4];
             const f32x4 q2 = *(const f32x4*)&Xs[r][4 * tid + 8];
@@ -324,6 +342,158 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
     }
 }
 
+constexpr int C1_WOUT = 248, C1_TN = 4 * C1_WOUT, C1_UN = 4;    // outputs per wave / per workgroup; channels per load group
+
+// lane i <- lane i + 1 over the whole wavefront (DPP wave_shl:1; lane 63 gets 0)
+__device__ __forceinline__ float wave_shl1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+// Streaming form: no LDS slab, no barrier in the channel loop.  A wave covers 248 consecutive outputs: every lane loads ONE 16-byte
+// piece per source and channel (lanes 62, 63 only supply the k - 1 halo), applies the prologue to its 4 samples once, and gets the 6
+// samples to its right from the next two lanes by whole-wave DPP shifts; the loads of the next 4 channels are in flight while the
+// current 4 are multiplied.  Lanes at a padded edge (reflect, conv.py:82-99) gather their 4 samples by index instead.
+template <int K, bool DUAL, int MO>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int breal = p.Fo > 1 ? b / p.Fo : b, fo = p.Fo > 1 ? b - breal * p.Fo : 0;
+    const int t0 = tile * C1_TN + wid * C1_WOUT;               // first output of this wave
+    const bool wave_on = t0 < p.T;                              // uniform per wave
+    const size_t in_off = (size_t)breal * p.in_sB0 + (size_t)fo * p.in_sB1;
+    const float* s0 = p.src0 + in_off;
+    const float* s1 = DUAL ? p.src1 + in_off : s0;
+    const bool wrap = p.affC != p.Cin;                          // virtual channel = frequency row * affC + real channel
+    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)breal * p.affC : nullptr;
+    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)breal * p.affC : nullptr;
+    const int g0 = t0 - p.padL + 4 * lane;                      // padded-coordinate index of this lane's first sample
+    const bool vec_ok = g0 >= 0 && g0 + 3 < p.T;
+    int esrc[4]; unsigned emask = 0;
+    {
+        const int refl = 2 * (p.Leff - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = g0 + j;
+            int src = g < 0 ? -g : g;
+            src = src >= p.Leff ? refl - src : src;
+            const bool ok = g >= -p.padL && src >= 0 && src < p.T;
+            esrc[j] = ok ? src : 0;
+            emask |= (ok ? 1u : 0u) << j;
+        }
+    }
+    const unsigned vmask = vec_ok ? 0xFu : emask;
+    float acc[MO][4];
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+
+    auto load_group = [&](int c0, f32x4 (&r0)[C1_UN], f32x4 (&r1)[DUAL ? C1_UN : 1]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < C1_UN; ++u) {
+            const int c = c0 + u < p.Cin ? c0 + u : p.Cin - 1;                  // clamped: unconditional loads
+            const float* q0 = s0 + (size_t)c * p.T;
+            const float* q1 = s1 + (size_t)c * p.T;
+            if (p.ablate & 4) {
+                r0[u] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
+                if (DUAL) r1[u] = r0[u];
+            } else if (vec_ok) {
+                r0[u] = *(const f32x4u*)(q0 + g0);
+                if (DUAL) r1[u] = *(const f32x4u*)(q1 + g0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r0[u][j] = q0[esrc[j]];
+                    if (DUAL) r1[u][j] = q1[esrc[j]];
+                }
+            }
+        }
+    };
+    auto mul_group = [&](int c0, const f32x4 (&r0)[C1_UN], const f32x4 (&r1)[DUAL ? C1_UN : 1]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < C1_UN; ++u) {
+            const int c = c0 + u;
+            if (c >= p.Cin) break;                                                // uniform
+            const int ca = wrap ? c % p.affC : c;
+            const float2 A = a0 ? a0[ca] : make_float2(1.f, 0.f);
+            const float2 A1 = a1 ? a1[ca] : make_float2(1.f, 0.f);
+            float x[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = r0[u][j];
+                if (!(p.ablate & 8)) {
+                    v = fmaf(v, A.x, A.y);
+                    if (DUAL) v = v + fmaf(r1[u][j], A1.x, A1.y);
+                    if (p.elu) v = elu_f(v, p.alpha);
+                }
+                x[j] = ((vmask >> j) & 1u) ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[4 + j] = wave_shl1(x[j]);               // samples of lane + 1
+#pragma unroll
+            for (int j = 0; j < 2; ++j) x[8 + j] = wave_shl1(x[4 + j]);           // first two samples of lane + 2
+            if (p.ablate & 1) continue;
+#pragma unroll
+            for (int m = 0; m < MO; ++m) {
+                const float* wr = p.w + ((size_t)m * p.Cin + c) * K;             // uniform address: scalar loads
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) {
+                    const float wv = wr[kk];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(wv, x[j + kk], acc[m][j]);
+                }
+            }
+        }
+    };
+    if (wave_on) {
+        f32x4 ra0[C1_UN], ra1[DUAL ? C1_UN : 1], rb0[C1_UN], rb1[DUAL ? C1_UN : 1];
+        load_group(0, ra0, ra1);
+        for (int c0 = 0; c0 < p.Cin; c0 += 2 * C1_UN) {
+            if (c0 + C1_UN < p.Cin) load_group(c0 + C1_UN, rb0, rb1);
+            mul_group(c0, ra0, ra1);
+            if (c0 + 2 * C1_UN < p.Cin) load_group(c0 + 2 * C1_UN, ra0, ra1);
+            if (c0 + C1_UN < p.Cin) mul_group(c0 + C1_UN, rb0, rb1);
+        }
+    }
+    // ---- epilogue: bias, store, statistics of the valid outputs (lanes 62, 63 hold no outputs)
+    float s1v = 0.f, s2v = 0.f;
+    const int n0 = t0 + 4 * lane;
+    const bool out_lane = wave_on && lane < C1_WOUT / 4;
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        float o[4];
+        const float bm = p.bias[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = acc[m][j] + bm;
+            if (out_lane && n0 + j < p.T) { s1v += o[j]; s2v = fmaf(o[j], o[j], s2v); }
+        }
+        if ((p.ablate & 2) || !out_lane) continue;
+        float* orow = p.out + (size_t)breal * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.out_sM + n0;
+        if (n0 + 3 < p.T) *(f32x4u*)orow = (f32x4){o[0], o[1], o[2], o[3]};
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n0 + j < p.T) orow[j] = o[j];
+    }
+    if (p.partials) {
+        double d1 = (double)s1v, d2 = (double)s2v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            d1 += __shfl_xor(d1, off, 64);
+            d2 += __shfl_xor(d2, off, 64);
+        }
+        if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t slot = ((size_t)breal * p.part_sB0 + (size_t)fo * gridDim.x + tile) * 2;
+            p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+    }
+}
+
 bool conv_cout1_ok(const ConvLaunch& c) {
     return c.w_plain && c.M >= 1 && c.M <= 4 && c.store_lo <= 0 && c.store_hi >= c.Fo && c.stride == 1 && c.dil == 1 && !c.up_r && !c.pad_zero && !c.s0.div && c.out_sT == 1 && c.Tout == c.Tin &&
            (c.k == 7 || c.k == 3 || c.k == 5) && c.padL + c.padR == c.k - 1;
@@ -337,16 +507,25 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
     a.Fo = c.Fo > 1 ? c.Fo : 1; a.affC = c.affC > 0 ? c.affC : c.Cin;
     a.in_sB0 = c.in_sB0 ? c.in_sB0 : (long long)c.Cin * c.Tin; a.in_sB1 = c.in_sB1;
     a.out_sB = c.out_sB; a.out_sF = c.out_sF; a.out_sM = c.out_sM;
-    a.part_sB0 = c.part_sB0 ? c.part_sB0 : (long long)a.Fo * ceil_div(c.Tout, C1_TN);
+    const int tile_n = conv_fewout_tile(c);
+    a.part_sB0 = c.part_sB0 ? c.part_sB0 : (long long)a.Fo * ceil_div(c.Tout, tile_n);
+    static const int ablate_env = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
+    a.ablate = ablate_env;
     const int maxpad = c.padL > c.padR ? c.padL : c.padR;
     a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
     a.elu = c.elu; a.alpha = c.alpha;
     if (c.B > 65535) return hipErrorInvalidValue;
-    dim3 grid(ceil_div(c.Tout, C1_TN), c.B), block(256);
+    dim3 grid(ceil_div(c.Tout, tile_n), c.B), block(256);
+    const bool rows = tile_n == C1L_TN;
 #define FC_C1M(KK, MM)                                                                                  \
     case MM:                                                                                            \
-        if (c.s1.ptr) hipLaunchKernelGGL((conv_cout1_kernel<KK, true, MM>), grid, block, 0, st, a);     \
-        else hipLaunchKernelGGL((conv_cout1_kernel<KK, false, MM>), grid, block, 0, st, a);             \
+        if (rows) {                                                                                     \
+            if (c.s1.ptr) hipLaunchKernelGGL((conv_fewout_rows_kernel<KK, true, MM>), grid, block, 0, st, a);  \
+            else hipLaunchKernelGGL((conv_fewout_rows_kernel<KK, false, MM>), grid, block, 0, st, a);   \
+        } else {                                                                                        \
+            if (c.s1.ptr) hipLaunchKernelGGL((conv_cout1_kernel<KK, true, MM>), grid, block, 0, st, a); \
+            else hipLaunchKernelGGL((conv_cout1_kernel<KK, false, MM>), grid, block, 0, st, a);         \
+        }                                                                                               \
         break;
 #define FC_C1(KK)                                                                                       \
     case KK:                                                                                            \
