@@ -240,29 +240,18 @@ __global__ __launch_bounds__(256) void conv_fewout_rows_kernel(const Cout1Args p
     // raw values of the chunk being loaded: the loads of chunk c+1 are in flight while chunk c is multiplied out of LDS
     f32x4 raw0[C1L_CH], raw1[DUAL ? C1L_CH : 1];
     float rt0[C1L_CH], rt1[DUAL ? C1L_CH : 1];
+    // straight-line loads (clamped addresses, no branch around them); threads at a padded edge re-gather when they stage
+    const int gsafe = g0 < 0 ? 0 : (g0 + 3 < p.T ? g0 : (p.T >= 4 ? p.T - 4 : 0));
     auto load_chunk = [&](int c0) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < C1L_CH; ++r) {
-            const int c = c0 + r < p.Cin ? c0 + r : p.Cin - 1;            // clamped: unconditional loads
+            const int c = c0 + r < p.Cin ? c0 + r : p.Cin - 1;
             const float* r0 = s0 + (size_t)c * p.T;
             const float* r1 = s1 + (size_t)c * p.T;
-            if (p.ablate & 4) {
-                raw0[r] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-                if (DUAL) raw1[r] = raw0[r];
-            } else if (vec_ok) {
-                raw0[r] = *(const f32x4u*)(r0 + g0);
-                if (DUAL) raw1[r] = *(const f32x4u*)(r1 + g0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    raw0[r][j] = r0[esrc[j]];
-                    if (DUAL) raw1[r][j] = r1[esrc[j]];
-                }
-            }
-            if (tid < 8) {
-                rt0[r] = r0[esrc[4]];
-                if (DUAL) rt1[r] = r1[esrc[4]];
-            }
+            raw0[r] = *(const f32x4u*)(r0 + gsafe);
+            if (DUAL) raw1[r] = *(const f32x4u*)(r1 + gsafe);
+            rt0[r] = r0[esrc[4]];                                        // tail column (threads 0..7 use it; index 0 elsewhere)
+            if (DUAL) rt1[r] = r1[esrc[4]];
         }
     };
     const unsigned vmask = vec_ok ? 0xFu | (emask & 0x10u) : emask;
@@ -276,15 +265,23 @@ __global__ __launch_bounds__(256) void conv_fewout_rows_kernel(const Cout1Args p
             const int ca = !cok ? 0 : wrap ? c % p.affC : c;
             const float2 A = a0 ? a0[ca] : make_float2(1.f, 0.f);
             const float2 A1 = a1 ? a1[ca] : make_float2(1.f, 0.f);
+            f32x4 w0 = raw0[r], w1 = DUAL ? raw1[r] : raw0[r];
+            if (!vec_ok && cok) {                                        // padded edge: gather by index
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w0[j] = s0[(size_t)c * p.T + esrc[j]];
+                    if (DUAL) w1[j] = s1[(size_t)c * p.T + esrc[j]];
+                }
+            }
             f32x4 v;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                v[j] = (cok && ((vmask >> j) & 1u)) ? act(raw0[r][j], DUAL ? raw1[r][j] : 0.f, A, A1) : 0.f;
+                v[j] = (cok && ((vmask >> j) & 1u)) ? act(w0[j], w1[j], A, A1) : 0.f;
             *(f32x4*)&Xs[r][4 * tid] = v;
             if (tid < 8) Xs[r][1024 + tid] = (cok && ((vmask >> 4) & 1u)) ? act(rt0[r], DUAL ? rt1[r] : 0.f, A, A1) : 0.f;
         }
         __syncthreads();
-        if (c0 + C1L_CH < p.Cin) load_chunk(c0 + C1L_CH);
+        load_chunk(c0 + C1L_CH);                                         // past the last channel: clamped re-read, dropped
         // ---- 4 outputs per thread and output channel: out[m][n] += sum_c sum_kk w[m][c][kk] * x[c][n + kk]
 #pragma unroll
         for (int r = 0; r < C1L_CH; ++r) {
@@ -390,25 +387,15 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
 
+    // straight-line loads (no branch, clamped addresses): a conditional load makes hipcc wait for it right behind its issue.  Lanes at a
+    // padded edge re-gather their samples in mul_group (only the first / last wave of a row has such lanes)
+    const int gsafe = g0 < 0 ? 0 : (g0 + 3 < p.T ? g0 : (p.T >= 4 ? p.T - 4 : 0));
     auto load_group = [&](int c0, f32x4 (&r0)[C1_UN], f32x4 (&r1)[DUAL ? C1_UN : 1]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < C1_UN; ++u) {
-            const int c = c0 + u < p.Cin ? c0 + u : p.Cin - 1;                  // clamped: unconditional loads
-            const float* q0 = s0 + (size_t)c * p.T;
-            const float* q1 = s1 + (size_t)c * p.T;
-            if (p.ablate & 4) {
-                r0[u] = (f32x4){0.1f, 0.2f, 0.3f, 0.4f};
-                if (DUAL) r1[u] = r0[u];
-            } else if (vec_ok) {
-                r0[u] = *(const f32x4u*)(q0 + g0);
-                if (DUAL) r1[u] = *(const f32x4u*)(q1 + g0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    r0[u][j] = q0[esrc[j]];
-                    if (DUAL) r1[u][j] = q1[esrc[j]];
-                }
-            }
+            const int c = c0 + u < p.Cin ? c0 + u : p.Cin - 1;
+            r0[u] = *(const f32x4u*)(s0 + (size_t)c * p.T + gsafe);
+            if (DUAL) r1[u] = *(const f32x4u*)(s1 + (size_t)c * p.T + gsafe);
         }
     };
     auto mul_group = [&](int c0, const f32x4 (&r0)[C1_UN], const f32x4 (&r1)[DUAL ? C1_UN : 1]) __attribute__((always_inline)) {
@@ -419,13 +406,21 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
             const int ca = wrap ? c % p.affC : c;
             const float2 A = a0 ? a0[ca] : make_float2(1.f, 0.f);
             const float2 A1 = a1 ? a1[ca] : make_float2(1.f, 0.f);
+            f32x4 w0 = r0[u], w1 = DUAL ? r1[u] : r0[u];
+            if (!vec_ok) {                                                        // padded edge: gather by index
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w0[j] = s0[(size_t)c * p.T + esrc[j]];
+                    if (DUAL) w1[j] = s1[(size_t)c * p.T + esrc[j]];
+                }
+            }
             float x[12];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = r0[u][j];
+                float v = w0[j];
                 if (!(p.ablate & 8)) {
                     v = fmaf(v, A.x, A.y);
-                    if (DUAL) v = v + fmaf(r1[u][j], A1.x, A1.y);
+                    if (DUAL) v = v + fmaf(w1[j], A1.x, A1.y);
                     if (p.elu) v = elu_f(v, p.alpha);
                 }
                 x[j] = ((vmask >> j) & 1u) ? v : 0.f;
@@ -450,11 +445,11 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
     if (wave_on) {
         f32x4 ra0[C1_UN], ra1[DUAL ? C1_UN : 1], rb0[C1_UN], rb1[DUAL ? C1_UN : 1];
         load_group(0, ra0, ra1);
-        for (int c0 = 0; c0 < p.Cin; c0 += 2 * C1_UN) {
-            if (c0 + C1_UN < p.Cin) load_group(c0 + C1_UN, rb0, rb1);
+        for (int c0 = 0; c0 < p.Cin; c0 += 2 * C1_UN) {       // the loads past the last channel re-read it (clamped) and are dropped
+            load_group(c0 + C1_UN, rb0, rb1);
             mul_group(c0, ra0, ra1);
-            if (c0 + 2 * C1_UN < p.Cin) load_group(c0 + 2 * C1_UN, ra0, ra1);
-            if (c0 + C1_UN < p.Cin) mul_group(c0 + C1_UN, rb0, rb1);
+            load_group(c0 + 2 * C1_UN, ra0, ra1);
+            mul_group(c0 + C1_UN, rb0, rb1);
         }
     }
     // ---- epilogue: bias, store, statistics of the valid outputs (lanes 62, 63 hold no outputs)
