@@ -355,7 +355,46 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     }
 
 
+def fuzz_recipe_config(seed: int) -> Dict[str, Any]:
+    """A small pseudo-random architecture inside the engine's documented limits (the parity tests walk a few of these through the
+    real reference / the oracle and the engine: unusual ratios, kernel sizes, widths, residual stacks, codebook sizes)."""
+    import random
+    r = random.Random(1000 + seed)
+    ratios = [r.choice([2, 3, 4, 5, 8]) for _ in range(r.choice([1, 2, 3, 3, 4]))]
+    lstm = r.random() < 0.6
+    nf = r.choice([4, 8, 12]) if not lstm else r.choice([c for c in (4, 8, 12, 16) if (c << len(ratios)) % 16 == 0])
+    norm = r.choice(["time_group_norm", "time_group_norm", "weight_norm"])
+    causal = norm == "weight_norm" and r.random() < 0.5
+    compress = r.choice([c for c in (1, 2, 4) if nf % c == 0])
+    dim = r.choice([16, 32, 64])
+    enc = {"ratios": ratios, "norm": norm, "causal": causal, "n_filters": nf, "dimension": dim,
+           "kernel_size": r.choice([3, 5, 7]), "last_kernel_size": r.choice([3, 5, 7]), "residual_kernel_size": r.choice([3, 5]),
+           "compress": compress, "n_residual_layers": r.choice([1, 1, 2, 3]), "dilation_base": r.choice([1, 2, 3]),
+           "seq_model": "lstm" if lstm else "none", "seq_layer_num": r.choice([1, 2]),
+           "activation_params": {"alpha": r.choice([1.0, 0.7])}}
+    if norm == "time_group_norm":
+        enc["norm_params"] = {"eps": r.choice([1e-5, 1e-3])}
+    dec = {k: v for k, v in enc.items() if k != "dimension"}
+    hop = 1
+    for x in ratios:
+        hop *= x
+    return {
+        "input_size": 1, "sampling_rate": 16000,
+        "encoder": "encodec_seanet_encoder", "encoder_conf": enc,
+        "quantizer": "costume_quantizer",
+        "quantizer_conf": {"codebook_size": r.choice([64, 128, 256]), "num_quantizers": r.choice([1, 3, 5, 8]), "ema_decay": 0.99,
+                           "kmeans_init": True, "sampling_rate": 16000, "use_ddp": True, "encoder_hop_length": hop},
+        "decoder": "encodec_seanet_decoder", "decoder_conf": dec,
+        "discriminator": "multiple_disc", "discriminator_conf": {"disc_conf_list": []},
+        "model": "encodec",
+        "model_conf": {"odim": dim, "multi_spectral_window_powers_of_two": [], "target_sample_hz": 16000,
+                       "audio_normalize": r.random() < 0.7, "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None},
+    }
+
+
 def recipe_config(name: str) -> Dict[str, Any]:
+    if name.startswith("fuzz"):
+        return fuzz_recipe_config(int(name[4:]))
     if name.startswith(("freqmp", "tinyfreq")):
         return freq_recipe_config(name)
     if name == "ds320seg":   # ds320 run in the segmented overlap-add mode (0.5 s frames, 10 % overlap)

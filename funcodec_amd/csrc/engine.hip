@@ -54,6 +54,8 @@ struct ConvLayer {
     int zpadL = -1, zpadR = -1; // explicit ZERO padding (the inverse-STFT GEMM); -1: reference padding rules
     bool synthetic = false;     // weights generated at finalize (DFT matrices), not part of the checkpoint
     int groups = 1;             // grouped Conv2d / ConvTranspose2d (conv_group_ratio > 0): dense block-diagonal weight at finalize
+    bool force_plain = false;   // the slab of the fused-prologue variants does not fit (large strides): materialise the input first
+    bool unsupported = false;   // no variant fits (stride > ~17): refused at fc_engine_create
     // GEMM view
     int M = 0, gk = 1, gstride = 1;    // rows, taps, stride of the implicit GEMM
     int BM = 128, BN = 128, CC = 2, nchunk = 1, Mpad = 0;
@@ -482,7 +484,20 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     // channels per K-chunk: as many as fit (a) the register-staged slab, (b) K-chunk <= 64, (c) half of the LDS
     // (two workgroups per CU).  Layers with >= 3 M tiles get their input materialised (run_conv) and therefore
     // always run the PLAIN variant: no affine tables, and the 16-element staging variant has no register pressure.
-    const bool plain = ceil_div_i(L.M, L.BM) >= 3;
+    // large strides (> 4 on the 256-column tiles, > 8 two-source): the slab of even a 2-channel chunk exceeds the staging registers.
+    // Narrower N tile first, then the materialised-input (plain, 18 slots) variant, else the layer is refused at create.
+    {
+        auto fits = [&](bool dual) { return fc::conv_slab_fits(L.gk, L.gstride, L.dil, 2, L.BN, L.BM, dual && ceil_div_i(L.M, L.BM) < 3); };
+        if (!fits(L.dual) && L.BN == 256) {
+            if (L.BM == 32) L.BN = 128;
+            else { L.BM = 128; L.BN = 128; }
+        }
+        if (!fits(L.dual)) {
+            if (fits(false)) L.force_plain = true;
+            else L.unsupported = true;
+        }
+    }
+    const bool plain = ceil_div_i(L.M, L.BM) >= 3 || L.force_plain;
     const bool dual_eff = L.dual && !plain;
     // LDS budget of one workgroup.  Layers at the bottleneck frame rate with M <= 1024 have at most one workgroup per CU at the
     // benchmark shape anyway (M/128 x 2 N tiles x 16 utterances <= 256): they take the whole CU's LDS, i.e. twice as deep K
@@ -815,7 +830,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     // Layers with several M tiles would re-apply the fused prologue (GroupNorm affine, residual add, ELU) once per
     // M tile; for those (deep, short tensors) it is cheaper to materialise the activated input once and stream it.
     const bool has_prologue = (s0.used & 2) || s1.used || elu;
-    if (L.Mpad / L.BM >= 3 && has_prologue) {
+    if ((L.Mpad / L.BM >= 3 || L.force_plain) && has_prologue) {
         float* tmp = cx.alloc<float>((size_t)cx.B * L.cin * Tin);
         cx.launches++;
         if (!cx.dry && !cx.err) {
@@ -1058,7 +1073,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
     // the few-output FMA kernel re-stages every input row for each of the kf output rows that read it: activate once instead
     static const int few_mat = getenv("FC_FEWOUT_MAT") ? atoi(getenv("FC_FEWOUT_MAT")) : 1;
     const bool few_out = few_mat && L.cout <= 4 && L.stride == 1 && sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && kf > 1;   // = pack_conv2d's w_plain rule
-    if ((L.Mpad / L.BM >= 3 || few_out) && (x0.normed || dual || elu)) {
+    if ((L.Mpad / L.BM >= 3 || few_out || L.force_plain) && (x0.normed || dual || elu)) {
         Act2 m;
         m.C = C; m.F = x0.F; m.T = x0.T; m.halo = x0.halo;
         m.buf = cx.alloc<float>((size_t)B * (m.F + 2 * m.halo) * C * m.T);
@@ -1437,6 +1452,13 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     e->arch = *arch;
     e->device = device;
     build_plan(e);
+    for (const auto& kv : e->by_prefix)
+        if (kv.second->unsupported) {
+            const std::string msg = "stride " + std::to_string(kv.second->gstride) + " / kernel " + std::to_string(kv.second->gk) + " of " + kv.first +
+                                    " exceeds the conv kernel's slab (ratios above 16 are not built)";
+            delete e;
+            return fail(msg);
+        }
     if (arch->model_type == 1) {          // torch.nn.Conv2d / ConvTranspose2d constraints on `groups` (conv_group_ratio > 0)
         std::vector<const ConvLayer*> ls;
         for (auto* st : {&e->enc_stages, &e->dec_stages})

@@ -116,7 +116,7 @@ int conv_wgs_per_cu(int) { return 2; }
 bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dual) {
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int img = CC * ceil_div(slabW, stride) * stride;
-    if (dual && CC > 2) return img <= NU_DUAL * 256;   // two-source prologue: the low-register variants (NU = 8 / NU_DUAL)
+    if (dual) return img <= NU_DUAL * 256;             // two-source prologue: at most NU_DUAL slots (two values + two table entries each)
     return img <= SLAB_PER_THREAD * 256;
 }
 

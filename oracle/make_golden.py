@@ -78,6 +78,13 @@ CASES = [
     ("ds640_wav_jamendo_0027", "ds640", 0, 1.0, "wav:jamendo_0027", 0, 1, 160000, None),
     ("ds320_wav_libritts_5105", "ds320", 0, 1.0, "wav:libritts_5105", 0, 1, 18186, None),
     ("ds320_wav_libritts_8230", "ds320", 0, 1.0, "wav:libritts_8230", 0, 1, 29440, None),
+    # pseudo-random small architectures (funcodec_amd/config.py::fuzz_recipe_config): ratios like 3 / 5 / 8, kernel sizes 3 / 5 / 7,
+    # compress 1 / 4, 1- and 2-layer LSTMs, dilation bases 1 / 3, ELU alpha 0.7, GroupNorm eps 1e-3, audio_normalize off ...
+    ("fuzz2_b2_t5000", "fuzz2", 2, 1.0, "tones", 91, 2, 5000, None),       # GroupNorm, ratios 8,5,3,3, compress 4, 1-layer LSTM(256)
+    ("fuzz10_b2_t3001", "fuzz10", 10, 1.0, "noise", 92, 2, 3001, None),    # GroupNorm, ratios 3,8,2,5, 2 residual blocks (dilation 1, 3), k = 3
+    ("fuzz11_b3_t2000", "fuzz11", 11, 0.9, "tones", 93, 3, 2000, None),    # GroupNorm, ratios 4,2,5, compress 4, 2-layer LSTM(128), k_last = 5
+    ("fuzz0_b2_t2222", "fuzz0", 0, 1.0, "noise", 94, 2, 2222, 2000),       # weight_norm non-causal, ratios 2,5,4, 2 blocks (dilation 1, 3), LSTM
+    ("fuzz3_b1_t4000", "fuzz3", 3, 1.0, "tones", 95, 1, 4000, None),       # weight_norm causal, ratios 8,4,3, 3 blocks (dilation 1, 3, 9)
 ]
 # cases stored without the decode-path waveform (file size): indices, scale, encoder output (the tie proof of the parity tests
 # needs it), quantized, recon
@@ -181,8 +188,9 @@ def main():
             assert torch.equal(od, recon_dec), f"{name}: oracle decode != reference"
             assert torch.equal(orc.decode_emb(quant), recon_emb)
 
-            arrays = dict(indices=idx[0].numpy().astype(np.int16), scale=scale_ref.numpy(), quantized=quant.numpy(),
-                          recon=recon.numpy(), encoder_out=emb_ref.numpy())
+            arrays = dict(indices=idx[0].numpy().astype(np.int16), quantized=quant.numpy(), recon=recon.numpy(), encoder_out=emb_ref.numpy())
+            if scale_ref is not None:                  # model_conf.audio_normalize: false -> no scale
+                arrays.update(scale=scale_ref.numpy())
             if name not in SLIM:
                 arrays.update(recon_from_codes=recon_dec.numpy())
             np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
