@@ -153,7 +153,7 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         if dict(conf.get("norm_params", {}) or {}).get("num_groups", 1) != 1:
             raise _unsupported(f"{which}.norm_params.num_groups", conf["norm_params"]["num_groups"])
         for key, ok in (("true_skip", False), ("pad_mode", "reflect"),
-                        ("activation", "ELU"), ("seq_model", "lstm"), ("final_activation", None), ("trim_right_ratio", 1.0)):
+                        ("activation", "ELU"), ("final_activation", None), ("trim_right_ratio", 1.0)):
             if conf.get(key, ok) != ok:
                 raise _unsupported(f"{which}.{key}", conf[key])
     domain = list(m.get("codec_domain", ["time", "time"]))
@@ -188,6 +188,10 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     ov = m["overlap_ratio"] if "overlap_ratio" in m else 0.01
     act_params = dict(shared("activation_params", {"alpha": 1.0}) or {})
     norm_params = dict(shared("norm_params", {}) or {})
+    seq_model = shared("seq_model", "lstm")
+    if seq_model not in ("lstm", "none", None):
+        raise _unsupported("encoder_conf.seq_model", seq_model, "lstm or none")
+    seq_model = "lstm" if seq_model == "lstm" else "none"
     arch = ArchSpec(
         sample_rate=int(m.get("target_sample_hz", 24000)), input_channels=n_in,
         audio_normalize=bool(m.get("audio_normalize", False)),            # FreqCodec.__init__ default is False (codec_freq.py:141)
@@ -196,7 +200,7 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         kernel_size=int(shared("kernel_size", 7)), last_kernel_size=int(shared("last_kernel_size", 7)),
         residual_kernel_size=int(shared("residual_kernel_size", 3)), n_residual_layers=int(shared("n_residual_layers", 1)),
         dilation_base=int(shared("dilation_base", 2)), compress=int(shared("compress", 2)),
-        lstm_layers=int(shared("seq_layer_num", 2)), lstm_skip=bool(shared("res_seq", True)),
+        lstm_layers=int(shared("seq_layer_num", 2)) if seq_model == "lstm" else 0, lstm_skip=bool(shared("res_seq", True)),
         elu_alpha=float(act_params.get("alpha", 1.0)), gn_eps=float(norm_params.get("eps", 1e-5)),
         codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=dimension, num_quantizers=int(q.get("num_quantizers", 8)),
         encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
@@ -311,10 +315,55 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
 # Values follow egs/LibriTTS/codec/conf/encodec_16k_n32_600k_step_ds640.yaml:1-53 (ds640) and the
 # class-default ratios of SEANetEncoder (seanet_encoder.py:92) for ds320.
 # ----------------------------------------------------------------------------------------------
+def fuzz_freq_recipe_config(seed: int) -> Dict[str, Any]:
+    """A small pseudo-random FreqCodec (mag_phase) architecture: n_fft 64 / 128 / 512 with frequency ratios that reduce n_fft / 2 + 1 bins to
+    one, time ratios 1 / 2, odd STFT hops included never (the engine wants an even hop), grouped and dense convs, with / without LSTM."""
+    import random
+    r = random.Random(7000 + seed)
+    n_fft = r.choice([64, 128, 512])
+    rf = {64: [4, 8], 128: [4, 4, 4], 512: [4, 4, 4, 4]}[n_fft]
+    if n_fft == 64 and r.random() < 0.5:
+        rf = [8, 4]
+    ratios = [[f, r.choice([1, 1, 2])] for f in rf]
+    nf = r.choice([4, 8])
+    lstm = (nf << len(rf)) % 16 == 0 and r.random() < 0.6
+    gr = r.choice([-1, -1, 1, 2]) if nf == 8 else -1
+    nres = r.choice([1, 1, 2])
+    dim = r.choice([16, 32])
+    enc = {"ratios": ratios, "norm": "time_group_norm", "norm_params": {"num_groups": 1}, "causal": False, "dilation_base": 1,
+           "n_filters": nf, "dimension": dim, "kernel_size": r.choice([3, 5, 7]), "last_kernel_size": r.choice([3, 5, 7]),
+           "residual_kernel_size": 3, "compress": r.choice([1, 2]), "n_residual_layers": nres,
+           "seq_model": "lstm" if lstm else "none", "seq_layer_num": r.choice([1, 2])}
+    if gr > 0:
+        enc["conv_group_ratio"] = gr
+    dec = dict({k: v for k, v in enc.items() if k != "dimension"}, channels=3)
+    if gr > 0:
+        dec["tr_conv_group_ratio"] = gr
+    hop = r.choice([h for h in (n_fft // 4, n_fft // 2, 40, 160) if h <= n_fft // 2 and h % 2 == 0])
+    tot = hop
+    for _, t in ratios:
+        tot *= t
+    return {
+        "input_size": 3, "sampling_rate": 16000,
+        "encoder": "encodec_seanet_encoder_2d", "encoder_conf": enc,
+        "quantizer": "costume_quantizer",
+        "quantizer_conf": {"codebook_size": r.choice([64, 128]), "num_quantizers": r.choice([2, 4]), "ema_decay": 0.99, "kmeans_init": True,
+                           "sampling_rate": 16000, "use_ddp": True, "encoder_hop_length": tot},
+        "decoder": "encodec_seanet_decoder_2d", "decoder_conf": dec,
+        "discriminator": "multiple_disc", "discriminator_conf": {"disc_conf_list": []},
+        "model": "freq_codec",
+        "model_conf": {"odim": dim, "multi_spectral_window_powers_of_two": [], "target_sample_hz": 16000,
+                       "audio_normalize": r.random() < 0.6, "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None,
+                       "codec_domain": ["mag_phase", "mag_phase"], "domain_conf": {"n_fft": n_fft, "hop_length": hop}},
+    }
+
+
 def freq_recipe_config(name: str) -> Dict[str, Any]:
     """`freqmp`: egs/LibriTTS/codec/conf/freqcodec_mag_phase_16k_n32_600k_step.yaml:1-59 (16.2 M parameters);
     `freqmp640`: ..._ds640.yaml (time ratios 2,1,2,1, 640 samples per frame);
     `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
+    if name.startswith("freqfuzz"):
+        return fuzz_freq_recipe_config(int(name[8:]))
     seg = name.endswith("seg")                        # FreqCodec._encode / _decode in segmented mode: 0.15 s frames, 10 % overlap
     name = name[:-3] if seg else name
     angle = name.endswith("ang")                      # freqcodec_mag_angle_16k_n32_600k_step.yaml (refused by arch_from_config)
@@ -395,7 +444,7 @@ def fuzz_recipe_config(seed: int) -> Dict[str, Any]:
 def recipe_config(name: str) -> Dict[str, Any]:
     if name.startswith("fuzz"):
         return fuzz_recipe_config(int(name[4:]))
-    if name.startswith(("freqmp", "tinyfreq")):
+    if name.startswith(("freqmp", "tinyfreq", "freqfuzz")):
         return freq_recipe_config(name)
     if name == "ds320seg":   # ds320 run in the segmented overlap-add mode (0.5 s frames, 10 % overlap)
         cfg = recipe_config("ds320")

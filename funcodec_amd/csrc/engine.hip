@@ -3,6 +3,7 @@
 // synchronises with the host after fc_engine_finalize().
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -135,6 +136,7 @@ struct fc_engine {
     // STFT-domain codec (arch.model_type == 1)
     ConvLayer enc2_first, dec2_last, stft, istft;
     std::vector<std::vector<ConvLayer>> dec_up_phases;                    // decoder stage s: one transposed 1-D GEMM per frequency phase
+    int halo2 = 3;                                                        // frequency halo rows of the 2-D activations
     float* win2 = nullptr;                                                // squared Hann window [n_fft] (istft envelope)                       // "encoder.model.1" -> block (fc_resblock_forward)
     std::map<std::string, LstmBlock*> lstm_by_prefix;
     // quantiser
@@ -250,6 +252,8 @@ void add_conv2d_expect(fc_engine* e, ConvLayer& L) {
 void build_plan_2d(fc_engine* e) {
     const fc_arch& a = e->arch;
     const int nf = a.n_filters, nres = a.n_residual_layers;
+    e->halo2 = std::max(std::max(a.kernel_size, a.last_kernel_size), a.residual_kernel_size) / 2;
+    for (int s = 0; s < a.n_ratios; ++s) e->halo2 = std::max(e->halo2, (a.ratios_f[s] + 1) / 2);
     auto name = [](const char* side, int idx, const char* suffix) { return std::string(side) + ".model." + std::to_string(idx) + suffix; };
     auto add_res = [&](fc_engine::ResBlock& R, const char* side, int idx, int c, int j, int dil) {
         const int hid = c / a.compress, rk = a.residual_kernel_size;
@@ -1059,7 +1063,9 @@ struct Act2 {              // raw [B][F + 2*halo][C][T] + pending GroupNorm affi
     int C = 0, F = 0, T = 0, halo = 0;
     bool normed = false;
 };
-constexpr int kHalo2 = 3;  // frequency halo rows of every 2-D activation that a kf > 1 conv may read (7x7: 3, 8-row strided: 2, 3x3: 1)
+// frequency halo rows of every 2-D activation that a kf > 1 conv may read = the largest one-sided frequency padding of the net's convs
+// (7x7: 3, 3x3: 1, strided 2 fr rows with stride fr: ceil(fr / 2)); fc_engine::halo2, set by build_plan_2d
+#define kHalo2 (e->halo2)
 
 // SConv2d.forward (conv.py:342-381) as ONE launch of the 1-D implicit-GEMM kernel over B * Fo virtual utterances
 Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* x1p, int elu, int out_halo) {

@@ -125,14 +125,19 @@ def freq_plan(cfg: Dict[str, Any]) -> list:
         mult *= 2
     idx += 1                                          # ReshapeModule
     cb = mult * nf
-    ops.append(("lstm", f"encoder.model.{idx}.lstm", (cb,)))
-    idx += 2
+    has_lstm = enc.get("seq_model", "lstm") == "lstm"
+    if has_lstm:
+        ops.append(("lstm", f"encoder.model.{idx}.lstm", (cb, enc.get("seq_layer_num", 2))))
+        idx += 1
+    idx += 1                                          # ELU
     ops.append(("conv", f"encoder.model.{idx}.conv", (dim, cb, lks)))
     idx = 0
     ops.append(("conv", f"decoder.model.{idx}.conv", (cb, dim, ks)))
     idx += 1
-    ops.append(("lstm", f"decoder.model.{idx}.lstm", (cb,)))
-    idx += 2                                          # + ReshapeModule
+    if has_lstm:
+        ops.append(("lstm", f"decoder.model.{idx}.lstm", (cb, enc.get("seq_layer_num", 2))))
+        idx += 1
+    idx += 1                                          # ReshapeModule
     for fr, tr in ratios:
         c = mult * nf
         idx += 1
@@ -162,7 +167,7 @@ def make_freq_state_dict(cfg: Dict[str, Any], seed: int = 0) -> Dict[str, np.nda
         if kind == "lstm":
             h = shape[0]
             b = 1.0 / np.sqrt(h)
-            for l in range(2):
+            for l in range(shape[1] if len(shape) > 1 else 2):
                 sd[f"{key}.weight_ih_l{l}"] = uni((4 * h, h), b)
                 sd[f"{key}.weight_hh_l{l}"] = uni((4 * h, h), b)
                 sd[f"{key}.bias_ih_l{l}"] = uni((4 * h,), b)

@@ -100,6 +100,11 @@ FREQ_CASES = [
     ("tinyfreqgr1_b2_t2500", "tinyfreqgr1", 7, "tones", 84, 2, 2500),
     # segmented mode (FreqCodec._encode / _decode with model_conf.segment_dur: 2400-sample frames, stride 2160, triangle overlap-add)
     ("tinyfreqseg_b2_t6000", "tinyfreqseg", 8, "tones", 85, 2, 6000),
+    # pseudo-random FreqCodec architectures (config.py::fuzz_freq_recipe_config): n_fft 512 / 128 / 64, STFT hops 128 / 64 / 16, grouped convs,
+    # two residual blocks per stage, kernel sizes 5 / 3, time ratios (1,2,1,1) / (2,1,2) / (1,1), 2-layer LSTMs
+    ("freqfuzz3_b2_t3000", "freqfuzz3", 3, "tones", 96, 2, 3000),
+    ("freqfuzz5_b2_t2500", "freqfuzz5", 5, "noise", 97, 2, 2500),
+    ("freqfuzz10_b3_t700", "freqfuzz10", 10, "tones", 98, 3, 700),
 ]
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [
@@ -295,9 +300,10 @@ def main():
             assert torch.equal(o["code_indices"][0], idx[0]), f"{name}: oracle indices != reference"
             assert torch.equal(o["code_embeddings"][0][0], embs[0][0]), f"{name}: oracle quantized != reference"
             assert torch.equal(o["recon_speech"], recon), f"{name}: oracle recon != reference"
-            np.savez_compressed(os.path.join(GOLD, name + ".npz"), indices=idx[0].numpy().astype(np.int16),
-                                encoder_out=emb_ref.numpy(), scale=scale_ref.numpy(), quantized=embs[0][0].numpy(),
-                                recon=recon.numpy())
+            arrays = dict(indices=idx[0].numpy().astype(np.int16), encoder_out=emb_ref.numpy(), quantized=embs[0][0].numpy(), recon=recon.numpy())
+            if scale_ref is not None:                  # model_conf.audio_normalize: false -> no scale
+                arrays.update(scale=scale_ref.numpy())
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
             manifest["cases"][name] = dict(kind="freq", config=cfg_name, weight_seed=wseed, codebook_decay=1.0, audio_kind=akind,
                                            audio_seed=aseed, batch=B, samples=T, bit_width=None, n_q=int(idx[0].shape[0]),
                                            frames=int(idx[0].shape[2]),

@@ -66,7 +66,7 @@ def test_freq_oracle_matches_reference_golden(name):
     wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
     g = golden(name)
     o = orc.inference(wav, None, True)
-    assert o["features"].shape[1:3] == (3, 257)
+    assert o["features"].shape[1:3] == (3, orc.n_fft // 2 + 1)
     assert rms(o["encoder_out"], g["encoder_out"]) < 1e-5 and rms(o["recon_speech"], g["recon"]) < 1e-4
     rep = index_report(o["code_indices"][0], g["indices"].astype(np.int64))
     if SAME_BUILD and torch.get_num_threads() == MAN["threads"]:
@@ -76,8 +76,9 @@ def test_freq_oracle_matches_reference_golden(name):
     from funcodec_amd.config import arch_from_config
     arch = arch_from_config(cfg)
     ds640 = c["config"].endswith("640")
-    assert (arch.model_type, arch.ratios, arch.ratios_f, arch.hop_length) == \
-        ("freq_codec", (2, 1, 2, 1) if ds640 else (1, 1, 2, 1), (4, 4, 4, 4), 640 if ds640 else 320)
+    if not c["config"].startswith("freqfuzz"):
+        assert (arch.model_type, arch.ratios, arch.ratios_f, arch.hop_length) == \
+            ("freq_codec", (2, 1, 2, 1) if ds640 else (1, 1, 2, 1), (4, 4, 4, 4), 640 if ds640 else 320)
     assert arch.frames_for(c["samples"]) == g["indices"].shape[2]
     for key, bad in (("encoder", "encodec_seanet_encoder"), ("model_conf", dict(cfg["model_conf"], codec_domain=["mag_angle", "mag_angle"])),
                      ("input_size", 1)):
