@@ -176,7 +176,9 @@ def main():
     if args.workload == "freqcodec" and not is_freq():
         CONFIG = "freqmp"
     if is_freq() and not os.environ.get("FC_BENCH_MICRO"):
-        MICRO_BATCH = 64                                   # configs[3]: batch 64 in one engine call
+        MICRO_BATCH = 32                                   # configs[3]: batch 64 = two engine calls of 32 (the persistent LSTM holds <= 32 utterances)
+    if is_freq() and not os.environ.get("FC_BENCH_UTTS"):
+        os.environ["FC_BENCH_UTTS"] = "64"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

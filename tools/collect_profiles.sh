@@ -17,6 +17,11 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o out --output-form
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/pmc_write.err
 python $R/tools/trace_summary.py $(ls $OUT/rp/*kernel_trace.csv | head -1) > $OUT/last_step_per_launch.txt 2>&1
 python $R/tools/profile_post.py $OUT
+# side measurement of the next scope row (BASELINE.json configs[3] shape): FreqCodec recipe, 64 x 10 s
+python $R/bench.py --workload freqcodec --steps 5 --warmup 2 > $OUT/bench_freqcodec.json 2> $OUT/bench_freqcodec.err
+rocprofv3 --kernel-trace --stats -d $OUT/rpf -o out --output-format csv -- python $R/bench.py --workload freqcodec --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/rpf.err
+cp $(ls $OUT/rpf/*kernel_stats.csv | head -1) $OUT/kernel_stats_freqcodec.csv
+rm -rf $OUT/rpf
 ls -la $OUT | head -30
 # keep the merge-back small: raw traces are large
 rm -rf $OUT/rp/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write
