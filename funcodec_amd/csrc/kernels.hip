@@ -1665,6 +1665,8 @@ struct LstmPersistArgs {
     unsigned* status;    // host-visible engine status words (kernels.h FC_STATUS_*), or null
     int B, H, T;
     int ablate;          // FC_ABLATE_LSTM env: 1 no grid barrier (profiling aid), 64 test hook: behave as if the grid barrier had timed out
+    int groups;          // independent recurrences in one launch: group j = workgroups [j*H/4, (j+1)*H/4) owns batch rows [16j, 16j+16) with
+                         // its own barrier words (H = 512 fills only half of the chip: two batch tiles then advance side by side)
 };
 
 constexpr int kLstmSyncWords = 1024;
@@ -1703,8 +1705,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, r16 = lane & 15;
     const int H = p.H, B = p.B, T = p.T;
-    const int blk = blockIdx.x;
-    const unsigned arrivals = gridDim.x >> 4;        // per counter per step
+    const int wgs = H >> 2;                          // workgroups of one recurrence
+    const int grp = p.groups > 1 ? blockIdx.x / wgs : 0;
+    const int blk = blockIdx.x - grp * wgs;
+    const int brow0 = grp * 16;                      // first batch row of this group (groups > 1 run with NBT == 1)
+    unsigned* const sync = p.sync + (size_t)grp * kLstmSyncWords;
+    const unsigned arrivals = (unsigned)wgs >> 4;    // per counter per step
     const int kslice = NS * 16;                      // H / 4 waves
     const size_t BH = (size_t)B * H;
     // ---- weights -> registers (once)
@@ -1740,7 +1746,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
         float* h1o = hist1 + (size_t)(s - 1) * BH;                                   // h1(s-2)   (s >= 2)
 #pragma unroll
         for (int nb = 0; nb < NBT; ++nb) {
-            const int brow = nb * 16 + r16;
+            const int brow = brow0 + nb * 16 + r16;
             const bool bvalid = brow < B;
             const size_t hoff = (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
             f32x4 xp = {0.f, 0.f, 0.f, 0.f};
@@ -1797,13 +1803,13 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             __syncthreads();
         }
         if (s > T) break;
-        const bool sync = !(p.ablate & 1);
-        if (sync) lstm_barrier_arrive(p.sync, blk);
+        const bool do_sync = !(p.ablate & 1);
+        if (do_sync) lstm_barrier_arrive(sync, blk);
         // ---- barrier shadow: P for the next step's layer-1 timestep t = s - 1 (needs h0(s-1), already visible)
         if (s >= 1) {
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) {
-                const int brow = nb * 16 + r16;
+                const int brow = brow0 + nb * 16 + r16;
                 const bool bvalid = brow < B;
                 const size_t hoff = (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
                 f32x4 b0l[NBT == 1 ? 1 : NS];
@@ -1824,11 +1830,11 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
                 pa[nb] = c1a; pb[nb] = c1b;
             }
         }
-        if (sync) lstm_barrier_wait(p.sync, (unsigned)(s + 1) * arrivals);
+        if (do_sync) lstm_barrier_wait(sync, (unsigned)(s + 1) * arrivals);
     }
     // a barrier that timed out (some workgroup was not resident) must not pass for a result: poison this workgroup's
     // outputs so that the failure is loud downstream (the engine's per-step launch path is the supported fallback)
-    if (__hip_atomic_load(p.sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || (p.ablate & 64)) {
+    if (__hip_atomic_load(sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || (p.ablate & 64)) {
         if (p.status && tid == 0) *(volatile unsigned*)(p.status + FC_STATUS_LSTM_TIMEOUT) = 1u;   // read by the host at its next fc_* call
         for (int i = tid; i < 4 * B * T; i += 256) {
             const int t = i % T, bu = i / T;
@@ -1837,20 +1843,23 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     }
 }
 
-size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords + (size_t)(2 * T + 1) * B * H; }
-size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords + (size_t)B * H; }
+// H = 512 occupies 128 of the 256 CUs: a second batch tile gets its own 128 workgroups (and barrier words) instead of a second pass
+static int lstm_persist_groups(int B, int H) { return (H == 512 && B > 16) ? 2 : 1; }
+size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)(2 * T + 1) * B * H; }
+size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)B * H; }
 
 // `state`: lstm_persist_state_floats() floats whose first lstm_persist_clear_floats() are zero (barrier words + the
 // all-zero initial hidden state)
 hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bias1, const float* xproj, float* state, float* y,
                                int B, int H, int T, unsigned* status, hipStream_t st) {
     LstmPersistArgs a;
-    a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.hist = state + kLstmSyncWords; a.y = y;
-    a.sync = (unsigned*)state; a.status = status; a.B = B; a.H = H; a.T = T;
+    const int groups = lstm_persist_groups(B, H);
+    a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.hist = state + (size_t)kLstmSyncWords * groups; a.y = y;
+    a.sync = (unsigned*)state; a.status = status; a.B = B; a.H = H; a.T = T; a.groups = groups;
     static const int ablate = getenv("FC_ABLATE_LSTM") ? atoi(getenv("FC_ABLATE_LSTM")) : 0;
     a.ablate = ablate;
-    const int nbt = (B + 15) / 16;
-    dim3 grid(H / 4), block(256);
+    const int nbt = groups > 1 ? 1 : (B + 15) / 16;
+    dim3 grid(H / 4 * groups), block(256);
     // FC_LSTM_COOP=1: hipLaunchCooperativeKernel (the runtime validates the grid against the occupancy query at every launch,
     // +15-19 us of host time per launch); default: plain launch, residency validated once per engine by lstm_persist_supported()
     static const int coop = getenv("FC_LSTM_COOP") ? atoi(getenv("FC_LSTM_COOP")) : 0;
@@ -1879,7 +1888,8 @@ bool lstm_persist_supported(int B, int H, int L, int device) {
     if (L != 2 || (H != 1024 && H != 512) || B > 32) return false;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
-    const int nbt = (B + 15) / 16;
+    const int groups = lstm_persist_groups(B, H);
+    const int nbt = groups > 1 ? 1 : (B + 15) / 16;
     int per_cu = 0;
     hipError_t e = hipErrorInvalidValue;
     if (H == 1024 && nbt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16, 1>, 256, 0);
@@ -1887,7 +1897,7 @@ bool lstm_persist_supported(int B, int H, int L, int device) {
     else if (H == 512 && nbt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 1>, 256, 0);
     else if (H == 512 && nbt == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 2>, 256, 0);
     if (e != hipSuccess || per_cu < 1) return false;
-    return (long long)per_cu * prop.multiProcessorCount >= H / 4 && prop.multiProcessorCount >= H / 4;
+    return (long long)per_cu * prop.multiProcessorCount >= H / 4 * groups && prop.multiProcessorCount >= H / 4 * groups;
 }
 
 // =================================================================================================
