@@ -638,6 +638,13 @@ def test_freq_codec_batch_independence_and_determinism():
     for i in (0, 4):
         one = m.engine.encode_decode(wav[i:i + 1], 32)
         assert torch.equal(one["codes"][:, 0], a["codes"][:, i]) and torch.equal(one["recon"][0], a["recon"][i])
+    # 19 utterances: the H = 512 persistent LSTM then runs TWO batch tiles side by side on their own workgroups and barrier words
+    big = torch.cat([wav, audio(14, 24000, 78, "noise").cuda()], 0)
+    c = m.engine.encode_decode(big, 32)
+    assert torch.equal(c["codes"][:, :5], a["codes"]) and torch.equal(c["recon"][:5], a["recon"])
+    for i in (16, 18):
+        one = m.engine.encode_decode(big[i:i + 1], 32)
+        assert torch.equal(one["codes"][:, 0], c["codes"][:, i]) and torch.equal(one["recon"][0], c["recon"][i])
     m.engine.check_status()
 
 
