@@ -55,6 +55,7 @@ struct ConvLayer {
     int zpadL = -1, zpadR = -1; // explicit ZERO padding (the inverse-STFT GEMM); -1: reference padding rules
     bool synthetic = false;     // weights generated at finalize (DFT matrices), not part of the checkpoint
     int groups = 1;             // grouped Conv2d / ConvTranspose2d (conv_group_ratio > 0): dense block-diagonal weight at finalize
+    float* w_group = nullptr;   // grouped Conv2d with 2 / 4 channels per group: torch-layout weights for the direct kernel (freq_kernels.hip)
     bool force_plain = false;   // the slab of the fused-prologue variants does not fit (large strides): materialise the input first
     bool unsupported = false;   // no variant fits (stride > ~17): refused at fc_engine_create
     // GEMM view
@@ -678,6 +679,9 @@ int pack_conv2d(fc_engine* e, ConvLayer& L) {
                     wg[((size_t)m * (kf * C) + (size_t)a * C + ci) * kt + b] = W[(((size_t)m * cpg + cl) * kf + a) * kt + b];
         }
     if (pack_gemm(e, L, wg, Bv)) return 1;
+    // FC_GCONV=0: grouped layers stay on the block-diagonal dense GEMM (A/B aid)
+    static const int gconv_env = getenv("FC_GCONV") ? atoi(getenv("FC_GCONV")) : 1;
+    if (gconv_env && L.groups > 1 && L.dil == 1 && fc::gconv2d_ok(cpg, opg, kf, kt, L.stride) && upload(e, W, &L.w_group)) return 1;
     if (L.cout <= 4 && L.stride == 1 && L.sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && upload(e, wg, &L.w_plain)) return 1;      // [cout][kf * C][kt]: FMA kernel, no MFMA tile
     if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
     if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
@@ -1076,6 +1080,49 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
     const int Fo = (x0.F + tot_f - kf) / sf + 1;
     const ConvGeom g = conv_geom(L, x0.T);
     // layers with several M tiles: materialise the activated input once (as run_conv does), frequency-major with the same halo
+    if (L.w_group) {     // grouped conv with 2 / 4 channels per group: direct FMA kernel, prologue fused, no GEMM
+        Act2 o;
+        o.C = L.cout; o.F = Fo; o.T = g.Tout; o.halo = out_halo;
+        o.buf = cx.alloc<float>((size_t)B * (Fo + 2 * out_halo) * L.cout * g.Tout);
+        if (!cx.dry && (x0.halo < f_before || x0.halo < f_after || (x1.buf && x1.halo != x0.halo))) {
+            cx.err = 1; g_err = "internal: frequency halo too small for " + L.prefix; return o;
+        }
+        const long long rowsz = (long long)C * x0.T, orow = (long long)L.cout * g.Tout;
+        fc::GConvLaunch c;
+        c.src0 = cx.dry ? nullptr : x0.buf + (long long)(x0.halo - f_before) * rowsz; c.aff0 = x0.aff;
+        if (dual) { c.src1 = cx.dry ? nullptr : x1.buf + (long long)(x1.halo - f_before) * rowsz; c.aff1 = x1.aff; }
+        c.w = L.w_group; c.bias = L.bias;
+        c.out = cx.dry ? nullptr : o.buf + (long long)out_halo * orow;
+        c.B = B; c.C = C; c.M = L.cout; c.G = L.groups; c.Tin = x0.T; c.Tout = g.Tout; c.Fo = Fo; c.kf = kf; c.kt = L.k; c.sf = sf; c.st = L.stride;
+        c.padL = g.padL; c.padR = g.padR; c.elu = elu; c.alpha = e->arch.elu_alpha;
+        c.in_sB = (long long)(x0.F + 2 * x0.halo) * rowsz; c.in_sF = rowsz;
+        c.out_sB = (long long)(Fo + 2 * out_halo) * orow; c.out_sF = orow;
+        const int nblk = fc::gconv2d_nblk(g.Tout, Fo, L.groups);
+        c.partials = cx.alloc<double>((size_t)B * nblk * 2);
+        o.aff = cx.alloc<float>((size_t)B * L.cout * 2);
+        o.normed = true;
+        const double fl = 2.0 * B * Fo * (double)L.cout * (C / L.groups) * kf * L.k * g.Tout;
+        const double by = 4.0 * B * ((double)C * x0.F * x0.T * (dual ? 2 : 1) + (double)L.cout * Fo * g.Tout);
+        cx.conv_flops += fl; cx.conv_bytes += by;
+        cx.launches += out_halo ? 3 : 2; cx.conv_launches += 1;
+        if (cx.dry || cx.err) return o;
+        hipError_t er;
+        {
+            int cls = 0;
+            if (e->profiling) {
+                char nm[64];
+                snprintf(nm, sizeof(nm), "gconv2d_kernel<%d, %d, %d, %d, %d, %s>", C / L.groups, L.cout / L.groups, kf, L.k, L.stride, dual ? "true" : "false");
+                cls = e->prof_class(nm);
+            }
+            ProfSpan sp(e, cx, cls, fl, by);
+            er = fc::launch_gconv2d(c, cx.st);
+        }
+        if (er == hipSuccess)
+            er = fc::launch_gn_finalize(c.partials, nblk, (double)L.cout * Fo * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps, B, o.aff, cx.st);
+        if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fo, out_halo, L.cout, g.Tout, 0, cx.st);
+        if (er != hipSuccess) { cx.err = 1; g_err = "grouped 2-D conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); }
+        return o;
+    }
     // the few-output FMA kernel re-stages every input row for each of the kf output rows that read it: activate once instead
     static const int few_mat = getenv("FC_FEWOUT_MAT") ? atoi(getenv("FC_FEWOUT_MAT")) : 1;
     const bool few_out = few_mat && L.cout <= 4 && L.stride == 1 && sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && kf > 1;   // = pack_conv2d's w_plain rule

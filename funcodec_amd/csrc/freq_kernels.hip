@@ -11,6 +11,7 @@
 namespace fc {
 
 static inline __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // xp[b][j][m] = xpad[m*hop + j], xpad = reflect-padded (n_fft/2 each side, torch.stft center=True) utterance, zero beyond it.
 // (optionally / div[b]: the volume normalisation of _encode_frame, codec_freq.py:334-341)
@@ -155,6 +156,177 @@ hipError_t launch_istft_finish(const float* ypoly, const float* win2, int B, int
                                float* wav, hipStream_t st) {
     hipLaunchKernelGGL(istft_finish_kernel, dim3(cdiv(out_len, 256 * 4), B), dim3(256), 0, st, ypoly, win2, hop, n_fft, Mp, Tp, mul, out_len, wav);
     return hipGetLastError();
+}
+
+// =================================================================================================
+// Grouped Conv2d with a few channels per group (conv_group_ratio = 1: 2 or 4 in, 2 or 4 out; seanet_encoder.py:224,234,321):
+// 18 .. 64 multiply-adds per output -- nothing for the matrix cores, the layer is bound by HBM and the prologue's VALU work.
+// Direct form, no LDS slab, no barrier: one workgroup = (utterance, output frequency row, group, 1024 output columns); a lane owns 4
+// consecutive output columns of all OPG output channels of the group, loads the 3*ST + KT input columns it needs per (frequency tap,
+// input channel) with 16-byte pieces (straight-line, clamped; lanes at a padded edge gather by index), applies the prologue once per
+// loaded sample and accumulates OPG x 4 outputs.  The group's weights (<= 128 floats) sit in LDS and are read as broadcasts.
+// Same contract as the implicit-GEMM kernel: raw output + bias, fp64 (sum, sum of squares) partial per workgroup.
+// =================================================================================================
+struct GConvArgs {
+    const float *src0, *aff0, *src1, *aff1;      // [B][Fin + 2h][C][Tin] (pointing at the first row the fo = 0 window reads), affines [B][C][2]
+    const float *w, *bias;                       // torch layout [M][CPG][KF][KT], [M]
+    float* out;                                  // [B][Fo + 2ho][M][Tout], pointing at row ho
+    double* partials;                            // [B][Fo][G][ttiles][2]
+    int C, M, Tin, Tout, Fo, G, sf;
+    int padL, Leff, elu;
+    float alpha;
+    long long in_sB, in_sF, out_sB, out_sF;      // floats between utterances / frequency rows
+};
+
+template <int CPG, int OPG, int KF, int KT, int ST, bool DUAL>
+__global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int NE = 3 * ST + KT;              // input columns behind 4 outputs
+    constexpr int NV = (NE + 3) / 4;             // 16-byte pieces
+    constexpr int NW = OPG * CPG * KF * KT;
+    __shared__ float wsh[NW];
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x, g = blockIdx.y, z = blockIdx.z;
+    const int b = z / p.Fo, fo = z - b * p.Fo;
+    for (int i = tid; i < NW; i += 256) wsh[i] = p.w[(size_t)g * NW + i];
+    __syncthreads();
+    const int n0 = tile * 1024 + 4 * tid;        // first output column of this lane
+    const int q0 = n0 * ST - p.padL;             // source index (before reflection) of its first input column
+    const bool vec_ok = q0 >= 0 && q0 + 4 * NV <= p.Tin;
+    const int qsafe = q0 < 0 ? 0 : (q0 + 4 * NV <= p.Tin ? q0 : (p.Tin >= 4 * NV ? p.Tin - 4 * NV : 0));
+    int esrc[NE]; unsigned emask = 0;
+    {
+        const int refl = 2 * (p.Leff - 1);
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int q = q0 + j;
+            int src = q < 0 ? -q : q;
+            src = src >= p.Leff ? refl - src : src;
+            const bool ok = q >= -p.padL && src >= 0 && src < p.Tin;
+            esrc[j] = ok ? src : 0;
+            emask |= (ok ? 1u : 0u) << j;
+        }
+    }
+    const unsigned vmask = vec_ok ? (1u << NE) - 1u : emask;
+    const size_t in_base = (size_t)b * p.in_sB + (size_t)(fo * p.sf) * p.in_sF + (size_t)(g * CPG) * p.Tin;
+    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)b * p.C + g * CPG : nullptr;
+    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)b * p.C + g * CPG : nullptr;
+    float acc[OPG][4];
+#pragma unroll
+    for (int o = 0; o < OPG; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+    const bool live = n0 < p.Tout;
+    if (live) {
+#pragma unroll
+        for (int a = 0; a < KF; ++a) {
+            f32x4 r0[CPG][NV], r1[DUAL ? CPG : 1][NV];
+#pragma unroll
+            for (int ci = 0; ci < CPG; ++ci) {   // straight-line loads of the whole frequency tap
+                const size_t off = in_base + (size_t)a * p.in_sF + (size_t)ci * p.Tin + qsafe;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    r0[ci][v] = *(const f32x4u*)(p.src0 + off + 4 * v);
+                    if (DUAL) r1[ci][v] = *(const f32x4u*)(p.src1 + off + 4 * v);
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < CPG; ++ci) {
+                const float2 A = a0 ? a0[ci] : make_float2(1.f, 0.f);
+                const float2 A1 = a1 ? a1[ci] : make_float2(1.f, 0.f);
+                float x[NE];
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    float v0 = r0[ci][j >> 2][j & 3], v1 = DUAL ? r1[ci][j >> 2][j & 3] : 0.f;
+                    if (!vec_ok) {               // padded edge: gather by index
+                        const size_t off = in_base + (size_t)a * p.in_sF + (size_t)ci * p.Tin + esrc[j];
+                        v0 = p.src0[off];
+                        if (DUAL) v1 = p.src1[off];
+                    }
+                    float v = fmaf(v0, A.x, A.y);
+                    if (DUAL) v = v + fmaf(v1, A1.x, A1.y);
+                    if (p.elu) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f); v = v > 0.f ? v : fmaf(e, p.alpha, -p.alpha); }
+                    x[j] = ((vmask >> j) & 1u) ? v : 0.f;
+                }
+#pragma unroll
+                for (int o = 0; o < OPG; ++o)
+#pragma unroll
+                    for (int kk = 0; kk < KT; ++kk) {
+                        const float wv = wsh[((o * CPG + ci) * KF + a) * KT + kk];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(wv, x[j * ST + kk], acc[o][j]);
+                    }
+            }
+        }
+    }
+    float s1v = 0.f, s2v = 0.f;
+#pragma unroll
+    for (int o = 0; o < OPG; ++o) {
+        const int m = g * OPG + o;
+        const float bm = p.bias[m];
+        float ov[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ov[j] = acc[o][j] + bm;
+            if (live && n0 + j < p.Tout) { s1v += ov[j]; s2v = fmaf(ov[j], ov[j], s2v); }
+        }
+        if (!live) continue;
+        float* orow = p.out + (size_t)b * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.Tout + n0;
+        if (n0 + 3 < p.Tout) *(f32x4u*)orow = (f32x4){ov[0], ov[1], ov[2], ov[3]};
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (n0 + j < p.Tout) orow[j] = ov[j];
+    }
+    if (p.partials) {
+        double d1 = (double)s1v, d2 = (double)s2v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            d1 += __shfl_xor(d1, off, 64);
+            d2 += __shfl_xor(d2, off, 64);
+        }
+        if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t slot = ((((size_t)b * p.Fo + fo) * p.G + g) * gridDim.x + tile) * 2;
+            p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+    }
+}
+
+bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st) {
+    const bool shape = (kf == 1 && kt == 1 && st == 1) || (kf == 3 && kt == 3 && st == 1) || (kf == 8 && kt == 2 && st == 1) ||
+                       (kf == 8 && kt == 4 && st == 2);
+    const bool chans = (cpg == 2 && opg == 2) || (cpg == 4 && opg == 2) || (cpg == 2 && opg == 4);
+    return shape && chans;
+}
+int gconv2d_nblk(int Tout, int Fo, int G) { return cdiv(Tout, 1024) * Fo * G; }
+
+hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
+    GConvArgs a;
+    a.src0 = c.src0; a.aff0 = c.aff0; a.src1 = c.src1; a.aff1 = c.aff1; a.w = c.w; a.bias = c.bias; a.out = c.out; a.partials = c.partials;
+    a.C = c.C; a.M = c.M; a.Tin = c.Tin; a.Tout = c.Tout; a.Fo = c.Fo; a.G = c.G; a.sf = c.sf;
+    a.padL = c.padL;
+    const int maxpad = c.padL > c.padR ? c.padL : c.padR;
+    a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
+    a.elu = c.elu; a.alpha = c.alpha;
+    a.in_sB = c.in_sB; a.in_sF = c.in_sF; a.out_sB = c.out_sB; a.out_sF = c.out_sF;
+    if ((long long)c.B * c.Fo > 65535 || c.G > 65535) return hipErrorInvalidValue;
+    dim3 grid(cdiv(c.Tout, 1024), c.G, c.B * c.Fo), block(256);
+    const int cpg = c.C / c.G, opg = c.M / c.G;
+    const bool dual = c.src1 != nullptr;
+#define FC_GC(CP, OP, KF_, KT_, ST_)                                                                                         \
+    if (cpg == CP && opg == OP && c.kf == KF_ && c.kt == KT_ && c.st == ST_) {                                               \
+        if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true>), grid, block, 0, st, a);                   \
+        else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false>), grid, block, 0, st, a);                       \
+        return hipGetLastError();                                                                                            \
+    }
+#define FC_GCS(KF_, KT_, ST_) FC_GC(2, 2, KF_, KT_, ST_) FC_GC(4, 2, KF_, KT_, ST_) FC_GC(2, 4, KF_, KT_, ST_)
+    FC_GCS(1, 1, 1) FC_GCS(3, 3, 1) FC_GCS(8, 2, 1) FC_GCS(8, 4, 2)
+#undef FC_GCS
+#undef FC_GC
+    return hipErrorInvalidValue;
 }
 
 }  // namespace fc

@@ -73,6 +73,19 @@ int reshead_ntiles(int T);
 hipError_t launch_reshead(const ResHeadLaunch& c, hipStream_t st);
 
 // ---- STFT-domain codec (freq_kernels.hip): frequency-major 2-D activations [B][F + 2*halo][C][T]
+// grouped Conv2d with 2 / 4 channels per group (freq_kernels.hip): direct FMA kernel instead of a block-diagonal dense GEMM
+struct GConvLaunch {
+    const float *src0 = nullptr, *aff0 = nullptr, *src1 = nullptr, *aff1 = nullptr;   // sources at the first row the fo = 0 window reads
+    const float *w = nullptr, *bias = nullptr;                                         // [M][C / G][kf][kt] (torch), [M]
+    float* out = nullptr;                                                              // at frequency row `halo`
+    double* partials = nullptr;                                                        // [B][gconv2d_nblk()][2]
+    int B = 0, C = 0, M = 0, G = 1, Tin = 0, Tout = 0, Fo = 0, kf = 1, kt = 1, sf = 1, st = 1, padL = 0, padR = 0, elu = 0;
+    float alpha = 1.f;
+    long long in_sB = 0, in_sF = 0, out_sB = 0, out_sF = 0;
+};
+bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st);
+int gconv2d_nblk(int Tout, int Fo, int G);
+hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st);
 hipError_t launch_polyphase_in(const float* wav, const float* div, int B, int T, int hop, int n_fft, int Mp, float* xp, hipStream_t st);
 hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, float* feats, hipStream_t st);
 hipError_t launch_halo_rows(float* buf, int B, int F, int halo, int C, int T, int zero, hipStream_t st);
