@@ -716,6 +716,10 @@ int pack_convtr2d(fc_engine* e, const ConvLayer& S, std::vector<ConvLayer>& phas
         if (pack_gemm(e, L, wg, bg)) return 1;
     }
     ConvLayer& L0 = phases[0];
+    static const int gconv_env = getenv("FC_GCONV") ? atoi(getenv("FC_GCONV")) : 1;
+    if (gconv_env && S.groups > 1 && fc::gconvtr2d_ok(cpg, opg, r)) {          // direct kernel: torch-layout weights + plain bias
+        if (upload(e, W, &L0.w_group) || upload(e, Bv, &L0.w_plain)) return 1;
+    }
     if (upload(e, e->host[S.prefix + ".norm.weight"].data, &L0.gamma)) return 1;
     if (upload(e, e->host[S.prefix + ".norm.bias"].data, &L0.beta)) return 1;
     return 0;
@@ -1225,7 +1229,8 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
     c0.M = phases[0].M; c0.BM = phases[0].BM; c0.BN = phases[0].BN; c0.Tout = T + 1;
     const int nblk = fc::conv_nblk(c0);
     const long long part_row = (long long)(Fin + 1) * nblk;
-    double* partials = cx.alloc<double>((size_t)B * sf * part_row * 2);
+    const int gnblk = fc::gconvtr2d_nblk(T, st, Fin, sf);     // partial slots of the grouped direct kernel (same buffer)
+    double* partials = cx.alloc<double>((size_t)B * std::max<long long>(sf * part_row, gnblk) * 2);
     o.aff = cx.alloc<float>((size_t)B * cout * 2);
     o.normed = true;
     const double fl = 2.0 * B * (Fin + 1) * (double)phases[0].M * 2 * C * 2 * (T + 1) * sf;
@@ -1236,6 +1241,26 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
     hipError_t er = fc::launch_combine2d(x0.buf, x0.aff, x0.halo, x1 ? x1->buf : nullptr, x1 ? x1->aff : nullptr, x1 ? x1->halo : 0, 1,
                                          e->arch.elu_alpha, B, Fin, C, T, z.buf, 1, cx.st);
     if (er == hipSuccess) er = fc::launch_halo_rows(z.buf, B, Fin, 1, C, T, 1, cx.st);
+    if (phases[0].w_group) {          // grouped (2 in / 1 out channel per group): one direct launch over the untrimmed output
+        double* gpart = partials;
+        if (er == hipSuccess) {
+            int cls = 0;
+            if (e->profiling) {
+                char nm[64];
+                snprintf(nm, sizeof(nm), "gconvtr2d_kernel<%d>", st);
+                cls = e->prof_class(nm);
+            }
+            ProfSpan sp(e, cx, cls, 2.0 * B * (double)cout * 8 * (Fin + 1) * sf * (T + 1) * st, by);
+            er = fc::launch_gconvtr2d(z.buf, phases[0].w_group, phases[0].w_plain, o.buf + (long long)out_halo * orow, gpart, B, C, cout, Fin, T, sf, st,
+                                      f_l, Fout, st - st / 2, g.Tout, (long long)(Fout + 2 * out_halo) * orow, cx.st);
+        }
+        if (er == hipSuccess)
+            er = fc::launch_gn_finalize(gpart, gnblk, (double)cout * (Fin + 1) * sf * g.count_T, phases[0].gamma, phases[0].beta, cout, e->arch.gn_eps,
+                                        B, o.aff, cx.st);
+        if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fout, out_halo, cout, g.Tout, 0, cx.st);
+        if (er != hipSuccess) { cx.err = 1; g_err = "grouped 2-D transposed conv launch failed (" + S.prefix + "): " + hipGetErrorString(er); }
+        return o;
+    }
     for (int p = 0; p < sf && er == hipSuccess; ++p) {
         const ConvLayer& L = phases[p];
         fc::ConvLaunch c;

@@ -329,4 +329,117 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     return hipErrorInvalidValue;
 }
 
+// =================================================================================================
+// Grouped ConvTranspose2d((2 fr, 2 tr), stride (fr, tr)) with 2 input channels and 1 output channel per group (tr_conv_group_ratio = 1,
+// seanet_decoder.py:324): 8 multiply-adds per output, the output tensor is fr * tr / 2 times the input -- a pure store-bound layer.
+// Output-centric direct form over the UNTRIMMED output (GroupNorm statistics cover it, conv.py:430-447): row fu = q fr + p reads input rows
+// q (tap p) and q - 1 (tap p + fr) of the materialised ELU'd input z (one zero row above and below), column tu = i tr + ph reads
+// columns i (tap ph) and i - 1 (tap ph + tr); a lane owns 4 consecutive columns, one workgroup = (utterance, untrimmed row, 1024
+// columns) x all output channels in turn (the input rows stay in L1 / L2 across them).  Stores only inside the trimmed window.
+// =================================================================================================
+struct GConvTrArgs {
+    const float* z;          // [B][Fin + 2][C][Tin], rows -1 and Fin zero
+    const float *w, *bias;   // torch layout [C][1][2 fr][2 tr], [cout]
+    float* out;              // [B][Fout + 2ho][cout][Tout], pointing at row ho
+    double* partials;        // [B][(Fin + 1) fr][ttiles][2]
+    int C, cout, Fin, Tin, fr, f_l, Fout, trimL, Tout;
+    long long out_sB;
+};
+
+template <int TR>
+__global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int NI = 4 / TR + 1;                   // input columns behind 4 untrimmed output columns
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x, fu = blockIdx.y, b = blockIdx.z;
+    const int q = fu / p.fr, ph_f = fu - q * p.fr;
+    const int tu0 = tile * 1024 + 4 * tid;           // first untrimmed output column of this lane (a multiple of 4, hence of TR)
+    const int Tu = (p.Tin + 1) * TR;
+    const bool live = tu0 < Tu;
+    const int i0 = tu0 / TR;                         // input column of tap s = 0 for the lane's first output
+    const int fo = fu - p.f_l;
+    const bool row_ok = fo >= 0 && fo < p.Fout;
+    const size_t rowsz = (size_t)p.C * p.Tin;
+    const float* zq = p.z + ((size_t)b * (p.Fin + 2) + (q + 1)) * rowsz;       // input row q (row Fin = the zero halo)
+    const float* zm = zq - rowsz;                                               // input row q - 1 (row -1 = the zero halo)
+    const int kt = 2 * TR, kf = 2 * p.fr;
+    float s1v = 0.f, s2v = 0.f;
+    if (live) {
+        for (int co = 0; co < p.cout; ++co) {
+            float x[2][2][NI];                       // [ci][row q / q - 1][columns i0 - 1 .. i0 + NI - 2]
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float* row = (r ? zm : zq) + (size_t)(2 * co + ci) * p.Tin;
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int t = i0 - 1 + j;
+                        x[ci][r][j] = (t >= 0 && t < p.Tin) ? row[t] : 0.f;
+                    }
+                }
+            float acc[4];
+            const float bm = p.bias[co];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float* wr = p.w + ((size_t)(2 * co + ci) * kf + ph_f + r * p.fr) * kt;     // uniform: scalar loads
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ph = j % TR, ii = j / TR;          // output column tu0 + j = (i0 + ii) TR + ph
+                        acc[j] = fmaf(wr[ph], x[ci][r][ii + 1], acc[j]);           // tap s = 0: column i0 + ii
+                        acc[j] = fmaf(wr[ph + TR], x[ci][r][ii], acc[j]);          // tap s = 1: column i0 + ii - 1
+                    }
+                }
+            float ov[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ov[j] = acc[j] + bm;
+                if (tu0 + j < Tu) { s1v += ov[j]; s2v = fmaf(ov[j], ov[j], s2v); }
+            }
+            if (row_ok) {
+                float* orow = p.out + (size_t)b * p.out_sB + ((size_t)fo * p.cout + co) * p.Tout;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int to = tu0 + j - p.trimL;
+                    if (to >= 0 && to < p.Tout) orow[to] = ov[j];
+                }
+            }
+        }
+    }
+    double d1 = (double)s1v, d2 = (double)s2v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        d1 += __shfl_xor(d1, off, 64);
+        d2 += __shfl_xor(d2, off, 64);
+    }
+    if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t slot = (((size_t)b * gridDim.y + fu) * gridDim.x + tile) * 2;
+        p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+}
+
+bool gconvtr2d_ok(int cpg, int opg, int tr) { return cpg == 2 && opg == 1 && (tr == 1 || tr == 2); }
+int gconvtr2d_nblk(int Tin, int tr, int Fin, int fr) { return cdiv((Tin + 1) * tr, 1024) * (Fin + 1) * fr; }
+
+hipError_t launch_gconvtr2d(const float* z, const float* w, const float* bias, float* out, double* partials, int B, int C, int cout, int Fin,
+                            int Tin, int fr, int tr, int f_l, int Fout, int trimL, int Tout, long long out_sB, hipStream_t st) {
+    GConvTrArgs a;
+    a.z = z; a.w = w; a.bias = bias; a.out = out; a.partials = partials;
+    a.C = C; a.cout = cout; a.Fin = Fin; a.Tin = Tin; a.fr = fr; a.f_l = f_l; a.Fout = Fout; a.trimL = trimL; a.Tout = Tout; a.out_sB = out_sB;
+    if ((Fin + 1) * fr > 65535 || B > 65535) return hipErrorInvalidValue;
+    dim3 grid(cdiv((Tin + 1) * tr, 1024), (Fin + 1) * fr, B), block(256);
+    if (tr == 1) hipLaunchKernelGGL(gconvtr2d_kernel<1>, grid, block, 0, st, a);
+    else if (tr == 2) hipLaunchKernelGGL(gconvtr2d_kernel<2>, grid, block, 0, st, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 }  // namespace fc

@@ -86,6 +86,11 @@ struct GConvLaunch {
 bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st);
 int gconv2d_nblk(int Tout, int Fo, int G);
 hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st);
+// grouped ConvTranspose2d((2 fr, 2 tr), stride (fr, tr)), 2 input / 1 output channel per group, over the materialised ELU'd input z
+bool gconvtr2d_ok(int cpg, int opg, int tr);
+int gconvtr2d_nblk(int Tin, int tr, int Fin, int fr);
+hipError_t launch_gconvtr2d(const float* z, const float* w, const float* bias, float* out, double* partials, int B, int C, int cout, int Fin,
+                            int Tin, int fr, int tr, int f_l, int Fout, int trimL, int Tout, long long out_sB, hipStream_t st);
 hipError_t launch_polyphase_in(const float* wav, const float* div, int B, int T, int hop, int n_fft, int Mp, float* xp, hipStream_t st);
 hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, float* feats, hipStream_t st);
 hipError_t launch_halo_rows(float* buf, int B, int F, int halo, int C, int T, int zero, hipStream_t st);
