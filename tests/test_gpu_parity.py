@@ -427,6 +427,59 @@ def test_lstm_against_torch_cpu(cfg_name, seed, B, T):
         assert (got - ref).abs().max().item() < 1e-5, p
 
 
+# ---- long recurrences and degenerate signals ---------------------------------------------------------------------------------------
+def test_long_utterance_against_oracle():
+    """60 s in one utterance (ds320: a 3 000-step LSTM recurrence on hardware exp2 / rcp gates, 3 750 tiles on the thin layers, 32-bit
+    offsets): the indices still match the CPU path (any flip proven a tie) and the waveform stays within 1e-4 RMS."""
+    m, orc = engine_for("ds320", 0), oracle_for("ds320", 0)
+    wav = audio(1, 16000 * 60, 7, "tones")
+    o = orc.inference(wav, bit_width=None, use_scale=True)
+    r = m.engine.encode_decode(wav.cuda(), 32)
+    m.engine.check_status()
+    assert r["codes"].shape[2] == 3000
+    rep = index_report(r["codes"], o["code_indices"][0])
+    if rep["frames_bad"]:
+        proofs = _assert_flips_are_near_ties(orc.embed, o["encoder_out"], o["code_indices"][0], r["codes"], max_frames=3)
+        cut = _prefix_before([p[1] for p in proofs], 3000, m.engine.hop_length, 0)
+        assert cut is None or rms(r["recon"][0, :, :cut], o["recon_speech"][0, :, :cut]) < WAV_RMS_TOL
+    else:
+        assert rms(r["recon"], o["recon_speech"]) < WAV_RMS_TOL
+
+
+@pytest.mark.parametrize("cfg_name,seed", [("ds320", 0), ("tinywn", 9), ("tinyfreq", 3)])
+def test_degenerate_signals_against_oracle(cfg_name, seed):
+    """Digital silence (volume 0 -> scale 1e-8, GroupNorm over constant tensors), a full-scale clipped square wave, a DC offset and a
+    single click: the reference path's behaviour on them is reproduced (the reference has no special cases for them either)."""
+    freq = cfg_name.startswith("tinyfreq")
+    if freq:
+        from helpers import freq_engine_for, freq_oracle_for
+        m, orc = freq_engine_for(cfg_name, seed), freq_oracle_for(cfg_name, seed)
+    else:
+        m, orc = engine_for(cfg_name, seed), oracle_for(cfg_name, seed)
+    T = 4000
+    t = torch.arange(T, dtype=torch.float32)
+    click = torch.zeros(T)
+    click[1234] = 0.9
+    wav = torch.stack([torch.zeros(T), torch.sign(torch.sin(2 * np.pi * 220.0 * t / 16000.0)), torch.full((T,), 0.5), click])
+    if freq:
+        # STFT-domain codec: log|X| and X / |X| of bins that are ANALYTICALLY zero (a pure DC offset, the even harmonics of a square wave)
+        # are functions of the transform's rounding noise, which no two FFT implementations share -- keep the rows whose spectrum is
+        # either exactly zero (silence: the clamp decides) or nowhere zero (a click)
+        wav = torch.stack([wav[0], wav[3], wav[0], wav[3]])
+    o = orc.inference(wav, bit_width=None, use_scale=True)
+    ret = m.inference(wav.cuda().unsqueeze(1), bit_width=None, use_scale=True)
+    m.engine.check_status()
+    assert bool(torch.isfinite(ret["recon_speech"]).all()) == bool(torch.isfinite(o["recon_speech"]).all())
+    for b in range(4):                        # per utterance: a degenerate row may sit on exact ties of its own
+        rep = index_report(ret["code_indices"][0][:, b:b + 1], o["code_indices"][0][:, b:b + 1])
+        ref_rms = max(float(o["recon_speech"][b].double().pow(2).mean().sqrt()), 1e-3)
+        if rep["frames_bad"] == 0:
+            assert rms(ret["recon_speech"][b], o["recon_speech"][b]) < 1e-3 * ref_rms, b
+        else:
+            _assert_flips_are_near_ties(orc.embed, o["encoder_out"][b:b + 1], o["code_indices"][0][:, b:b + 1], ret["code_indices"][0][:, b:b + 1],
+                                        max_frames=max(2, rep["frames"] // 4))
+
+
 # ---- pseudo-random architectures (config.py::fuzz_recipe_config; five more of them have goldens from the real reference above) -------
 @pytest.mark.parametrize("seed", [1, 4, 5, 6, 7, 8, 9, 12, 13, 14])
 def test_random_architectures_against_oracle(seed):
