@@ -36,7 +36,7 @@ CONFIG = os.environ.get("FC_BENCH_CONFIG", "ds640")   # the contract metric is d
 PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix (= vector) peak
 PEAK_HBM_TBS = 8.0
 RIDGE = PEAK_F32_TFLOPS / PEAK_HBM_TBS      # FLOP per byte above which the fp32 roof is the tighter one
-CONV_CLASSES = ("conv_", "reshead_")        # kernel classes of the Conv1d / ConvTranspose1d layers (fc_engine_profile names)
+CONV_CLASSES = ("conv_", "reshead_", "gconv")   # kernel classes of the conv / transposed-conv layers (fc_engine_profile names)
 
 
 def physical_cores() -> int:
