@@ -188,18 +188,39 @@ def inference_modelscope(
         result_list = []
         run_mod = kwargs.get("run_mod", "inference")
         hop = my_model.model.quantizer.encoder_hop_length
-        for keys, batch in loader:
-            if should_resample:                                                 # reference :318-322 (lengths stay in file samples)
-                batch["speech"] = fio.resample(batch["speech"], file_sr, sampling_rate)
-            speech_length = batch.pop("speech_lengths")
-            bw = param_dict["bit_width"] if param_dict is not None and "bit_width" in param_dict else bit_width
-            token_id, token_emb, recon_speech, sub_quants = my_model(**batch, need_recon=True, bit_width=bw,
-                                                                     use_scale=use_scale, run_mod=run_mod)
-            # device-side failures cannot raise in-line like the reference's F.embedding / asserts do: synchronise and ask the
-            # engine before anything of this batch is written (corrupt token files, LSTM barrier timeout)
-            my_model.model.engine.check_status(sync=True)
-            if should_resample and recon_speech is not None:                    # reference :352-356
-                recon_speech = fio.resample(recon_speech, sampling_rate, file_sr)
+
+        # Host pipeline around the engine (the engine does 160 audio-seconds in 17 ms; reading / padding the next batch and writing
+        # the previous one must not sit on its critical path): a loader thread keeps up to 3 batches ready, each finished batch is
+        # copied to the host ONCE per output and handed to a small writer pool (wav files: the library's C writer, GIL released);
+        # codecs.txt lines and ark entries are appended by this thread in batch order.
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        def _prefetch(it, depth=3):
+            q: "queue.Queue" = queue.Queue(maxsize=depth)
+            end = object()
+
+            def run():
+                try:
+                    for item in it:
+                        q.put(item)
+                    q.put(end)
+                except BaseException as ex:          # noqa: BLE001 -- re-raised in the consumer
+                    q.put(ex)
+
+            threading.Thread(target=run, daemon=True).start()
+            while True:
+                item = q.get()
+                if item is end:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+
+        def _write_batch(keys, speech_length, recon_host, tok_host):
+            """wav files of one batch + its codecs.txt lines (returned, written in order by the caller)."""
+            lines, results = [], []
             for i, key in enumerate(keys):
                 if run_mod in ["decode", "decode_emb"]:
                     codec_len = int(speech_length[i])
@@ -207,22 +228,57 @@ def inference_modelscope(
                 else:
                     ilen = int(speech_length[i])
                     codec_len = int(math.ceil(ilen / hop))
-                recon_wav = recon_speech[i].cpu()[:, :ilen] if recon_speech is not None else None
+                recon_wav = recon_host[i][:, :ilen] if recon_host is not None else None
                 if output_path is None:
-                    result_list.append({"key": key, "value": recon_wav})
+                    results.append({"key": key, "value": recon_wav})
                     continue
                 if recon_wav is not None:
                     save_audio(recon_wav, os.path.join(output_path, key + ".wav" if not key.endswith(".wav") else key),
                                rescale=True, sample_rate=file_sr if should_resample else sampling_rate)
-                if token_id is not None and indices_writer is not None:
-                    if ark_indices:                                            # [T, n_q] float matrix (reference :292-294)
-                        mats = [x[:, i, :codec_len].cpu().float().numpy().T for x in token_id]
-                        indices_writer(key, np.concatenate(mats, axis=0))
-                    else:
-                        indices_writer.write(fio.format_codec_line(key, token_id, i, codec_len))
-                if sub_quants is not None and sub_quants_writer is not None:     # [T, n_q*D] (reference :301-311)
-                    sq = torch.cat(sub_quants, dim=-1).permute(1, 3, 0, 2)[i][:codec_len]
-                    sub_quants_writer(key, sq.reshape(sq.shape[0], -1).cpu().numpy())
+                if tok_host is not None and indices_writer is not None and not ark_indices:
+                    lines.append(fio.format_codec_line(key, tok_host, i, codec_len))
+            return lines, results
+
+        def _drain(job):
+            keys, speech_length, tok_host, sq_host, fut = job
+            lines, results = fut.result()
+            result_list.extend(results)
+            if lines:
+                indices_writer.write("".join(lines))
+            for i, key in enumerate(keys):               # Kaldi ark writers keep file offsets: sequential, in order
+                codec_len = int(speech_length[i]) if run_mod in ["decode", "decode_emb"] else int(math.ceil(int(speech_length[i]) / hop))
+                if tok_host is not None and indices_writer is not None and ark_indices and output_path is not None:   # [T, n_q] (reference :292-294)
+                    mats = [x[:, i, :codec_len].float().numpy().T for x in tok_host]
+                    indices_writer(key, np.concatenate(mats, axis=0))
+                if sq_host is not None and sub_quants_writer is not None and output_path is not None:                # [T, n_q*D] (reference :301-311)
+                    sq = torch.cat(sq_host, dim=-1).permute(1, 3, 0, 2)[i][:codec_len]
+                    sub_quants_writer(key, sq.reshape(sq.shape[0], -1).numpy())
+
+        pool = ThreadPoolExecutor(max_workers=4)
+        jobs = []
+        try:
+            for keys, batch in _prefetch(loader):
+                if should_resample:                                                 # reference :318-322 (lengths stay in file samples)
+                    batch["speech"] = fio.resample(batch["speech"], file_sr, sampling_rate)
+                speech_length = batch.pop("speech_lengths")
+                bw = param_dict["bit_width"] if param_dict is not None and "bit_width" in param_dict else bit_width
+                token_id, token_emb, recon_speech, sub_quants = my_model(**batch, need_recon=True, bit_width=bw,
+                                                                         use_scale=use_scale, run_mod=run_mod)
+                # device-side failures cannot raise in-line like the reference's F.embedding / asserts do: synchronise and ask the
+                # engine before anything of this batch is written (corrupt token files, LSTM barrier timeout)
+                my_model.model.engine.check_status(sync=True)
+                if should_resample and recon_speech is not None:                    # reference :352-356
+                    recon_speech = fio.resample(recon_speech, sampling_rate, file_sr)
+                recon_host = recon_speech.cpu() if recon_speech is not None else None
+                tok_host = [x.cpu().contiguous() for x in token_id] if (token_id is not None and indices_writer is not None) else None
+                sq_host = [x.cpu() for x in sub_quants] if (sub_quants is not None and sub_quants_writer is not None) else None
+                jobs.append((keys, speech_length, tok_host, sq_host, pool.submit(_write_batch, keys, speech_length, recon_host, tok_host)))
+                while len(jobs) > 3:                                                # bounds the host memory held by queued batches
+                    _drain(jobs.pop(0))
+            while jobs:
+                _drain(jobs.pop(0))
+        finally:
+            pool.shutdown(wait=True)
         for w in (indices_writer, sub_quants_writer):
             if w is not None:
                 w.close()

@@ -1873,6 +1873,62 @@ int fc_overlap_add(const float* const* frames, const int* lens, int n_frames, in
     return 0;
 }
 
+size_t fc_codec_json_bound(int n_q, int len) { return (size_t)(n_q > 0 ? n_q : 0) * ((size_t)(len > 0 ? len : 0) * 22 + 4) + 8; }
+
+int fc_format_codec_json(const int64_t* codes, int n_q, int B, int T, int b, int len, char* out, size_t cap, size_t* written) {
+    if (!codes || !out || !written || n_q <= 0 || B <= 0 || T <= 0 || b < 0 || b >= B || len < 0 || len > T) return fail("bad argument");
+    if (cap < fc_codec_json_bound(n_q, len)) return fail("output buffer too small (fc_codec_json_bound)");
+    char* p = out;
+    *p++ = '['; *p++ = '[';
+    for (int q = 0; q < n_q; ++q) {
+        if (q) { *p++ = ','; *p++ = ' '; }
+        *p++ = '[';
+        const int64_t* row = codes + ((size_t)q * B + b) * T;
+        for (int t = 0; t < len; ++t) {
+            if (t) { *p++ = ','; *p++ = ' '; }
+            long long v = row[t];
+            if (v < 0) { *p++ = '-'; v = -v; }
+            char tmp[24];
+            int n = 0;
+            do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (n) *p++ = tmp[--n];
+        }
+        *p++ = ']';
+    }
+    *p++ = ']'; *p++ = ']';
+    *written = (size_t)(p - out);
+    return 0;
+}
+
+int fc_write_wav_pcm16(const char* path, const float* wav, int n, int sample_rate, int rescale) {
+    if (!path || !wav || n < 0 || sample_rate <= 0) return fail("bad argument");
+    const float limit = 0.99f;
+    float mx = 0.f;
+    for (int i = 0; i < n; ++i) { const float a = fabsf(wav[i]); if (a > mx) mx = a; }
+    // torch: wav * min(limit / mx, 1) (python float min -> float32 multiply), else clamp(-limit, limit)
+    float mul = 1.f;
+    if (rescale && mx > 0.f) { const float r = limit / mx; mul = r < 1.f ? r : 1.f; }
+    std::vector<int16_t> pcm((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        float v = wav[i];
+        if (rescale) v = v * mul;
+        else v = v < -limit ? -limit : (v > limit ? limit : v);
+        float s = nearbyintf(v * 32768.0f);            // torch.round: half to even
+        s = s < -32768.f ? -32768.f : (s > 32767.f ? 32767.f : s);
+        pcm[i] = (int16_t)s;
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(std::string("cannot open ") + path);
+    const uint32_t data_bytes = (uint32_t)n * 2u, riff = 36u + data_bytes, fmt_len = 16u, sr = (uint32_t)sample_rate, byte_rate = sr * 2u;
+    const uint16_t pcm_tag = 1, ch = 1, align = 2, bits = 16;
+    bool ok = fwrite("RIFF", 1, 4, f) == 4 && fwrite(&riff, 4, 1, f) == 1 && fwrite("WAVEfmt ", 1, 8, f) == 8 && fwrite(&fmt_len, 4, 1, f) == 1 &&
+              fwrite(&pcm_tag, 2, 1, f) == 1 && fwrite(&ch, 2, 1, f) == 1 && fwrite(&sr, 4, 1, f) == 1 && fwrite(&byte_rate, 4, 1, f) == 1 &&
+              fwrite(&align, 2, 1, f) == 1 && fwrite(&bits, 2, 1, f) == 1 && fwrite("data", 1, 4, f) == 4 && fwrite(&data_bytes, 4, 1, f) == 1 &&
+              (n == 0 || fwrite(pcm.data(), 2, (size_t)n, f) == (size_t)n);
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : fail(std::string("short write to ") + path);
+}
+
 int fc_debug_timeline(unsigned long long* dst) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(fc::debug_timeline(dst));

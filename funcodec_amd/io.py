@@ -15,8 +15,25 @@ import struct
 import wave
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
+import ctypes as C
+
 import numpy as np
 import torch
+
+_NATIVE = False
+
+
+def _native():
+    """The engine library's host-side wire-format helpers (fc_format_codec_json, fc_write_wav_pcm16), or None when the library has not
+    been built (pure-Python formatting then; the compute path has no such fallback)."""
+    global _NATIVE
+    if _NATIVE is False:
+        try:
+            from . import _lib
+            _NATIVE = _lib.load()
+        except Exception:                      # noqa: BLE001 -- I/O helpers only
+            _NATIVE = None
+    return _NATIVE
 
 
 # ------------------------------------------------------------------------------------------------
@@ -24,6 +41,16 @@ import torch
 # ------------------------------------------------------------------------------------------------
 def read_wav(path: str) -> Tuple[np.ndarray, int]:
     """First channel of a RIFF wav as float32 (PCM16/32 scaled by 2^15 / 2^31, float passed through)."""
+    try:                                   # plain PCM: the stdlib reader is ~25x faster than scipy's chunk walker (0.13 vs 3.5 ms per 10 s)
+        with wave.open(path, "rb") as f:
+            ch, width, sr, n = f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()
+            if width in (2, 4):
+                data = np.frombuffer(f.readframes(n), dtype=np.int16 if width == 2 else np.int32).reshape(-1, ch)[:, 0]
+                scale = 32768.0 if width == 2 else 2147483648.0
+                x = data.astype(np.float32) / np.float32(scale) if width == 2 else (data.astype(np.float64) / scale).astype(np.float32)
+                return np.ascontiguousarray(x), int(sr)
+    except (wave.Error, EOFError):         # float / extensible / 8-bit files: scipy
+        pass
     from scipy.io import wavfile
     sr, data = wavfile.read(path)
     if data.ndim > 1:
@@ -40,11 +67,17 @@ def read_wav(path: str) -> Tuple[np.ndarray, int]:
 
 
 def save_audio(wav: torch.Tensor, path: str, sample_rate: int, rescale: bool = False) -> None:
-    """codec_inference.py:153-161: peak-rescale to 0.99 (or clamp), then 16-bit PCM."""
+    """codec_inference.py:153-161: peak-rescale to 0.99 (or clamp), then 16-bit PCM.  Mono float32 goes through the library's
+    fc_write_wav_pcm16 (same arithmetic, one pass in C; byte-identical files, tests/test_io.py)."""
     limit = 0.99
     wav = torch.as_tensor(wav).detach().float().cpu()
     if wav.dim() == 1:
         wav = wav[None]
+    if wav.shape[0] == 1 and _native() is not None:
+        x = wav[0].contiguous()
+        if _native().fc_write_wav_pcm16(os.fsencode(path), x.data_ptr(), x.numel(), int(sample_rate), int(bool(rescale))) != 0:
+            raise OSError(_native().fc_last_error().decode("utf-8", "replace"))
+        return
     mx = wav.abs().max()
     if rescale:
         wav = wav * min(limit / mx, 1) if mx > 0 else wav
@@ -149,7 +182,18 @@ def load_kaldi_mat(spec: str) -> np.ndarray:
 # codec index text format
 # ------------------------------------------------------------------------------------------------
 def format_codec_line(key: str, indices: Sequence[torch.Tensor], batch_id: int, length: int) -> str:
-    """codec_inference.py:295-299: ``<key> [[[T ints] x n_q]]`` (n_frame x n_q x T, n_frame always 1)."""
+    """codec_inference.py:295-299: ``<key> [[[T ints] x n_q]]`` (n_frame x n_q x T, n_frame always 1).  One frame of int64 codes on
+    the host goes through the library's fc_format_codec_json (byte-identical to json.dumps, ~50x faster; tests/test_io.py)."""
+    if len(indices) == 1 and _native() is not None:
+        x = indices[0]
+        if isinstance(x, torch.Tensor) and x.dtype == torch.int64 and x.device.type == "cpu" and x.dim() == 3 and x.is_contiguous():
+            lib = _native()
+            n_q, B, T = x.shape
+            cap = lib.fc_codec_json_bound(n_q, int(length))
+            buf = C.create_string_buffer(cap)
+            written = C.c_size_t(0)
+            if lib.fc_format_codec_json(x.data_ptr(), n_q, B, T, int(batch_id), int(length), buf, cap, C.byref(written)) == 0:
+                return key + " " + buf.raw[:written.value].decode("ascii") + "\n"
     to_write = [x[:, batch_id, :length].cpu().numpy().tolist() for x in indices]
     return key + " " + json.dumps(to_write) + "\n"
 
@@ -192,6 +236,8 @@ def _load_item(value: str, dtype: str) -> np.ndarray:
 def pad_list_with_mod(xs: Sequence[np.ndarray], pad_value=0.0, mode: str = "wrap") -> torch.Tensor:
     """nets_utils.py:65-98."""
     max_len = max(x.shape[0] for x in xs)
+    if all(x.shape[0] == max_len for x in xs):       # equal lengths: nothing to pad
+        return torch.from_numpy(np.stack(xs, 0))
     kw = {"mode": mode}
     if mode == "constant":
         kw["constant_values"] = pad_value

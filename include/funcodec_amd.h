@@ -211,6 +211,17 @@ int fc_engine_profile_read(fc_engine* e, fc_prof* out /* [FC_PROF_CLASSES] */);
  * Only builds made with FC_TIMELINE=1 record anything (all zeros otherwise); a tuning aid, not part of the path. */
 int fc_debug_timeline(unsigned long long* dst /* [2*24*8] */);
 
+/* ---- host-side wire formats of the CLI (no GPU work) -------------------------------------------
+ * The text form of one utterance's codes, byte for byte what funcodec/bin/codec_inference.py:295-299 writes with
+ * json.dumps(indices[:, b, :len].tolist()) for the single frame of non-segmented inference: "[[[i, i, ...], [...], ...]]"
+ * (n_q rows of `len` integers, ", " separators).
+ *   codes   HOST i64 [n_q][B][T];  out: at least fc_codec_json_bound(n_q, len) bytes;  *written = bytes produced (no terminator) */
+size_t fc_codec_json_bound(int n_q, int len);
+int fc_format_codec_json(const int64_t* codes, int n_q, int B, int T, int b, int len, char* out, size_t cap, size_t* written);
+/* save_audio (codec_inference.py:153-161): peak-rescale to 0.99 (rescale != 0; else clamp to +-0.99), round(x * 32768) clamped to
+ * int16, mono 16-bit PCM RIFF file.   wav HOST f32 [n] */
+int fc_write_wav_pcm16(const char* path, const float* wav, int n, int sample_rate, int rescale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -102,3 +102,37 @@ def test_resample_matches_the_published_sinc_hann_algorithm_properties():
     # a tone above the new Nyquist is removed (anti-aliasing), not folded back
     hi = torch.sin(2 * math.pi * 11000 * t).float()
     assert fio.resample(hi, 24000, 16000)[200:-200].abs().max() < 2e-2
+
+
+def test_native_wire_format_writers_are_byte_identical(tmp_path):
+    """fc_format_codec_json == json.dumps(x.tolist()) and fc_write_wav_pcm16 == the torch formula of save_audio
+    (codec_inference.py:153-161, 295-299), byte for byte."""
+    import json
+    import wave
+    from funcodec_amd import io as fio
+    assert fio._native() is not None
+    g = torch.Generator().manual_seed(0)
+    tok = [torch.randint(0, 1024, (8, 3, 57), generator=g)]
+    tok[0][0, 1, 0] = 0
+    tok[0][7, 2, 56] = 1023
+    for b, n in ((0, 57), (1, 1), (2, 56), (1, 0)):
+        assert fio.format_codec_line("utt", tok, b, n) == "utt " + json.dumps([tok[0][:, b, :n].numpy().tolist()]) + "\n"
+
+    def torch_save(wav, path, sr, rescale):
+        limit = 0.99
+        mx = wav.abs().max()
+        w = (wav * min(limit / mx, 1) if mx > 0 else wav) if rescale else wav.clamp(-limit, limit)
+        pcm = torch.clamp((w * 32768.0).round(), -32768, 32767).to(torch.int16).numpy()
+        with wave.open(path, "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr); f.writeframes(np.ascontiguousarray(pcm.T).tobytes())
+
+    for rescale in (True, False):
+        for amp in (0.3, 2.5, 0.0, 1e-6):
+            x = torch.randn(1, 4097, generator=g) * amp
+            x[0, 5] = 0.5 / 32768.0 * (1 if amp else 0)            # a round-half-to-even sample
+            a, b = str(tmp_path / "a.wav"), str(tmp_path / "b.wav")
+            fio.save_audio(x, a, 16000, rescale=rescale)
+            torch_save(x, b, 16000, rescale)
+            assert open(a, "rb").read() == open(b, "rb").read(), (rescale, amp)
+            y, sr = fio.read_wav(a)                                 # the stdlib fast path reads it back
+            assert sr == 16000 and y.shape == (4097,)
