@@ -28,3 +28,14 @@ for rep in range(2):                       # first pass warms the page cache / l
     main(["--output_dir", out] + args)
     dt = time.perf_counter() - t0
     print(f"pass {rep}: {N} x 10 s in {dt:.2f} s = {N * 10 / dt:.0f} audio-s/s end to end (engine load included)", flush=True)
+
+# stage 3 of encoding_decoding.sh: decode the codes file back to wavs
+codes = os.path.join(d, "out1.1", "codecs.txt")
+dargs = ["--ngpu", "1", "--gpuid_list", "0", "--batch_size", "16", "--sampling_rate", "16000", "--config_file", cfg_path,
+         "--model_file", pth_path, "--bit_width", "16000", "--run_mod", "decode", "--data_path_and_name_and_type", f"{codes},speech,codec_json"]
+for rep in range(2):
+    out = os.path.join(d, f"dec{rep}.1")
+    t0 = time.perf_counter()
+    main(["--output_dir", out] + dargs)
+    dt = time.perf_counter() - t0
+    print(f"decode pass {rep}: {N} x 10 s in {dt:.2f} s = {N * 10 / dt:.0f} audio-s/s end to end", flush=True)
