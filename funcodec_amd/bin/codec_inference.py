@@ -254,6 +254,14 @@ def inference_modelscope(
                     sq = torch.cat(sq_host, dim=-1).permute(1, 3, 0, 2)[i][:codec_len]
                     sub_quants_writer(key, sq.reshape(sq.shape[0], -1).numpy())
 
+        if kwargs.get("stat_flops") and not my_model.already_stat_flops:     # reference :328-342 (thop profile of a 1 s random input)
+            eng = my_model.model.engine
+            nq = my_model.model.arch.num_quantizers_for_bandwidth(bit_width)
+            w = eng.work(1, int(sampling_rate), nq)
+            params = sum(int(np.prod(shape)) for shape in eng.expected_tensors().values())
+            logging.info(f"Model total MACs: {w['total_flops'] / 2e9:.2f} G (conv {w['conv_flops'] / 2e9:.2f}, lstm {w['lstm_flops'] / 2e9:.2f}, "
+                         f"rvq {w['rvq_flops'] / 2e9:.2f}; 1 s of audio, n_q = {nq}), params: {params / 1e6:.2f} M")
+            my_model.already_stat_flops = True
         pool = ThreadPoolExecutor(max_workers=4)
         jobs = []
         try:

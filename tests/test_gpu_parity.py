@@ -946,7 +946,7 @@ def test_cli_encoding_decoding_pipeline(tmp_path):
     out = str(tmp_path / "out.1")
     main(["--ngpu", "1", "--gpuid_list", "0", "--output_dir", out, "--batch_size", "2", "--sampling_rate", "16000",
           "--config_file", cfg_path, "--model_file", pth_path, "--bit_width", "8000", "--use_scale", "false",
-          "--need_indices", "true", "--run_mod", "inference",
+          "--need_indices", "true", "--run_mod", "inference", "--stat_flops", "true",
           "--data_path_and_name_and_type", f"{scp},speech,sound"])
     lines = fio.read_scp(os.path.join(out, "codecs.txt"))
     assert [k for k, _ in lines] == ["u0", "u1", "u2"]
