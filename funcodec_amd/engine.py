@@ -49,6 +49,10 @@ class CodecEngine:
     def __init__(self, arch: ArchSpec, device: "torch.device | str | int" = "cuda:0"):
         self.lib = _lib.load()
         self.arch = arch
+        if arch.lstm_layers > 0 and arch.bottleneck_channels == 512:
+            # H = 512: the persistent LSTM advances two 16-utterance batch tiles side by side (128 workgroups each), so 32 utterances
+            # per call cost the recurrence what 16 do
+            self.micro_batch = 32
         dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         if dev.type != "cuda":
             raise EngineError(
