@@ -1071,9 +1071,8 @@ struct Act2 {              // raw [B][F + 2*halo][C][T] + pending GroupNorm affi
     int C = 0, F = 0, T = 0, halo = 0;
     bool normed = false;
 };
-// frequency halo rows of every 2-D activation that a kf > 1 conv may read = the largest one-sided frequency padding of the net's convs
-// (7x7: 3, 3x3: 1, strided 2 fr rows with stride fr: ceil(fr / 2)); fc_engine::halo2, set by build_plan_2d
-#define kHalo2 (e->halo2)
+// fc_engine::halo2 (set by build_plan_2d): frequency halo rows of every 2-D activation that a kf > 1 conv may read = the largest one-sided
+// frequency padding of the net's convs (7x7: 3, 3x3: 1, strided 2 fr rows with stride fr: ceil(fr / 2))
 
 // SConv2d.forward (conv.py:342-381) as ONE launch of the 1-D implicit-GEMM kernel over B * Fo virtual utterances
 Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* x1p, int elu, int out_halo) {
@@ -1201,9 +1200,9 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
 void run_resblocks2d(fc_engine* e, Ctx& cx, const fc_engine::Stage& S, Act2 a0, const Act2* a1, Act2* sc, Act2* b3) {
     Act2 prev1;
     for (const auto& R : S.res) {
-        *sc = run_conv2d(e, cx, R.shortcut, a0, a1, 0, kHalo2);
+        *sc = run_conv2d(e, cx, R.shortcut, a0, a1, 0, e->halo2);
         Act2 b1 = run_conv2d(e, cx, R.block1, a0, a1, 1, 0);
-        *b3 = run_conv2d(e, cx, R.block3, b1, nullptr, 1, kHalo2);
+        *b3 = run_conv2d(e, cx, R.block3, b1, nullptr, 1, e->halo2);
         a0 = *sc; prev1 = *b3; a1 = &prev1;
     }
 }
@@ -1321,19 +1320,19 @@ Act run_encoder_2d(fc_engine* e, Ctx& cx, const float* wav, int T, const float* 
     fc::Src sx; sx.ptr = xp; sx.used = 1;
     Act spec = run_conv(e, cx, e->stft, sx, fc::Src(), 0, Mp);                     // [B][2F][Tp]: re rows, then im rows
     Act2 feats;
-    feats.C = a.input_channels; feats.F = F; feats.T = Tp; feats.halo = kHalo2;
-    feats.buf = cx.alloc<float>((size_t)B * (F + 2 * kHalo2) * feats.C * Tp);
+    feats.C = a.input_channels; feats.F = F; feats.T = Tp; feats.halo = e->halo2;
+    feats.buf = cx.alloc<float>((size_t)B * (F + 2 * e->halo2) * feats.C * Tp);
     if (!cx.dry && !cx.err) {
-        hipError_t er = fc::launch_stft_feats(spec.raw, B, F, Tp, (long long)2 * F * Tp, kHalo2, feats.buf, cx.st);
-        if (er == hipSuccess) er = fc::launch_halo_rows(feats.buf, B, F, kHalo2, feats.C, Tp, 0, cx.st);
+        hipError_t er = fc::launch_stft_feats(spec.raw, B, F, Tp, (long long)2 * F * Tp, e->halo2, feats.buf, cx.st);
+        if (er == hipSuccess) er = fc::launch_halo_rows(feats.buf, B, F, e->halo2, feats.C, Tp, 0, cx.st);
         if (er != hipSuccess) { cx.err = 1; g_err = std::string("stft feature launch failed: ") + hipGetErrorString(er); }
     }
-    Act2 x = run_conv2d(e, cx, e->enc2_first, feats, nullptr, 0, kHalo2);
+    Act2 x = run_conv2d(e, cx, e->enc2_first, feats, nullptr, 0, e->halo2);
     for (size_t si = 0; si < e->enc_stages.size(); ++si) {
         auto& S = e->enc_stages[si];
         Act2 sc, b3;
         run_resblocks2d(e, cx, S, x, nullptr, &sc, &b3);
-        x = run_conv2d(e, cx, S.resample, sc, &b3, 1, si + 1 == e->enc_stages.size() ? 0 : kHalo2);
+        x = run_conv2d(e, cx, S.resample, sc, &b3, 1, si + 1 == e->enc_stages.size() ? 0 : e->halo2);
     }
     if (!cx.dry && !cx.err && x.F != 1) { cx.err = 1; g_err = "the 2-D encoder must reduce the frequency axis to one bin (n_fft / ratios mismatch)"; }
     Act x1;                                                                        // ReshapeModule: [B][1][C][T] is [B][C][T]
@@ -1363,7 +1362,7 @@ void run_decoder_2d(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf, const flo
     }
     for (size_t si = 0; si < e->dec_stages.size(); ++si) {
         auto& S = e->dec_stages[si];
-        Act2 up = run_convtr2d(e, cx, S.resample, e->dec_up_phases[si], a0, has1 ? &a1 : nullptr, si + 1 == e->dec_stages.size(), kHalo2);
+        Act2 up = run_convtr2d(e, cx, S.resample, e->dec_up_phases[si], a0, has1 ? &a1 : nullptr, si + 1 == e->dec_stages.size(), e->halo2);
         Act2 sc, b3;
         run_resblocks2d(e, cx, S, up, nullptr, &sc, &b3);
         a0 = sc; a1 = b3; has1 = true;
