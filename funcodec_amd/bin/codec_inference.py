@@ -48,8 +48,11 @@ class Speech2Token:
             sampling_rate: int = 24_000,
             bit_width: int = 24_000,
     ):
-        if dtype != "float32":
-            raise NotImplementedError("only dtype=float32 is supported (index exactness, SURVEY.md §7-3)")
+        if dtype not in ("float16", "float32", "float64"):
+            raise ValueError(f"dtype must be float16, float32 or float64, got {dtype!r}")
+        # The engine computes in fp32 whatever `dtype` says (index exactness).  The reference converts the MODEL with
+        # model.to(dtype) (:78) and feeds the caller's tensors unchanged; here float16 / float64 means: inputs of that dtype are
+        # accepted and the floating-point outputs are returned in it (fp32 arithmetic in between).
         if device == "cpu":
             raise RuntimeError("funcodec_amd.Speech2Token runs on MI355X only; use the reference for device='cpu'")
         model, model_args = build_model_from_file(config_file, model_file, device)
@@ -90,6 +93,13 @@ class Speech2Token:
             speech = speech[:, :, :nq]
             logging.info("use %d quantizers.", speech.shape[-1])
             ret = self.model.inference_decoding(speech)
+        if self.dtype != "float32":
+            td = getattr(torch, self.dtype)
+            cast = lambda t: t.to(td) if isinstance(t, torch.Tensor) and t.is_floating_point() else t   # noqa: E731
+            ret = dict(ret,
+                       code_embeddings=[(cast(q), cast(sc)) for q, sc in ret["code_embeddings"]],
+                       recon_speech=cast(ret["recon_speech"]),
+                       sub_quants=None if ret["sub_quants"] is None else [cast(x) for x in ret["sub_quants"]])
         return (ret["code_indices"], ret["code_embeddings"], ret["recon_speech"], ret["sub_quants"])
 
     @staticmethod

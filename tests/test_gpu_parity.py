@@ -754,6 +754,12 @@ def test_speech2token_dropin_api(tmp_path):
     assert s2t.model.quantizer.encoder_hop_length == 320 and s2t.model.quantizer.codebook_size == 1024
     t2s = Token2Speech(speech2token=s2t)
     assert rms(t2s(tok), orc.decode_codes(tok.cpu())[0]) < WAV_RMS_TOL
+    # dtype="float16": inputs of that dtype accepted, floating outputs returned in it, fp32 arithmetic in between (same indices)
+    s16 = Speech2Token(cfg_path, pth_path, device="cuda", dtype="float16")
+    i16, e16, r16, q16 = s16(wav.half(), run_mod="inference")
+    i32, _, r32, _ = s2t(wav.half().float(), run_mod="inference")
+    assert torch.equal(i16[0], i32[0]) and r16.dtype == torch.float16 and e16[0][0].dtype == torch.float16 and q16[0].dtype == torch.float16
+    assert torch.equal(r16, r32.half())
     # use_scale=False: reconstruction stays in the normalised domain (encoding_decoding.sh passes this)
     _, embs_ns, recon_ns, _ = s2t(wav, use_scale=False)
     assert embs_ns[0][1] is None
