@@ -1100,7 +1100,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         c.padL = g.padL; c.padR = g.padR; c.elu = elu; c.alpha = e->arch.elu_alpha;
         c.in_sB = (long long)(x0.F + 2 * x0.halo) * rowsz; c.in_sF = rowsz;
         c.out_sB = (long long)(Fo + 2 * out_halo) * orow; c.out_sF = orow;
-        const int nblk = fc::gconv2d_nblk(g.Tout, Fo, L.groups);
+        const int nblk = fc::gconv2d_nblk(g.Tout, Fo, L.groups, kf);
         c.partials = cx.alloc<double>((size_t)B * nblk * 2);
         o.aff = cx.alloc<float>((size_t)B * L.cout * 2);
         o.normed = true;

@@ -178,8 +178,10 @@ struct GConvArgs {
     long long in_sB, in_sF, out_sB, out_sF;      // floats between utterances / frequency rows
 };
 
-template <int CPG, int OPG, int KF, int KT, int ST, bool DUAL>
+template <int CPG, int OPG, int KF, int KT, int ST, bool DUAL, int FO>
 __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
+    // FO = output frequency rows per lane (rows fo0, fo0 + 1): the KF + (FO - 1) SF input rows they read are loaded and activated once
+    // instead of FO x KF times (3x3: 4 rows instead of 6; 8-row stride-4 layers: 12 instead of 16)
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int NE = 3 * ST + KT;              // input columns behind 4 outputs
     constexpr int NV = (NE + 3) / 4;             // 16-byte pieces
@@ -188,7 +190,9 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
     __shared__ double red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int tile = blockIdx.x, g = blockIdx.y, z = blockIdx.z;
-    const int b = z / p.Fo, fo = z - b * p.Fo;
+    const int FoP = (p.Fo + FO - 1) / FO;        // row groups per utterance
+    const int b = z / FoP, fo0 = (z - b * FoP) * FO;
+    const int sf = p.sf;
     for (int i = tid; i < NW; i += 256) wsh[i] = p.w[(size_t)g * NW + i];
     __syncthreads();
     const int n0 = tile * 1024 + 4 * tid;        // first output column of this lane
@@ -209,22 +213,29 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
         }
     }
     const unsigned vmask = vec_ok ? (1u << NE) - 1u : emask;
-    const size_t in_base = (size_t)b * p.in_sB + (size_t)(fo * p.sf) * p.in_sF + (size_t)(g * CPG) * p.Tin;
+    const int row_max = (p.Fo - 1) * sf + KF - 1;    // last input row any valid output row reads (a dangling second row is clamped onto it)
+    const size_t in_b = (size_t)b * p.in_sB + (size_t)(g * CPG) * p.Tin;
     const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)b * p.C + g * CPG : nullptr;
     const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)b * p.C + g * CPG : nullptr;
-    float acc[OPG][4];
+    float acc[FO][OPG][4];
 #pragma unroll
-    for (int o = 0; o < OPG; ++o)
+    for (int f = 0; f < FO; ++f)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+        for (int o = 0; o < OPG; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][o][j] = 0.f;
     const bool live = n0 < p.Tout;
     if (live) {
+        // the stride between the FO rows' windows is a run-time value; the reference's 2-D nets use sf == KF / 2 for strided layers and
+        // sf == 1 otherwise, which is what the (row, output) -> tap table below is unrolled for
 #pragma unroll
-        for (int a = 0; a < KF; ++a) {
+        for (int r = 0; r < KF + (FO - 1) * (KF >= 4 ? KF / 2 : 1); ++r) {
+            int rr = fo0 * sf + r;
+            rr = rr > row_max ? row_max : rr;
             f32x4 r0[CPG][NV], r1[DUAL ? CPG : 1][NV];
 #pragma unroll
-            for (int ci = 0; ci < CPG; ++ci) {   // straight-line loads of the whole frequency tap
-                const size_t off = in_base + (size_t)a * p.in_sF + (size_t)ci * p.Tin + qsafe;
+            for (int ci = 0; ci < CPG; ++ci) {   // straight-line loads of the whole input row
+                const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)ci * p.Tin + qsafe;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     r0[ci][v] = *(const f32x4u*)(p.src0 + off + 4 * v);
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
                 for (int j = 0; j < NE; ++j) {
                     float v0 = r0[ci][j >> 2][j & 3], v1 = DUAL ? r1[ci][j >> 2][j & 3] : 0.f;
                     if (!vec_ok) {               // padded edge: gather by index
-                        const size_t off = in_base + (size_t)a * p.in_sF + (size_t)ci * p.Tin + esrc[j];
+                        const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)ci * p.Tin + esrc[j];
                         v0 = p.src0[off];
                         if (DUAL) v1 = p.src1[off];
                     }
@@ -250,33 +261,44 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
                     x[j] = ((vmask >> j) & 1u) ? v : 0.f;
                 }
 #pragma unroll
-                for (int o = 0; o < OPG; ++o)
+                for (int f = 0; f < FO; ++f) {
+                    constexpr int SFC = KF >= 4 ? KF / 2 : 1;          // compile-time row stride between the FO windows (== p.sf, checked by the launcher)
+                    const int a = r - f * SFC;                         // frequency tap of input row r for output row f
+                    if (a < 0 || a >= KF) continue;
 #pragma unroll
-                    for (int kk = 0; kk < KT; ++kk) {
-                        const float wv = wsh[((o * CPG + ci) * KF + a) * KT + kk];
+                    for (int o = 0; o < OPG; ++o)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(wv, x[j * ST + kk], acc[o][j]);
-                    }
+                        for (int kk = 0; kk < KT; ++kk) {
+                            const float wv = wsh[((o * CPG + ci) * KF + a) * KT + kk];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[f][o][j] = fmaf(wv, x[j * ST + kk], acc[f][o][j]);
+                        }
+                }
             }
         }
     }
     float s1v = 0.f, s2v = 0.f;
 #pragma unroll
-    for (int o = 0; o < OPG; ++o) {
-        const int m = g * OPG + o;
-        const float bm = p.bias[m];
-        float ov[4];
+    for (int f = 0; f < FO; ++f) {
+        const int fo = fo0 + f;
+        if (fo >= p.Fo) continue;                // dangling second row of an odd row count
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ov[j] = acc[o][j] + bm;
-            if (live && n0 + j < p.Tout) { s1v += ov[j]; s2v = fmaf(ov[j], ov[j], s2v); }
+        for (int o = 0; o < OPG; ++o) {
+            const int m = g * OPG + o;
+            const float bm = p.bias[m];
+            float ov[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ov[j] = acc[f][o][j] + bm;
+                if (live && n0 + j < p.Tout) { s1v += ov[j]; s2v = fmaf(ov[j], ov[j], s2v); }
+            }
+            if (!live) continue;
+            float* orow = p.out + (size_t)b * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.Tout + n0;
+            if (n0 + 3 < p.Tout) *(f32x4u*)orow = (f32x4){ov[0], ov[1], ov[2], ov[3]};
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (n0 + j < p.Tout) orow[j] = ov[j];
         }
-        if (!live) continue;
-        float* orow = p.out + (size_t)b * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.Tout + n0;
-        if (n0 + 3 < p.Tout) *(f32x4u*)orow = (f32x4){ov[0], ov[1], ov[2], ov[3]};
-        else
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (n0 + j < p.Tout) orow[j] = ov[j];
     }
     if (p.partials) {
         double d1 = (double)s1v, d2 = (double)s2v;
@@ -288,7 +310,7 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
         if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
         __syncthreads();
         if (tid == 0) {
-            const size_t slot = ((((size_t)b * p.Fo + fo) * p.G + g) * gridDim.x + tile) * 2;
+            const size_t slot = ((((size_t)b * FoP + (fo0 / FO)) * p.G + g) * gridDim.x + tile) * 2;
             p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
             p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
         }
@@ -301,7 +323,10 @@ bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st) {
     const bool chans = (cpg == 2 && opg == 2) || (cpg == 4 && opg == 2) || (cpg == 2 && opg == 4);
     return shape && chans;
 }
-int gconv2d_nblk(int Tout, int Fo, int G) { return cdiv(Tout, 1024) * Fo * G; }
+// output frequency rows per lane: 2 for the 3 x 3 layers (4 input rows instead of 6: 6.9 -> 5.6 ms on freqmpgr1); the strided 8-row layers
+// measured slower with 2 (12 rows x two sources in flight: 4.4 -> 5.6 ms), 1 x 1 layers share nothing
+static int gconv2d_fo(int kf, int Fo) { return (kf == 3 && Fo > 1) ? 2 : 1; }
+int gconv2d_nblk(int Tout, int Fo, int G, int kf) { return cdiv(Tout, 1024) * cdiv(Fo, gconv2d_fo(kf, Fo)) * G; }
 
 hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     GConvArgs a;
@@ -312,14 +337,21 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
     a.elu = c.elu; a.alpha = c.alpha;
     a.in_sB = c.in_sB; a.in_sF = c.in_sF; a.out_sB = c.out_sB; a.out_sF = c.out_sF;
-    if ((long long)c.B * c.Fo > 65535 || c.G > 65535) return hipErrorInvalidValue;
-    dim3 grid(cdiv(c.Tout, 1024), c.G, c.B * c.Fo), block(256);
+    const int fo_n = gconv2d_fo(c.kf, c.Fo);
+    if (c.kf >= 4 ? c.sf != c.kf / 2 : c.sf != 1) return hipErrorInvalidValue;          // the kernel's compile-time row stride
+    if ((long long)c.B * cdiv(c.Fo, fo_n) > 65535 || c.G > 65535) return hipErrorInvalidValue;
+    dim3 grid(cdiv(c.Tout, 1024), c.G, c.B * cdiv(c.Fo, fo_n)), block(256);
     const int cpg = c.C / c.G, opg = c.M / c.G;
     const bool dual = c.src1 != nullptr;
 #define FC_GC(CP, OP, KF_, KT_, ST_)                                                                                         \
     if (cpg == CP && opg == OP && c.kf == KF_ && c.kt == KT_ && c.st == ST_) {                                               \
-        if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true>), grid, block, 0, st, a);                   \
-        else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false>), grid, block, 0, st, a);                       \
+        if (fo_n == 2) {                                                                                                     \
+            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, (KF_ == 3 ? 2 : 1)>), grid, block, 0, st, a);    \
+            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, (KF_ == 3 ? 2 : 1)>), grid, block, 0, st, a);        \
+        } else {                                                                                                             \
+            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, 1>), grid, block, 0, st, a);            \
+            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, 1>), grid, block, 0, st, a);                \
+        }                                                                                                                    \
         return hipGetLastError();                                                                                            \
     }
 #define FC_GCS(KF_, KT_, ST_) FC_GC(2, 2, KF_, KT_, ST_) FC_GC(4, 2, KF_, KT_, ST_) FC_GC(2, 4, KF_, KT_, ST_)

@@ -84,7 +84,7 @@ struct GConvLaunch {
     long long in_sB = 0, in_sF = 0, out_sB = 0, out_sF = 0;
 };
 bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st);
-int gconv2d_nblk(int Tout, int Fo, int G);
+int gconv2d_nblk(int Tout, int Fo, int G, int kf);
 hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st);
 // grouped ConvTranspose2d((2 fr, 2 tr), stride (fr, tr)), 2 input / 1 output channel per group, over the materialised ELU'd input z
 bool gconvtr2d_ok(int cpg, int opg, int tr);
