@@ -1084,6 +1084,22 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
     const ConvGeom g = conv_geom(L, x0.T);
     // layers with several M tiles: materialise the activated input once (as run_conv does), frequency-major with the same halo
     if (L.w_group) {     // grouped conv with 2 / 4 channels per group: direct FMA kernel, prologue fused, no GEMM
+        // the strided 8-row layers read every input sample from 2 output rows x ~1.25 lanes with a two-source prologue (11 VALU per read):
+        // activate once instead (FC_GCONV_MAT=0: in-kernel prologue)
+        static const int gmat = getenv("FC_GCONV_MAT") ? atoi(getenv("FC_GCONV_MAT")) : 1;
+        if (gmat && kf >= 4 && dual) {
+            Act2 m;
+            m.C = C; m.F = x0.F; m.T = x0.T; m.halo = x0.halo;
+            m.buf = cx.alloc<float>((size_t)B * (m.F + 2 * m.halo) * C * m.T);
+            cx.launches += 2;
+            if (!cx.dry && !cx.err) {
+                hipError_t er = fc::launch_combine2d(x0.buf, x0.aff, x0.halo, x1.buf, x1.aff, x1.halo, elu, e->arch.elu_alpha, B, m.F, C, m.T, m.buf,
+                                                     m.halo, cx.st);
+                if (er == hipSuccess) er = fc::launch_halo_rows(m.buf, B, m.F, m.halo, C, m.T, 0, cx.st);
+                if (er != hipSuccess) { cx.err = 1; g_err = std::string("combine2d launch failed: ") + hipGetErrorString(er); }
+            }
+            x0 = m; x1 = Act2(); elu = 0; dual = false;
+        }
         Act2 o;
         o.C = L.cout; o.F = Fo; o.T = g.Tout; o.halo = out_halo;
         o.buf = cx.alloc<float>((size_t)B * (Fo + 2 * out_halo) * L.cout * g.Tout);
