@@ -427,6 +427,40 @@ def test_lstm_against_torch_cpu(cfg_name, seed, B, T):
         assert (got - ref).abs().max().item() < 1e-5, p
 
 
+def test_two_engines_on_two_threads_and_streams_concurrently():
+    """Two engines driven from two Python threads on two HIP streams at once (conv kernels of one next to the persistent LSTM of the other,
+    thread-local error strings, per-engine status words): every call still returns the single-stream result bit for bit."""
+    import threading
+    from funcodec_amd.model import EncodecMI355X
+    cfg, arch, sd = state_for("ds640", 0)
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    wavs = [audio(8, 48000, 11 + i, "tones").cuda() for i in range(2)]
+    m0 = engine_for("ds640", 0)
+    refs = [m0.engine.encode_decode(w, 32) for w in wavs]
+    torch.cuda.synchronize()
+    errs = []
+
+    def worker(i):
+        try:
+            m = EncodecMI355X(arch, "cuda:0")
+            m.load_state_dict(tsd)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for it in range(12):
+                    r = m.engine.encode_decode(wavs[i], 32)
+                    if not (torch.equal(r["codes"], refs[i]["codes"]) and torch.equal(r["recon"], refs[i]["recon"])):
+                        errs.append((i, it, "mismatch"))
+                s.synchronize()
+                m.engine.check_status()
+        except Exception as ex:                      # noqa: BLE001
+            errs.append((i, repr(ex)[:300]))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:3]
+
+
 # ---- long recurrences and degenerate signals ---------------------------------------------------------------------------------------
 def test_long_utterance_against_oracle():
     """60 s in one utterance (ds320: a 3 000-step LSTM recurrence on hardware exp2 / rcp gates, 3 750 tiles on the thin layers, 32-bit
