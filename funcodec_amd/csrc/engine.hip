@@ -945,7 +945,7 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
     cx.launches += persist ? 2 : T + L;
     if (!cx.dry && !cx.err) {
         ProfSpan sp(e, cx, e->profiling ? e->prof_class(persist ? kLstmPersistClass : kLstmWaveClass) : 0, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
-        hipError_t er = hipMemsetAsync(state, 0, (persist ? fc::lstm_persist_clear_floats(B, H) : (size_t)3 * L * B * H) * sizeof(float), cx.st);
+        hipError_t er = fc::launch_zero_fill(state, persist ? fc::lstm_persist_clear_floats(B, H) : (size_t)3 * L * B * H, cx.st);
         const float* w[FC_LSTM_MAX_LAYERS] = {nullptr};
         const float* bias[FC_LSTM_MAX_LAYERS] = {nullptr};
         for (int l = 0; l < L; ++l) { w[l] = l == 0 ? lb.layers[0].whh : lb.layers[l].wcat; bias[l] = lb.layers[l].bperm; }

@@ -145,6 +145,7 @@ hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bi
 hipError_t launch_overlap_add(const float* const* frames, const int* lens, int n_frames, int B, int L0, int stride, int out_len,
                               float* out, hipStream_t st);
 hipError_t debug_timeline(unsigned long long* dst);      // [2 roles][24 items][8 slots], profiling builds only
+hipError_t launch_zero_fill(float* p, size_t n, hipStream_t st);
 size_t lstm_persist_state_floats(int B, int H, int T);   // barrier words + zero slot + hidden-state history of both layers
 size_t lstm_persist_clear_floats(int B, int H);
 bool lstm_persist_supported(int B, int H, int L, int device);

@@ -1845,6 +1845,19 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
 
 // H = 512 occupies 128 of the 256 CUs: a second batch tile gets its own 128 workgroups (and barrier words) instead of a second pass
 static int lstm_persist_groups(int B, int H) { return (H == 512 && B > 16) ? 2 : 1; }
+// zero fill as a KERNEL of this library (not hipMemsetAsync): under HIP-graph replay the runtime's memset node was observed to run
+// unordered with respect to the neighbouring kernel nodes (tools/graph_probe.py), which resets the barrier words mid-recurrence
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+hipError_t launch_zero_fill(float* p, size_t n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
+    return hipGetLastError();
+}
+
 size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)(2 * T + 1) * B * H; }
 size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)B * H; }
 

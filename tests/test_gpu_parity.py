@@ -427,6 +427,31 @@ def test_lstm_against_torch_cpu(cfg_name, seed, B, T):
         assert (got - ref).abs().max().item() < 1e-5, p
 
 
+def test_engine_calls_can_be_replayed_as_a_hip_graph():
+    """fc_* calls only enqueue kernels of this library on the given stream, so a caller may stream-capture them (torch.cuda.CUDAGraph).
+    Round 2: the barrier words / initial LSTM state used to be cleared with hipMemsetAsync, whose graph memset node replayed unordered with
+    its neighbours (persistent-LSTM barrier timeouts, wrong states); they are cleared by a kernel of the library now."""
+    m = engine_for("ds320", 0)
+    wav = audio(3, 24000, 5, "tones").cuda()
+    ref = m.engine.encode_decode(wav, 32)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.engine.encode_decode(wav, 32)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m.engine.encode_decode(wav, 32)
+    for i in range(40):
+        g.replay()
+        if i % 13 == 0:
+            torch.cuda.synchronize()
+            assert torch.equal(out["codes"], ref["codes"]) and torch.equal(out["recon"], ref["recon"]), i
+    torch.cuda.synchronize()
+    assert torch.equal(out["codes"], ref["codes"]) and torch.equal(out["recon"], ref["recon"])
+    m.engine.check_status()
+
+
 def test_two_engines_on_two_threads_and_streams_concurrently():
     """Two engines driven from two Python threads on two HIP streams at once (conv kernels of one next to the persistent LSTM of the other,
     thread-local error strings, per-engine status words): every call still returns the single-stream result bit for bit."""
