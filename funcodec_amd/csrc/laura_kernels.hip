@@ -1,0 +1,947 @@
+// gfx950 (MI355X / CDNA4) kernels of the LauraTTS generation path (laura_kernels.h).  fp32 everywhere; contractions on the
+// fp32-input matrix cores (v_mfma_f32_16x16x4_f32: an fmaf chain in k order, no narrower arithmetic).  Wavefront = 64 lanes.
+//
+// MFMA 16x16x4 operand layout (as used by the codec kernels): lane l = 16 g + r;  A operand = A[row r][k g];
+// B operand = B[k g][col r];  accumulator register v = D[row 4 g + v][col r].
+#include "laura_kernels.h"
+
+#include <atomic>
+
+namespace fc {
+namespace laura {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+namespace {
+
+__device__ __forceinline__ int ceil_div_d(int a, int b) { return (a + b - 1) / b; }
+inline int ceil_div_h(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float act_f(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v / (1.f + expf(-v));      // Swish: x * sigmoid(x) (nets_utils.py:568-574)
+    return v;
+}
+
+// opt-in to > 64 KiB of dynamic LDS, once per (kernel, device)
+template <typename F>
+hipError_t big_lds(F kfn, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+// LayerNorm over the channel axis of a feature-major tensor (torch.nn.LayerNorm, biased variance; eps 1e-12 inside the blocks,
+// funcodec/modules/layer_norm.py:22, 1e-5 in the input layers).  One thread column per time step (coalesced over t), the C
+// channels split over 4 thread rows; two-pass mean / variance in fp32.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void layernorm_fm_kernel(const float* __restrict__ x, const float* __restrict__ add, float* sum_out,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           int relu, float post_scale, float* __restrict__ y, int C, int T) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tx, b = blockIdx.y;
+    const bool ok = t < T;
+    const size_t base = (size_t)b * C * T + (ok ? t : 0);
+    const int c0 = cg * (C / 4), c1 = cg == 3 ? C : c0 + C / 4;
+    float s = 0.f;
+    for (int c = c0; c < c1; ++c) {
+        float v = x[base + (size_t)c * T];
+        if (add) v += add[base + (size_t)c * T];
+        if (sum_out && ok) sum_out[base + (size_t)c * T] = v;
+        s += v;
+    }
+    red[cg][tx] = s;
+    __syncthreads();
+    const float mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+    __syncthreads();
+    const float* src = sum_out ? sum_out : x;        // sum_out == x (in place) or a separate buffer: both hold x + add now
+    float q = 0.f;
+    for (int c = c0; c < c1; ++c) {
+        float v = src[base + (size_t)c * T];
+        if (add && !sum_out) v += add[base + (size_t)c * T];
+        const float dv = v - mean;
+        q += dv * dv;
+    }
+    red[cg][tx] = q;
+    __syncthreads();
+    const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+    const float rstd = 1.f / sqrtf(var + eps);
+    if (!ok) return;
+    for (int c = c0; c < c1; ++c) {
+        float v = src[base + (size_t)c * T];
+        if (add && !sum_out) v += add[base + (size_t)c * T];
+        float o = (v - mean) * rstd * gamma[c] + beta[c];
+        if (relu) o = o > 0.f ? o : 0.f;
+        y[base + (size_t)c * T] = o * post_scale;
+    }
+}
+
+hipError_t launch_layernorm_fm(const float* x, const float* add, float* sum_out, const float* gamma, const float* beta, float eps,
+                               int relu, float post_scale, float* y, int B, int C, int T, hipStream_t st) {
+    if (C % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_fm_kernel, dim3(ceil_div_h(T, 64), B), dim3(256), 0, st, x, add, sum_out, gamma, beta, eps, relu,
+                       post_scale, y, C, T);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void act_kernel(float* x, size_t n, int act) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        f32x4 v = *(f32x4*)(x + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_f(v[j], act);
+        *(f32x4*)(x + i) = v;
+    } else {
+        for (size_t k = i; k < n; ++k) x[k] = act_f(x[k], act);
+    }
+}
+hipError_t launch_act(float* x, size_t n, int act, hipStream_t st) {
+    if (!act || !n) return hipSuccess;
+    hipLaunchKernelGGL(act_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, x, n, act);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// Full-sequence rel-pos attention (RelPositionMultiHeadedAttention.forward, funcodec/modules/attention.py:265-308 +
+// forward_attention :64-96).  One workgroup = 16 queries of one (utterance, head):
+//   A  scores of the 16 queries against every key tile (4 waves, one 16-key tile each per trip) into LDS:
+//        ac = (q + u) . k_j                       one 16x16 MFMA tile
+//        bd = (q + v) . p_{i-j}                   the 31 relative positions of the tile as two MFMA tiles against the position
+//                                                 table, the (i, j) diagonal picked through LDS (= the reference's rel_shift)
+//        s  = (ac + bd) / sqrt(dk), masked (padding; causal with a bidirectional prefix block for the LM)
+//   B  row softmax in LDS (max, exp, sum, divide; masked entries 0 like masked_fill(mask, 0.0))
+//   C  ctx = P . V: wave w owns 16 of the dk output dims, A operand = probabilities from LDS, B operand = V rows (16-byte loads)
+// =====================================================================================================================
+struct AttnFullArgs {
+    const float *qkv, *ptab, *bias_u, *bias_v;
+    const int *lens, *bidir;
+    float* ctx;
+    int causal, H, T, R, PR, SW;     // SW = LDS row stride of the score block
+};
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_full_kernel(AttnFullArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* S = lds;                          // [16][SW]
+    float* Gs = lds + 16 * a.SW;             // [4 waves][16][33]
+    constexpr int NC = DK / 16;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int i0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const int T = a.T, d = a.H * DK;
+    const int len = a.lens[b];
+    const int bid = (a.causal && a.bidir) ? a.bidir[b] : 0;
+    if (i0 >= len) {       // padded queries: the reference computes garbage there too and every consumer masks them; write zeros
+        if (w < NC) {
+            const int t0 = i0 + 4 * g;
+            if (t0 < T) *(f32x4*)(a.ctx + ((size_t)b * d + h * DK + 16 * w + r16) * T + t0) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    // key tiles this query tile can see at all
+    int nkt = ceil_div_d(len, 16);
+    if (a.causal) {
+        int lim = i0 + 16;
+        if (bid > lim) lim = bid;
+        if (lim < len) nkt = ceil_div_d(lim, 16);
+    }
+    const float* qb = a.qkv + (size_t)b * 3 * d * T;
+    const float* kb = qb + (size_t)d * T;
+    const float* vb = kb + (size_t)d * T;
+    // query fragments (A operand): lane (r16 = query, g) holds dims 16 c + 4 g + j
+    const int iq = (i0 + r16 < T) ? i0 + r16 : T - 1;
+    float qu[NC][4], qv[NC][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dd = h * DK + 16 * c + 4 * g + j;
+            const float q = qb[(size_t)dd * T + iq];
+            qu[c][j] = q + a.bias_u[dd];
+            qv[c][j] = q + a.bias_v[dd];
+        }
+    const float scale = 1.f / sqrtf((float)DK);
+    const float NEG = -3.4028234663852886e38f;       // numpy.finfo(float32).min (attention.py:79-82)
+    float* Gw = Gs + w * 16 * 33;
+    const int ntrip = ceil_div_d(nkt, 4);
+    for (int trip = 0; trip < ntrip; ++trip) {
+        const int kt = trip * 4 + w;
+        const bool active = kt < nkt;
+        const int j0 = kt * 16;
+        f32x4 ac = {0.f, 0.f, 0.f, 0.f}, g0 = ac, g1 = ac;
+        if (active) {
+            const int jk = (j0 + r16 < T) ? j0 + r16 : T - 1;
+            const int rlo = i0 - j0 - 15 + (a.R - 1);                 // table column of window column 0
+            int p0 = rlo + r16, p1 = rlo + 16 + r16;
+            p0 = p0 < 0 ? 0 : (p0 >= a.PR ? a.PR - 1 : p0);
+            p1 = p1 < 0 ? 0 : (p1 >= a.PR ? a.PR - 1 : p1);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int dd = h * DK + 16 * c + 4 * g + j;
+                    const float kv = kb[(size_t)dd * T + jk];
+                    const float pa = a.ptab[(size_t)dd * a.PR + p0];
+                    const float pb = a.ptab[(size_t)dd * a.PR + p1];
+                    ac = __builtin_amdgcn_mfma_f32_16x16x4f32(qu[c][j], kv, ac, 0, 0, 0);
+                    g0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[c][j], pa, g0, 0, 0, 0);
+                    g1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv[c][j], pb, g1, 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Gw[(4 * g + r) * 33 + r16] = g0[r];
+                Gw[(4 * g + r) * 33 + 16 + r16] = g1[r];
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int il = 4 * g + r, i = i0 + il, j = j0 + r16;
+                const float bd = Gw[il * 33 + (il - r16 + 15)];      // window column of relative position i - j
+                bool vis = j < len;
+                if (a.causal) vis = vis && (j <= i || (i < bid && j < bid));
+                S[il * a.SW + j] = vis ? (ac[r] + bd) * scale : NEG;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- B: softmax, 16 threads per row
+    {
+        const int row = tid >> 4, part = tid & 15;
+        const int nk = nkt * 16;
+        float* Sr = S + row * a.SW;
+        float m = NEG;
+        for (int j = part; j < nk; j += 16) m = fmaxf(m, Sr[j]);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float s = 0.f;
+        for (int j = part; j < nk; j += 16) {
+            const float v = Sr[j];
+            const float e = (v == NEG) ? 0.f : expf(v - m);
+            Sr[j] = e;
+            s += e;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float inv = s > 0.f ? 1.f / s : 0.f;
+        for (int j = part; j < nk; j += 16) Sr[j] *= inv;
+    }
+    __syncthreads();
+    // ---- C: ctx[i][dd] = sum_j P[i][j] V[dd][j]
+    if (w < NC) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* vrow = vb + (size_t)(h * DK + 16 * w + r16) * T;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int j = kt * 16 + 4 * g;
+            const f32x4 p = *(const f32x4*)(S + r16 * a.SW + j);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < T) v = *(const f32x4*)(vrow + j);               // T % 4 == 0: the 16-byte piece is inside the row or past it
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(p[jj], v[jj], acc, 0, 0, 0);
+        }
+        const int t0 = i0 + 4 * g;
+        if (t0 < T) *(f32x4*)(a.ctx + ((size_t)b * d + h * DK + 16 * w + r16) * T + t0) = acc;
+    }
+}
+
+static int attn_sw(int T) { return ((T + 15) / 16) * 16 + 4; }
+size_t attn_full_lds_bytes(int T) { return (size_t)(16 * attn_sw(T) + 4 * 16 * 33) * sizeof(float); }
+
+hipError_t launch_attn_full(const AttnFull& a, hipStream_t st) {
+    if (a.T % 4 || a.T < 1 || (a.DK != 64 && a.DK != 32)) return hipErrorInvalidValue;
+    const size_t lds = attn_full_lds_bytes(a.T);
+    if (lds > 160 * 1024 || a.T > a.R) return hipErrorInvalidValue;
+    AttnFullArgs k{a.qkv, a.ptab, a.bias_u, a.bias_v, a.lens, a.bidir, a.ctx, a.causal, a.H, a.T, a.R, a.PR, attn_sw(a.T)};
+    const dim3 grid(ceil_div_h(a.T, 16), a.H, a.B);
+    static std::atomic<unsigned long long> d64{0ull}, d32{0ull};
+    hipError_t e;
+    if (a.DK == 64) {
+        if ((e = big_lds(attn_full_kernel<64>, d64)) != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_full_kernel<64>, grid, dim3(256), lds, st, k);
+    } else {
+        if ((e = big_lds(attn_full_kernel<32>, d32)) != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_full_kernel<32>, grid, dim3(256), lds, st, k);
+    }
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// layout changes and input assembly (all HBM-bound elementwise work)
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void tm_to_fm_kernel(const float* __restrict__ in, const int* __restrict__ lens, int L, int D, int T,
+                                                       float* __restrict__ out) {
+    // 32 x 32 tile transpose through LDS: read rows of D (coalesced over d), write rows of T (coalesced over t)
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int len = lens ? lens[b] : L;
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, d = d0 + tx;
+        tile[r][tx] = (t < len && t < L && d < D) ? in[((size_t)b * L + t) * D + d] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int d = d0 + r, t = t0 + tx;
+        if (d < D && t < T) out[((size_t)b * D + d) * T + t] = tile[tx][r];
+    }
+}
+hipError_t launch_tm_to_fm(const float* in, const int* lens, int B, int L, int D, int T, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(tm_to_fm_kernel, dim3(ceil_div_h(T, 32), ceil_div_h(D, 32), B), dim3(256), 0, st, in, lens, L, D, T, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void fm_to_tm_kernel(const float* __restrict__ in, const int* __restrict__ lens, int D, int T, int L,
+                                                       float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int len = lens ? lens[b] : L;
+    for (int r = ty; r < 32; r += 8) {
+        const int d = d0 + r, t = t0 + tx;
+        tile[r][tx] = (d < D && t < T && t < len) ? in[((size_t)b * D + d) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, d = d0 + tx;
+        if (t < L && d < D) out[((size_t)b * L + t) * D + d] = tile[tx][r];
+    }
+}
+hipError_t launch_fm_to_tm(const float* in, const int* lens, int B, int D, int T, int L, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(fm_to_tm_kernel, dim3(ceil_div_h(L, 32), ceil_div_h(D, 32), B), dim3(256), 0, st, in, lens, D, T, L, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void token_embed_fm_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, int vocab,
+                                                             int L, int D, int T, float* __restrict__ out) {
+    const int b = blockIdx.z, t = blockIdx.x * 64 + (threadIdx.x & 63);
+    if (t >= T) return;
+    long long id = t < L ? ids[(size_t)b * L + t] : -1;
+    if (id >= vocab) id = -1;
+    for (int d = blockIdx.y * 4 + (threadIdx.x >> 6); d < D; d += gridDim.y * 4)
+        out[((size_t)b * D + d) * T + t] = id >= 0 ? table[(size_t)id * D + d] : 0.f;
+}
+hipError_t launch_token_embed_fm(const int64_t* ids, const float* table, int vocab, int B, int L, int D, int T, float* out,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(token_embed_fm_kernel, dim3(ceil_div_h(T, 64), 8, B), dim3(256), 0, st, ids, table, vocab, L, D, T, out);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ float codebook_sum(const float* cb, int K, int D, int nq, const int64_t* tok, int stride, int d) {
+    // sum over the groups in group order (QuantizerCodebook.forward, laura_model.py:51-53; cal_codec_emb :303-310)
+    float s = 0.f;
+    for (int k = 0; k < nq; ++k) {
+        long long c = tok[k * stride];
+        c = c < 0 ? 0 : (c >= K ? K - 1 : c);
+        const float v = cb[((size_t)k * K + c) * D + d];
+        s = k == 0 ? v : s + v;
+    }
+    return s;
+}
+
+__global__ __launch_bounds__(256) void lm_assemble_kernel(const float* __restrict__ text_fm, int Tt, const int* __restrict__ text_lens,
+                                                          const float* __restrict__ lm_emb, const float* __restrict__ cb, int K, int nq,
+                                                          const int64_t* __restrict__ codec, const int* __restrict__ codec_lens, int Cmax,
+                                                          int D, int T, float* __restrict__ out, int* seq_len, int* bidir_len) {
+    const int b = blockIdx.z, t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int tl = text_lens[b], cl = (codec && codec_lens) ? codec_lens[b] : 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        seq_len[b] = tl + 2 + cl;
+        if (bidir_len) bidir_len[b] = tl + 1;          // <sos> + text (transformer_lm.py:286-288)
+    }
+    if (t >= T) return;
+    for (int d = blockIdx.y * 4 + (threadIdx.x >> 6); d < D; d += gridDim.y * 4) {
+        float v = 0.f;
+        if (t == 0) v = lm_emb[d];                                         // sos_eos = 0
+        else if (t <= tl) v = text_fm[((size_t)b * D + d) * Tt + (t - 1)];
+        else if (t == tl + 1) v = lm_emb[D + d];                           // task_id = 1
+        else if (t < tl + 2 + cl) v = codebook_sum(cb, K, D, nq, codec + ((size_t)b * Cmax + (t - tl - 2)) * nq, 1, d);
+        out[((size_t)b * D + d) * T + t] = v;
+    }
+}
+hipError_t launch_lm_assemble(const float* text_fm, int Tt, const int* text_lens, const float* lm_emb, const float* cb, int K, int nq,
+                              const int64_t* codec, const int* codec_lens, int Cmax, int B, int D, int T, float* out, int* seq_len,
+                              int* bidir_len, hipStream_t st) {
+    hipLaunchKernelGGL(lm_assemble_kernel, dim3(ceil_div_h(T, 64), 8, B), dim3(256), 0, st, text_fm, Tt, text_lens, lm_emb, cb, K, nq,
+                       codec, codec_lens, Cmax, D, T, out, seq_len, bidir_len);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void nar_assemble_kernel(const float* __restrict__ text_fm, int Tt, const int* __restrict__ text_lens,
+                                                           const float* __restrict__ cb, int K, int nq, const int64_t* __restrict__ codec,
+                                                           const int* __restrict__ codec_lens, int Cmax, int cstride,
+                                                           const float* __restrict__ pe_abs, int split, int D, int T,
+                                                           float* __restrict__ out, int* seq_len) {
+    const int b = blockIdx.z, t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int tl = text_lens[b], cl = codec_lens[b];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) seq_len[b] = tl + cl;
+    if (t >= T) return;
+    const float xs = sqrtf((float)D);
+    for (int d = blockIdx.y * 4 + (threadIdx.x >> 6); d < D; d += gridDim.y * 4) {
+        float v = 0.f;
+        if (t < tl) {
+            v = text_fm[((size_t)b * D + d) * Tt + t];
+            if (split) v = v * xs + pe_abs[(size_t)t * D + d];              // PositionalEncoding.forward (embedding.py:79-91)
+        } else if (t < tl + cl) {
+            v = codebook_sum(cb, K, D, nq, codec + ((size_t)b * Cmax + (t - tl)) * cstride, 1, d);
+            if (split) v = v * xs + pe_abs[(size_t)(t - tl) * D + d];
+        }
+        out[((size_t)b * D + d) * T + t] = v;
+    }
+}
+hipError_t launch_nar_assemble(const float* text_fm, int Tt, const int* text_lens, const float* cb, int K, int nq, const int64_t* codec,
+                               const int* codec_lens, int Cmax, int codec_stride_nq, const float* pe_abs, int split, int B, int D, int T,
+                               float* out, int* seq_len, hipStream_t st) {
+    hipLaunchKernelGGL(nar_assemble_kernel, dim3(ceil_div_h(T, 64), 8, B), dim3(256), 0, st, text_fm, Tt, text_lens, cb, K, nq, codec,
+                       codec_lens, Cmax, codec_stride_nq, pe_abs, split, D, T, out, seq_len);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void nar_extract_kernel(const float* __restrict__ in, const int* __restrict__ text_lens,
+                                                          const int* __restrict__ codec_lens, int D, int T, int Cmax,
+                                                          float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tl = text_lens[b], cl = codec_lens[b];
+    for (int r = ty; r < 32; r += 8) {
+        const int d = d0 + r, c = c0 + tx, t = tl + c;
+        tile[r][tx] = (d < D && c < cl && t < T) ? in[((size_t)b * D + d) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, d = d0 + tx;
+        if (c < Cmax && d < D) out[((size_t)b * Cmax + c) * D + d] = tile[tx][r];
+    }
+}
+hipError_t launch_nar_extract(const float* in, const int* text_lens, const int* codec_lens, int B, int D, int T, int Cmax, float* out,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(nar_extract_kernel, dim3(ceil_div_h(Cmax, 32), ceil_div_h(D, 32), B), dim3(256), 0, st, in, text_lens, codec_lens,
+                       D, T, Cmax, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(64) void logsoftmax_fm_kernel(const float* __restrict__ in, const int* __restrict__ lens, int V, int T, int L,
+                                                           float* __restrict__ out) {
+    const int b = blockIdx.y, t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= L) return;
+    float* o = out + ((size_t)b * L + t) * V;
+    if (t >= lens[b] || t >= T) {
+        for (int v = 0; v < V; ++v) o[v] = 0.f;
+        return;
+    }
+    const float* x = in + (size_t)b * V * T + t;
+    float m = -INFINITY;
+    for (int v = 0; v < V; ++v) m = fmaxf(m, x[(size_t)v * T]);
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += expf(x[(size_t)v * T] - m);
+    const float ls = logf(s);
+    for (int v = 0; v < V; ++v) o[v] = (x[(size_t)v * T] - m) - ls;
+}
+hipError_t launch_logsoftmax_fm(const float* in, const int* lens, int B, int V, int T, int L, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(logsoftmax_fm_kernel, dim3(ceil_div_h(L, 64), B), dim3(64), 0, st, in, lens, V, T, L, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void kv_store_kernel(const float* __restrict__ qkv, const int* __restrict__ lens, int d, int T, int Tcap,
+                                                       float* __restrict__ kc, float* __restrict__ vc) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int len = lens[b];
+    const float* kb = qkv + ((size_t)b * 3 + 1) * d * T;
+    const float* vb = qkv + ((size_t)b * 3 + 2) * d * T;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, t = t0 + tx;
+        const bool ok = n < d && t < len && t < T;
+        if (ok) kc[((size_t)b * d + n) * Tcap + t] = kb[(size_t)n * T + t];
+        tile[r][tx] = ok ? vb[(size_t)n * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, n = n0 + tx;
+        if (t < len && t < T && n < d) vc[((size_t)b * Tcap + t) * d + n] = tile[tx][r];
+    }
+}
+hipError_t launch_kv_store(const float* qkv, const int* lens, int B, int d, int T, int Tcap, float* kc, float* vc, hipStream_t st) {
+    hipLaunchKernelGGL(kv_store_kernel, dim3(ceil_div_h(T, 32), ceil_div_h(d, 32), B), dim3(256), 0, st, qkv, lens, d, T, Tcap, kc, vc);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gather_last_kernel(const float* __restrict__ x, const int* __restrict__ lens, int C, int T,
+                                                          float* __restrict__ out) {
+    const int b = blockIdx.x;
+    const int t = lens[b] - 1;
+    for (int c = threadIdx.x; c < C; c += 256) out[(size_t)b * C + c] = x[((size_t)b * C + c) * T + (t < 0 ? 0 : t)];
+}
+hipError_t launch_gather_last(const float* x, const int* lens, int B, int C, int T, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_last_kernel, dim3(B), dim3(256), 0, st, x, lens, C, T, out);
+    return hipGetLastError();
+}
+
+__global__ void fill_i32_kernel(int* p, int v, int n) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+hipError_t launch_fill_i32(int* p, int v, int n, hipStream_t st) {
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(ceil_div_h(n, 64)), dim3(64), 0, st, p, v, n);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// STEP FORM.  Weight-streaming GEMV for B <= 16 new tokens: y[b][n] = f(sum_k W[n][k] g(x)[b][k] + bias[n]).
+//   workgroup = one 16-row tile of W, KS waves splitting K; W in fragment order [tile][K/16][lane][4]: every wave load is one
+//   contiguous 1 KiB, all loads of a wave's K range issued before its MFMAs; x (optionally LayerNorm'ed) staged in LDS as the
+//   B operand (batch = the 16 MFMA columns, rows >= B read a zero row); partial tiles reduced across the waves in wave order
+//   (deterministic), then bias / activation / residual add / cache scatter.
+// =====================================================================================================================
+struct GemvArgs {
+    const float *x, *wf, *bias, *gamma, *beta;
+    float eps;
+    int act, mode;
+    float* y;
+    int ldy;
+    float *kc, *vc;
+    const int* pos;
+    int d, Tcap, B, K, N, XS;       // XS = LDS row stride of x
+};
+
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xs = lds;                                   // [B + 1][XS], row B = zeros
+    float* red = lds + (a.B + 1) * a.XS;               // [KS][64][4]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, r16 = lane & 15;
+    const int K = a.K, B = a.B, XS = a.XS;
+    for (int e = tid * 4; e < (B + 1) * K; e += 64 * KS * 4) {
+        const int b = e / K, k = e - b * K;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (b < B) v = *(const f32x4*)(a.x + (size_t)b * K + k);
+        *(f32x4*)(Xs + b * XS + k) = v;
+    }
+    __syncthreads();
+    if (a.gamma) {       // LayerNorm of every row, two-pass in LDS (one wave per row at a time)
+        for (int b = w; b < B; b += KS) {
+            float* xr = Xs + b * XS;
+            float s = 0.f;
+            for (int k = lane; k < K; k += 64) s += xr[k];
+            const float mean = wave_sum(s) / (float)K;
+            float q = 0.f;
+            for (int k = lane; k < K; k += 64) { const float dv = xr[k] - mean; q += dv * dv; }
+            const float rstd = 1.f / sqrtf(wave_sum(q) / (float)K + a.eps);
+            for (int k = lane; k < K; k += 64) xr[k] = (xr[k] - mean) * rstd * a.gamma[k] + a.beta[k];
+        }
+        __syncthreads();
+    }
+    const int tile = blockIdx.x;
+    const int nch = K / 16;                            // 16-wide k chunks of the row
+    const int cpw = nch / KS;                          // chunks per wave
+    const float* wp = a.wf + ((size_t)tile * nch + (size_t)w * cpw) * 256 + lane * 4;
+    const float* xb = Xs + (r16 < B ? r16 : B) * XS + w * cpw * 16 + 4 * g;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < cpw; c0 += 8) {
+        f32x4 wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u < cpw) wv[u] = *(const f32x4*)(wp + (size_t)(c0 + u) * 256);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u < cpw) {
+                const f32x4 xv = *(const f32x4*)(xb + (c0 + u) * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], xv[j], acc, 0, 0, 0);
+            }
+    }
+    *(f32x4*)(red + (w * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (w != 0) return;
+    f32x4 s = *(const f32x4*)(red + lane * 4);
+    for (int u = 1; u < KS; ++u) s += *(const f32x4*)(red + (u * 64 + lane) * 4);
+    const int b = r16;
+    if (b >= B) return;
+    const int p = a.mode == 2 ? a.pos[b] : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = tile * 16 + 4 * g + r;
+        if (n >= a.N) continue;
+        float v = act_f(s[r] + a.bias[n], a.act);
+        if (a.mode == 0) a.y[(size_t)b * a.ldy + n] = v;
+        else if (a.mode == 1) a.y[(size_t)b * a.ldy + n] += v;
+        else {
+            if (n < a.d) a.y[(size_t)b * a.ldy + n] = v;
+            else if (n < 2 * a.d) a.kc[((size_t)b * a.d + (n - a.d)) * a.Tcap + p] = v;
+            else a.vc[((size_t)b * a.Tcap + p) * a.d + (n - 2 * a.d)] = v;
+        }
+    }
+}
+
+hipError_t launch_gemv(const Gemv& g, hipStream_t st) {
+    if (g.B < 1 || g.B > 16 || g.K % 16 || g.K < 16) return hipErrorInvalidValue;
+    const int nch = g.K / 16;
+    int KS = 16;
+    while (KS > 1 && (nch % KS || nch / KS < 2)) KS >>= 1;     // >= 2 chunks per wave, K split evenly
+    if (nch % KS) KS = 1;
+    GemvArgs a{g.x, g.wf, g.bias, g.gamma, g.beta, g.eps, g.act, g.mode, g.y, g.ldy, g.kc, g.vc, g.pos, g.d, g.Tcap, g.B, g.K, g.N, g.K + 4};
+    const size_t lds = ((size_t)(g.B + 1) * a.XS + (size_t)KS * 256) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const dim3 grid(ceil_div_h(g.N, 16));
+    static std::atomic<unsigned long long> d16{0ull}, d8{0ull}, d4{0ull}, d2{0ull}, d1{0ull};
+    hipError_t e;
+#define FC_GEMV_CASE(ks, flag)                                                            \
+    if (KS == ks) {                                                                       \
+        if ((e = big_lds(gemv_kernel<ks>, flag)) != hipSuccess) return e;                 \
+        hipLaunchKernelGGL(gemv_kernel<ks>, grid, dim3(64 * ks), lds, st, a);             \
+        return hipGetLastError();                                                         \
+    }
+    FC_GEMV_CASE(16, d16)
+    FC_GEMV_CASE(8, d8)
+    FC_GEMV_CASE(4, d4)
+    FC_GEMV_CASE(2, d2)
+    FC_GEMV_CASE(1, d1)
+#undef FC_GEMV_CASE
+    return hipErrorInvalidValue;
+}
+
+__global__ __launch_bounds__(64) void layernorm_rows_kernel(float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float eps, int relu, float post_scale, int C) {
+    float* xr = x + (size_t)blockIdx.x * C;
+    const int lane = threadIdx.x;
+    float s = 0.f;
+    for (int k = lane; k < C; k += 64) s += xr[k];
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int k = lane; k < C; k += 64) { const float dv = xr[k] - mean; q += dv * dv; }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
+    for (int k = lane; k < C; k += 64) {
+        float o = (xr[k] - mean) * rstd * gamma[k] + beta[k];
+        if (relu) o = o > 0.f ? o : 0.f;
+        xr[k] = o * post_scale;
+    }
+}
+hipError_t launch_layernorm_rows(float* x, const float* gamma, const float* beta, float eps, int relu, float post_scale, int B, int C,
+                                 hipStream_t st) {
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(B), dim3(64), 0, st, x, gamma, beta, eps, relu, post_scale, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Step attention: one query (the newest token) of one (utterance, head) against the KV cache.  K cache feature-major
+// [dd][j] (lanes over keys: coalesced), V cache token-major [j][dd] (lanes over dims: coalesced); relative position of key j
+// is pos - j >= 0, read backwards from the position table.
+// ---------------------------------------------------------------------------------------------------------------------
+struct AttnStepArgs {
+    const float *q, *kc, *vc, *ptab, *bias_u, *bias_v;
+    const int* pos;
+    float* ctx;
+    int H, Tcap, R, PR;
+};
+
+template <int DK>
+__global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sc = lds;                 // [Tcap]
+    __shared__ float qu[DK], qv[DK];
+    __shared__ float wred[4];
+    __shared__ float part[4][DK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, d = a.H * DK;
+    const int p = a.pos[b], n = p + 1;
+    if (tid < DK) {
+        const float q = a.q[(size_t)b * d + h * DK + tid];
+        qu[tid] = q + a.bias_u[h * DK + tid];
+        qv[tid] = q + a.bias_v[h * DK + tid];
+    }
+    __syncthreads();
+    const float scale = 1.f / sqrtf((float)DK);
+    const float* kb = a.kc + ((size_t)b * d + h * DK) * a.Tcap;
+    const float* pb = a.ptab + (size_t)(h * DK) * a.PR + (a.R - 1) + p;      // column of relative position p - j is this - j
+    float m = -INFINITY;
+    for (int j = tid; j < n; j += 256) {
+        float ac = 0.f, bd = 0.f;
+#pragma unroll 8
+        for (int dd = 0; dd < DK; ++dd) {
+            ac = fmaf(qu[dd], kb[(size_t)dd * a.Tcap + j], ac);
+            bd = fmaf(qv[dd], pb[(size_t)dd * a.PR - j], bd);
+        }
+        const float s = (ac + bd) * scale;
+        sc[j] = s;
+        m = fmaxf(m, s);
+    }
+    m = wave_max(m);
+    if (lane == 0) wred[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int j = tid; j < n; j += 256) {
+        const float e = expf(sc[j] - m);
+        sc[j] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) wred[w] = s;
+    __syncthreads();
+    const float inv = 1.f / (wred[0] + wred[1] + wred[2] + wred[3]);
+    // ctx: wave w takes keys j = w, w + 4, ...; lanes = dims (DK = 32: the two half-waves take alternate keys)
+    constexpr int JPW = 64 / DK;                    // keys per wave trip
+    const int dd = lane % DK, jo = lane / DK;
+    const float* vb = a.vc + (size_t)b * a.Tcap * d + h * DK + dd;
+    float acc = 0.f;
+    for (int j = w * JPW + jo; j < n; j += 4 * JPW) acc = fmaf(sc[j], vb[(size_t)j * d], acc);
+    if (JPW == 2) acc += __shfl_xor(acc, 32, 64);
+    if (lane < DK) part[w][lane] = acc;
+    __syncthreads();
+    if (tid < DK) a.ctx[(size_t)b * d + h * DK + tid] = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * inv;
+}
+
+hipError_t launch_attn_step(const AttnStep& a, hipStream_t st) {
+    if (a.DK != 64 && a.DK != 32) return hipErrorInvalidValue;
+    AttnStepArgs k{a.q, a.kc, a.vc, a.ptab, a.bias_u, a.bias_v, a.pos, a.ctx, a.H, a.Tcap, a.R, a.PR};
+    const size_t lds = (size_t)a.Tcap * sizeof(float);
+    if (lds > 128 * 1024) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> d64{0ull}, d32{0ull};
+    hipError_t e;
+    if (a.DK == 64) {
+        if ((e = big_lds(attn_step_kernel<64>, d64)) != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_step_kernel<64>, dim3(a.H, a.B), dim3(256), lds, st, k);
+    } else {
+        if ((e = big_lds(attn_step_kernel<32>, d32)) != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_step_kernel<32>, dim3(a.H, a.B), dim3(256), lds, st, k);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-side token sampling (LauraGenModel.sampling_ids, laura_model.py:466-499; the loop body of decode_codec :537-542).
+// One workgroup per utterance, the nq groups in turn.  The reference samples from softmax(log_softmax(logits)[group]) =
+// softmax(logits[group]).  The multinomial draw is the inverse CDF of ONE uniform number per (utterance, step, group) from a
+// counter-based generator (Philox4x32-10 keyed by the caller's seed), so a generation is reproducible from its seed and never
+// leaves the device; torch.multinomial's own generator stream cannot be shared by any second implementation.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mulhi32(unsigned a, unsigned b) { return __umulhi(a, b); }
+__device__ float philox_uniform(unsigned long long seed, unsigned c0, unsigned c1, unsigned c2) {
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    unsigned x0 = c0, x1 = c1, x2 = c2, x3 = 0x5eedu;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned h0 = mulhi32(0xD2511F53u, x0), l0 = 0xD2511F53u * x0;
+        const unsigned h1 = mulhi32(0xCD9E8D57u, x2), l1 = 0xCD9E8D57u * x2;
+        const unsigned n0 = h1 ^ x1 ^ k0, n1 = l1, n2 = h0 ^ x3 ^ k1, n3 = l0;
+        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(x0 >> 8) * (1.0f / 16777216.0f);      // [0, 1)
+}
+
+struct SampleArgs {
+    const float* logits;
+    int K, nq, mode, ki;
+    float pf;
+    unsigned long long seed;
+    const int64_t* forced;
+    int max_steps;
+    int64_t* tokens;
+    int tok_stride;
+    const int* tok_off;
+    int *n_gen, *done, *n_done, *pos, *step;
+    float* logp_out;
+    const float* cb;
+    int D;
+    float* next_emb;
+    int B;
+};
+
+#define FC_SAMPLE_MAXV 2048      // candidates per group, padded to a power of two for the bitonic sort (K + 1 <= 2048)
+
+__global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
+    __shared__ float val[FC_SAMPLE_MAXV];
+    __shared__ int idx[FC_SAMPLE_MAXV];
+    __shared__ float csum[256];
+    __shared__ float wred[4];
+    __shared__ int wredi[4];
+    __shared__ int chosen[8];
+    __shared__ float sh_f[2];
+    __shared__ int sh_i[2];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int b = blockIdx.x;
+    const int G = a.K + 1, V = a.nq * G;
+    const int step = a.step[b];          // per-utterance sample counter (RNG stream position)
+    const int gen = a.n_gen[b];
+    const bool was_done = a.done[b] != 0;
+    const float* lg = a.logits + (size_t)b * V;
+    // log-softmax over the whole vocabulary of the step (TransformerEmbedLM.score, transformer_lm.py:309-311), when asked for
+    if (a.logp_out && !was_done && gen < a.max_steps) {
+        float m = -INFINITY;
+        for (int v = tid; v < V; v += 256) m = fmaxf(m, lg[v]);
+        m = wave_max(m);
+        if (lane == 0) wred[w] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        __syncthreads();
+        float s = 0.f;
+        for (int v = tid; v < V; v += 256) s += expf(lg[v] - m);
+        s = wave_sum(s);
+        if (lane == 0) wred[w] = s;
+        __syncthreads();
+        const float ls = logf(wred[0] + wred[1] + wred[2] + wred[3]);
+        float* o = a.logp_out + ((size_t)b * a.max_steps + gen) * V;
+        for (int v = tid; v < V; v += 256) o[v] = (lg[v] - m) - ls;
+        __syncthreads();
+    }
+    for (int k = 0; k < a.nq; ++k) {
+        const float* x = lg + k * G;
+        // ---- group maximum and its FIRST index (greedy: weighted_scores.topk(1))
+        float m = -INFINITY;
+        int mi = 0x7fffffff;
+        for (int v = tid; v < G; v += 256) {
+            const float xv = x[v];
+            if (xv > m) { m = xv; mi = v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float om = __shfl_xor(m, o, 64);
+            const int oi = __shfl_xor(mi, o, 64);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        if (lane == 0) { wred[w] = m; wredi[w] = mi; }
+        __syncthreads();
+        m = wred[0]; mi = wredi[0];
+        for (int u = 1; u < 4; ++u)
+            if (wred[u] > m || (wred[u] == m && wredi[u] < mi)) { m = wred[u]; mi = wredi[u]; }
+        __syncthreads();
+        int pick = mi;
+        if (a.mode != 0) {
+            // unnormalised probabilities exp(x - max) (the normaliser cancels in every mode except the nucleus threshold)
+            float s = 0.f;
+            for (int v = tid; v < FC_SAMPLE_MAXV; v += 256) {
+                const float e = v < G ? expf(x[v] - m) : -1.f;       // padding sorts last
+                val[v] = e;
+                idx[v] = v;
+                if (v < G) s += e;
+            }
+            s = wave_sum(s);
+            if (lane == 0) wred[w] = s;
+            __syncthreads();
+            const float total = wred[0] + wred[1] + wred[2] + wred[3];
+            int ncand = G;
+            if (a.mode >= 2) {
+                // descending by probability, ties by index (topk / a stable descending sort): bitonic sort of 2048 pairs
+                for (int kk = 2; kk <= FC_SAMPLE_MAXV; kk <<= 1)
+                    for (int j = kk >> 1; j > 0; j >>= 1) {
+                        __syncthreads();
+                        for (int i = tid; i < FC_SAMPLE_MAXV; i += 256) {
+                            const int l = i ^ j;
+                            if (l > i) {
+                                const bool up = (i & kk) == 0;      // "up" = descending order here
+                                const float vi = val[i], vl = val[l];
+                                const int ii = idx[i], il = idx[l];
+                                const bool i_first = vi > vl || (vi == vl && ii < il);
+                                if (up ? !i_first : i_first) { val[i] = vl; val[l] = vi; idx[i] = il; idx[l] = ii; }
+                            }
+                        }
+                    }
+                __syncthreads();
+                if (a.mode == 2) ncand = a.ki < G ? (a.ki < 1 ? 1 : a.ki) : G;
+                else {
+                    // nucleus: take entries while the running probability mass is < pf (the entry that crosses is kept)
+                    if (tid == 0) {
+                        float cum = 0.f;
+                        int n = 0;
+                        const float thr = a.pf * total;
+                        while (n < G && cum < thr) { cum += val[n]; ++n; }
+                        sh_i[0] = n < 1 ? 1 : n;
+                    }
+                    __syncthreads();
+                    ncand = sh_i[0];
+                }
+            }
+            // inverse CDF over the first ncand candidates in their order: chunk sums, then an exact walk inside the chunk
+            const int CH = (ncand + 255) / 256;
+            float cs = 0.f;
+            for (int i = tid * CH; i < (tid + 1) * CH && i < ncand; ++i) cs += val[i];
+            csum[tid] = cs;
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.f;
+                for (int i = 0; i < 256; ++i) tot += csum[i];
+                const float u = philox_uniform(a.seed, (unsigned)step, (unsigned)b, (unsigned)k);
+                const float target = u * tot;
+                float run = 0.f;
+                int c = 0;
+                while (c < 255 && run + csum[c] <= target) { run += csum[c]; ++c; }
+                int i = c * CH;
+                const int iend = (c + 1) * CH < ncand ? (c + 1) * CH : ncand;
+                while (i + 1 < iend && run + val[i] <= target) { run += val[i]; ++i; }
+                if (i >= ncand) i = ncand - 1;
+                sh_i[1] = idx[i];
+            }
+            __syncthreads();
+            pick = sh_i[1];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (a.forced && gen < a.max_steps) pick = (int)a.forced[((size_t)b * a.max_steps + gen) * a.nq + k];
+            chosen[k] = pick;
+        }
+        __syncthreads();
+    }
+    // ---- bookkeeping of decode_codec (laura_model.py:519-546): a step whose ids contain <eos> ends the utterance and is dropped
+    bool eos = false;
+    for (int k = 0; k < a.nq; ++k) eos = eos || chosen[k] == a.K;
+    const bool active = !was_done && gen < a.max_steps;
+    if (active && !eos) {
+        if (tid < a.nq) a.tokens[((size_t)b * a.tok_stride + a.tok_off[b] + gen) * a.nq + tid] = (int64_t)chosen[tid];
+        // next LM input: sum of the groups' codebook rows (build_llm_io -> calc_dense_vector)
+        for (int dd = tid; dd < a.D; dd += 256) {
+            float s = 0.f;
+            for (int k = 0; k < a.nq; ++k) {
+                const float v = a.cb[((size_t)k * a.K + chosen[k]) * a.D + dd];
+                s = k == 0 ? v : s + v;
+            }
+            a.next_emb[(size_t)b * a.D + dd] = s;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (active) {
+            if (eos) { a.done[b] = 1; atomicAdd(a.n_done, 1); }
+            else {
+                a.n_gen[b] = gen + 1;
+                if (step > 0) a.pos[b] += 1;      // step 0 samples from the prefix; later steps appended one token to the cache
+                if (gen + 1 >= a.max_steps) { a.done[b] = 1; atomicAdd(a.n_done, 1); }
+            }
+        }
+        a.step[b] = step + 1;
+    }
+}
+
+hipError_t launch_sample(const Sample& s, hipStream_t st) {
+    if (s.K + 1 > FC_SAMPLE_MAXV || s.nq > 8 || s.nq < 1) return hipErrorInvalidValue;
+    SampleArgs a{s.logits, s.K, s.nq, s.mode, s.ki, s.pf, s.seed, s.forced, s.max_steps, s.tokens, s.tok_stride, s.tok_off, s.n_gen,
+                 s.done, s.n_done, s.pos, s.step, s.logp_out, s.cb, s.D, s.next_emb, s.B};
+    hipLaunchKernelGGL(sample_kernel, dim3(s.B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace laura
+}  // namespace fc

@@ -212,3 +212,110 @@ def make_checkpoint(out_dir: str, name: str = "ds640", seed: int = 0,
         return write_checkpoint(out_dir, cfg, make_freq_state_dict(cfg, seed))
     arch = arch_from_config(cfg)
     return write_checkpoint(out_dir, cfg, make_state_dict(arch, seed, codebook_sigma_decay))
+
+
+# ---- LauraTTS checkpoints (funcodec/models/audio_generation/laura_model.py): same idea for the text -> codec-token model ---------
+def laura_plan(cfg: Dict[str, Any]) -> list:
+    """(key, shape) of every tensor the generation path of a LauraGenModel checkpoint holds, in state_dict order
+    (Text2AudioGenTask.build_model, funcodec/tasks/text2audio_generation.py:202-247).  The model's private training-time
+    quantiser (`quantizer.rq.model.*`, laura_model.py:141-151) is not on the inference path and is left out."""
+    from .laura_config import laura_spec_from_config
+    s = laura_spec_from_config(cfg)
+    plan = []
+
+    def stack(prefix, st):
+        d, dk = st.d_model, st.d_model // st.heads
+        plan.append((f"{prefix}.embed.0.weight", (d, st.idim)))
+        plan.append((f"{prefix}.embed.0.bias", (d,)))
+        plan.append((f"{prefix}.embed.1.weight", (d,)))
+        plan.append((f"{prefix}.embed.1.bias", (d,)))
+        for i in range(st.layers):
+            p = f"{prefix}.encoders.{i}"
+            plan.append((f"{p}.self_attn.pos_bias_u", (st.heads, dk)))
+            plan.append((f"{p}.self_attn.pos_bias_v", (st.heads, dk)))
+            for n in ("linear_q", "linear_k", "linear_v", "linear_out"):
+                plan.append((f"{p}.self_attn.{n}.weight", (d, d)))
+                plan.append((f"{p}.self_attn.{n}.bias", (d,)))
+            plan.append((f"{p}.self_attn.linear_pos.weight", (d, d)))
+            plan.append((f"{p}.feed_forward.w_1.weight", (st.ff, d)))
+            plan.append((f"{p}.feed_forward.w_1.bias", (st.ff,)))
+            plan.append((f"{p}.feed_forward.w_2.weight", (d, st.ff)))
+            plan.append((f"{p}.feed_forward.w_2.bias", (d,)))
+            for n in (st.norm_names if st.norm_names[0] == "norm1" else (st.norm_names[1], st.norm_names[0])):
+                plan.append((f"{p}.{n}.weight", (d,)))
+                plan.append((f"{p}.{n}.bias", (d,)))
+        plan.append((f"{prefix}.after_norm.weight", (d,)))
+        plan.append((f"{prefix}.after_norm.bias", (d,)))
+
+    D = s.codebook_dim
+    stack("text_encoder", s.text_encoder)
+    plan.append(("text_enc_out_layer.weight", (D, s.text_encoder.d_model)))
+    plan.append(("text_enc_out_layer.bias", (D,)))
+    if s.vocab_size > 0:
+        plan.append(("token_embedding.weight", (s.vocab_size, s.input_size)))
+    plan.append(("lm_embedding.weight", (2, D)))
+    stack("codec_lm.encoder", s.codec_lm)
+    plan.append(("codec_lm.decoder.weight", (s.lm_vocab, s.codec_lm.d_model)))
+    plan.append(("codec_lm.decoder.bias", (s.lm_vocab,)))
+    stack("codec_encoder", s.codec_encoder)
+    plan.append(("codec_encoder_out_layer.weight", (D, s.codec_encoder.d_model)))
+    plan.append(("codec_encoder_out_layer.bias", (D,)))
+    plan.append(("quantizer_codebook.embed", (s.num_quantizers, s.codebook_size, D)))
+    return plan
+
+
+def make_laura_state_dict(cfg: Dict[str, Any], seed: int = 0, eos_bias=None) -> Dict[str, np.ndarray]:
+    """Seeded random LauraGenModel weights.  Linear layers: torch's default bound; LayerNorm gamma / beta randomised around
+    (1, 0); the relative-position biases and the codebook table at unit scale so that every term of the attention score and both
+    summed codebooks matter."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd: Dict[str, np.ndarray] = {}
+    for key, shape in laura_plan(cfg):
+        leaf = key.rsplit(".", 1)[-1]
+        if key == "quantizer_codebook.embed":
+            v = rng.standard_normal(shape)
+        elif key in ("lm_embedding.weight", "token_embedding.weight"):
+            v = rng.standard_normal(shape)
+        elif leaf in ("pos_bias_u", "pos_bias_v"):
+            v = 0.5 * rng.standard_normal(shape)
+        elif len(shape) == 1 and (".norm" in key or "after_norm" in key or ".embed.1." in key):
+            v = 1.0 + 0.1 * rng.standard_normal(shape) if leaf == "weight" else 0.1 * rng.standard_normal(shape)
+        else:
+            fan_in = shape[-1] if len(shape) == 2 else [s for k, s in laura_plan_fanin(cfg) if k == key][0]
+            b = 1.0 / np.sqrt(fan_in)
+            v = rng.uniform(-b, b, size=shape)
+        sd[key] = np.ascontiguousarray(v, dtype=np.float32)
+    sd["quantizer_codebook.codec_index_shift"] = (1024.0 * np.arange(32, dtype=np.float32))[None, None, :]
+    if eos_bias is not None:     # (group, value): raise that group's <eos> logit so that greedy generation ends inside the loop
+        from .laura_config import laura_spec_from_config
+        K = laura_spec_from_config(cfg).codebook_size
+        sd["codec_lm.decoder.bias"][eos_bias[0] * (K + 1) + K] += np.float32(eos_bias[1])
+    return sd
+
+
+def laura_plan_fanin(cfg: Dict[str, Any]) -> list:
+    """fan-in of every bias vector (= the input width of its Linear), for torch's default bias bound"""
+    shapes = dict(laura_plan(cfg))
+    out = []
+    for key, shape in shapes.items():
+        if key.endswith(".bias") and key[:-5] + ".weight" in shapes and len(shapes[key[:-5] + ".weight"]) == 2:
+            out.append((key, shapes[key[:-5] + ".weight"][1]))
+    return out
+
+
+def synthetic_text(cfg: Dict[str, Any], batch: int, lengths, seed: int = 77):
+    """Deterministic text-side inputs: embeddings [batch, max(lengths), input_size] (zero past each length) for an
+    embedding-input model, token ids [batch, max(lengths)] (int64, -1 past each length) for a token-list model."""
+    from .laura_config import laura_spec_from_config
+    s = laura_spec_from_config(cfg)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    L = int(max(lengths))
+    if s.vocab_size > 0:
+        ids = rng.integers(2, s.vocab_size, size=(batch, L)).astype(np.int64)
+        for b, n in enumerate(lengths):
+            ids[b, n:] = -1
+        return ids
+    x = rng.standard_normal((batch, L, s.input_size)).astype(np.float32)
+    for b, n in enumerate(lengths):
+        x[b, n:] = 0.0
+    return x

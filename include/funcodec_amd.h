@@ -26,7 +26,7 @@ extern "C" {
 #endif
 
 #define FC_MAX_RATIOS 8
-#define FC_ABI_VERSION 4
+#define FC_ABI_VERSION 5
 
 typedef struct fc_engine fc_engine;
 
@@ -221,6 +221,93 @@ int fc_format_codec_json(const int64_t* codes, int n_q, int B, int T, int b, int
 /* save_audio (codec_inference.py:153-161): peak-rescale to 0.99 (rescale != 0; else clamp to +-0.99), round(x * 32768) clamped to
  * int16, mono 16-bit PCM RIFF file.   wav HOST f32 [n] */
 int fc_write_wav_pcm16(const char* path, const float* wav, int n, int sample_rate, int rescale);
+
+/* ======================================================================================================================
+ * LauraTTS generation (ABI version 5; SURVEY.md §8f rank 3, BASELINE.json configs[4]): text -> conformer text encoder ->
+ * decoder-only rel-pos transformer LM sampling the first `predict_nq` codec groups autoregressively -> non-autoregressive
+ * conformer predicting the dense codec embedding -> fc_decode_emb of the codec engine above.
+ * Replaces, for inference, funcodec/models/audio_generation/laura_model.py (LauraGenModel.encode :186-202, decode_codec :501-548,
+ * cal_codec_emb :296-333 as syn_audio :550-567 calls it), funcodec/lm/transformer_lm.py (TransformerEmbedLM.score :266-313),
+ * funcodec/models/encoder/conformer_encoder.py / transformer_encoder.py (the three rel-pos stacks) and
+ * funcodec/modules/attention.py:212-308.  The reference re-scores the whole prefix for every token (no KV cache, batch 1, one
+ * host round trip per token); this engine keeps a KV cache, decodes a batch of <= 16 prompts per call and samples on the device.
+ * Same conventions as above: "dev" = device pointer, "host" = host pointer, fp32, int64 token ids, work enqueued on `stream`
+ * (fc_laura_decode_codec additionally synchronises the stream, see there). */
+typedef struct fc_laura fc_laura;
+
+/* one rel-pos self-attention stack: ConformerEncoder without CNN / macaron modules (conformer_encoder.py:317-532) or
+ * TransformerEncoder_s0 (transformer_encoder.py:424-654) */
+typedef struct fc_laura_stack {
+    int32_t idim, d_model, heads, ff, layers;
+    int32_t act;          /* FFN activation: 1 = ReLU (TransformerEncoder_s0), 2 = Swish (conformer) */
+    int32_t embed_relu;   /* ReLU after the input layer's LayerNorm (transformer_encoder.py:463-469) */
+    int32_t norm_style;   /* state_dict names of the block norms: 0 = norm_mha / norm_ff, 1 = norm1 / norm2 */
+} fc_laura_stack;
+
+typedef struct fc_laura_arch {
+    int32_t abi_version;            /* FC_ABI_VERSION */
+    int32_t input_size;             /* width of the text embeddings (T5: 1536) or of token_embedding */
+    int32_t vocab_size;             /* > 0: the checkpoint holds token_embedding [vocab_size][input_size] */
+    int32_t codebook_size;          /* 1024 (the reference's index shift is hard-wired to it, laura_model.py:29) */
+    int32_t codebook_dim;           /* 128 */
+    int32_t num_quantizers;         /* rows of quantizer_codebook.embed */
+    int32_t predict_nq;             /* codec groups the LM predicts per frame */
+    int32_t pos_emb_split;          /* model_conf.pos_emb_type: 1 = "split" (abs. positional encoding per part, laura_model.py:312-317), 0 = "uni" */
+    int32_t bidirectional_inputs;   /* codec_lm_conf.bidirectional_inputs (transformer_lm.py:286-288) */
+    int32_t max_positions;          /* longest sequence any stack will see (sizes the relative-position tables; <= 2048) */
+    fc_laura_stack text_encoder, codec_lm, codec_encoder;
+} fc_laura_arch;
+
+/* Text2AudioGenTask.build_model (funcodec/tasks/text2audio_generation.py:202-247) */
+int  fc_laura_create(const fc_laura_arch* arch, int device, fc_laura** out);
+void fc_laura_destroy(fc_laura* e);
+/* checkpoint contract, as fc_engine_*: state_dict names of LauraGenModel (host fp32 tensors in the reference's layout) */
+int  fc_laura_num_weights(const fc_laura* e);
+int  fc_laura_weight_info(const fc_laura* e, int i, const char** name, int64_t* dims);
+int  fc_laura_set_weight(fc_laura* e, const char* name, const float* host, const int64_t* dims, int ndim);
+int  fc_laura_finalize(fc_laura* e);
+/* device scratch for any call with B utterances, texts of <= L tokens, <= Cmax prompt / codec tokens and max_length new tokens */
+size_t fc_laura_workspace_bytes(const fc_laura* e, int B, int L, int Cmax, int max_length);
+
+/* LauraGenModel.encode (laura_model.py:186-202): text encoder + text_enc_out_layer.
+ *   text_emb  dev f32 [B][L][input_size] or NULL;  text_ids dev i64 [B][L] or NULL (token_embedding lookup,
+ *             bin/text2audio_inference.py:99-113; ids < 0 = padding): exactly one of the two
+ *   text_lens host i32 [B];   text_outs dev f32 [B][L][codebook_dim] (rows >= text_lens[b] zero) */
+int fc_laura_encode(fc_laura* e, const float* text_emb, const int64_t* text_ids, const int32_t* text_lens, int B, int L,
+                    float* text_outs, void* workspace, size_t workspace_bytes, void* stream);
+
+/* TransformerEmbedLM.score (transformer_lm.py:266-313) at EVERY position of [<sos>, text, <task>, codec...] in one pass
+ * (teacher forcing): logp[b][t] = log_softmax of the decoder output at position t, i.e. what decode_codec samples token
+ * t - text_lens[b] - 1 from.   codec dev i64 [B][Cmax][predict_nq] or NULL, codec_lens host i32 [B] or NULL;
+ * logp dev f32 [B][Tseq][vocab], Tseq >= max_b(text_lens[b] + 2 + codec_lens[b]), vocab = predict_nq * (codebook_size + 1) */
+int fc_laura_lm_logprobs(fc_laura* e, const float* text_outs, const int32_t* text_lens, int B, int L, const int64_t* codec,
+                         const int32_t* codec_lens, int Cmax, float* logp, int Tseq, void* workspace, size_t workspace_bytes, void* stream);
+
+/* LauraGenModel.decode_codec (laura_model.py:501-548) for a batch: prefix pass, then one KV-cached step per token, sampled on the device.
+ *   continual  dev i64 [B][Cmax][predict_nq] or NULL, cont_lens host i32 [B] or NULL: prompt tokens (zero-shot continuation)
+ *   sampling_mode 0 greedy (sampling=False) | 1 softmax (True) | 2 top-k (int, sampling_k) | 3 nucleus (float, sampling_p)
+ *   seed       counter-based generator key; the same (seed, inputs) reproduce the same tokens
+ *   forced     dev i64 [B][max_length][predict_nq] or NULL: teacher forcing (sampled ids are replaced by these)
+ *   tokens     dev i64 [B][Cmax + max_length][predict_nq]: prompt tokens followed by the generated ones (<eos> step dropped)
+ *   out_lens   host i32 [B]: valid rows of tokens[b] (filled after an internal stream synchronise, like the reference's .item())
+ *   step_logp  dev f32 [B][max_length][vocab] or NULL: the log-probability vector every step sampled from
+ * Utterances end at <eos> (any group) or after max_length steps; the call ends when all have. */
+int fc_laura_decode_codec(fc_laura* e, const float* text_outs, const int32_t* text_lens, int B, int L, const int64_t* continual,
+                          const int32_t* cont_lens, int Cmax, int max_length, int sampling_mode, int sampling_k, float sampling_p,
+                          uint64_t seed, const int64_t* forced, int64_t* tokens, int32_t* out_lens, float* step_logp,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* LauraGenModel.cal_codec_emb (laura_model.py:296-333) on one-hot probabilities, as syn_audio (:550-567) calls it:
+ *   codec dev i64 [B][Cmax][nq_cols] (the first predict_nq columns are used), codec_lens host i32 [B]
+ *   emb   dev f32 [B][Cmax][codebook_dim] (rows >= codec_lens[b] zero): the input of fc_decode_emb */
+int fc_laura_codec_emb(fc_laura* e, const float* text_outs, const int32_t* text_lens, int B, int L, const int64_t* codec, int nq_cols,
+                       const int32_t* codec_lens, int Cmax, float* emb, void* workspace, size_t workspace_bytes, void* stream);
+
+/* per-op entry point (tests pin each Linear against torch.nn.functional.linear): `name` = state_dict prefix of a Linear
+ * ("codec_lm.encoder.encoders.3.feed_forward.w_1", "text_enc_out_layer", ...; "<block>.self_attn.linear_qkv" = the fused q/k/v).
+ * x dev f32 [B][T][in], y dev f32 [B][T][out].  step_form != 0: through the decoding step's GEMV (LM layers only, B*T <= 16). */
+int fc_laura_linear(fc_laura* e, const char* name, const float* x, int B, int T, int step_form, float* y,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }
