@@ -7,7 +7,7 @@ import os
 from . import build as _build
 
 FC_MAX_RATIOS = 8
-FC_ABI_VERSION = 4
+FC_ABI_VERSION = 5
 
 
 class FcArch(C.Structure):
@@ -38,6 +38,19 @@ class FcProf(C.Structure):
 
 
 FC_PROF_CLASSES = 48
+
+
+class FcLauraStack(C.Structure):
+    _fields_ = [("idim", C.c_int32), ("d_model", C.c_int32), ("heads", C.c_int32), ("ff", C.c_int32), ("layers", C.c_int32),
+                ("act", C.c_int32), ("embed_relu", C.c_int32), ("norm_style", C.c_int32)]
+
+
+class FcLauraArch(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("input_size", C.c_int32), ("vocab_size", C.c_int32), ("codebook_size", C.c_int32),
+                ("codebook_dim", C.c_int32), ("num_quantizers", C.c_int32), ("predict_nq", C.c_int32), ("pos_emb_split", C.c_int32),
+                ("bidirectional_inputs", C.c_int32), ("max_positions", C.c_int32),
+                ("text_encoder", FcLauraStack), ("codec_lm", FcLauraStack), ("codec_encoder", FcLauraStack)]
+
 
 # every symbol include/funcodec_amd.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
@@ -72,6 +85,21 @@ SYMBOLS = {
     "fc_write_wav_pcm16": (C.c_int, [C.c_char_p, _P, C.c_int, C.c_int, C.c_int]),
     "fc_overlap_add": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "fc_engine_status": (C.c_int, [_P, C.POINTER(C.c_uint)]),
+    # LauraTTS generation (ABI version 5)
+    "fc_laura_create": (C.c_int, [C.POINTER(FcLauraArch), C.c_int, C.POINTER(_P)]),
+    "fc_laura_destroy": (None, [_P]),
+    "fc_laura_num_weights": (C.c_int, [_P]),
+    "fc_laura_weight_info": (C.c_int, [_P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
+    "fc_laura_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
+    "fc_laura_finalize": (C.c_int, [_P]),
+    "fc_laura_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "fc_laura_encode": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "fc_laura_lm_logprobs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P, C.c_size_t, _P]),
+    "fc_laura_decode_codec": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.c_uint64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "fc_laura_codec_emb": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
+    "fc_laura_linear": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
+    "fc_laura_debug_probe": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

@@ -15,11 +15,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libfuncodec_amd.so")
 OBJ_DIR = os.path.join(CSRC, "_obj")
-HEADERS = ["kernels.h", "conv_kernel.h", os.path.join("..", "..", "include", "funcodec_amd.h")]
+HEADERS = ["kernels.h", "conv_kernel.h", "laura_kernels.h", os.path.join("..", "..", "include", "funcodec_amd.h")]
 
 
 def sources():
-    return ["kernels.hip", "engine.hip", "freq_kernels.hip"] + sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "conv_tile_*.hip")))
+    return ["kernels.hip", "engine.hip", "freq_kernels.hip", "laura.hip", "laura_kernels.hip"] + sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "conv_tile_*.hip")))
 
 
 def _hipcc() -> str:

@@ -1505,6 +1505,8 @@ extern "C" {
 
 int fc_abi_version(void) { return FC_ABI_VERSION; }
 const char* fc_last_error(void) { return g_err.c_str(); }
+// the other translation units of the library (laura.hip) report through the same thread-local message
+void fc_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }
 
 int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (!arch || !out) return fail("null argument");
@@ -1920,9 +1922,10 @@ int fc_write_wav_pcm16(const char* path, const float* wav, int n, int sample_rat
     const float limit = 0.99f;
     float mx = 0.f;
     for (int i = 0; i < n; ++i) { const float a = fabsf(wav[i]); if (a > mx) mx = a; }
-    // torch: wav * min(limit / mx, 1) (python float min -> float32 multiply), else clamp(-limit, limit)
+    // torch: wav * min(limit / mx, 1), else clamp(-limit, limit).  `limit / mx` with a 0-dim tensor mx is Tensor.__rtruediv__ =
+    // mx.reciprocal() * limit, two fp32 roundings (1 ulp off limit / mx for about a quarter of all peaks)
     float mul = 1.f;
-    if (rescale && mx > 0.f) { const float r = limit / mx; mul = r < 1.f ? r : 1.f; }
+    if (rescale && mx > 0.f) { const float r = (1.0f / mx) * limit; mul = r < 1.f ? r : 1.f; }
     std::vector<int16_t> pcm((size_t)n);
     for (int i = 0; i < n; ++i) {
         float v = wav[i];

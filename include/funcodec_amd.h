@@ -309,6 +309,12 @@ int fc_laura_codec_emb(fc_laura* e, const float* text_outs, const int32_t* text_
 int fc_laura_linear(fc_laura* e, const char* name, const float* x, int B, int T, int step_form, float* y,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* debugging aid, not part of the path: the NEXT full-sequence stack runs of this thread copy one intermediate tensor (feature-major
+ * [B][rows][T padded to 4]) to dev_dst.  stack 0 text_encoder / 1 codec_lm / 2 codec_encoder (-1 any); what 0 = stream after the input
+ * layer, 1 = attention-norm output of block `layer`, 2 = its q/k/v, 3 = its attention context, 5 = residual stream at the entry of
+ * block `layer` (layer = number of blocks: before after_norm).  dev_dst NULL switches it off. */
+int fc_laura_debug_probe(void* dev_dst, size_t cap_bytes, int stack, int layer, int what);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,47 @@ class Stack:
         y = torch.relu(y) if self.s.act == "relu" else y * torch.sigmoid(y)
         return F.linear(y, self.w(f"{pre}.w_2.weight"), self.w(f"{pre}.w_2.bias"))
 
+    def trace(self, x: torch.Tensor, mask: torch.Tensor) -> dict:
+        """Intermediates of forward() for the engine's debug probe (tools/laura_debug.py): keys (what, layer) like
+        fc_laura_debug_probe -- 0 = stream after the input layer, 1 = attention-norm output, 2 = q/k/v stacked on the feature axis,
+        3 = attention context before linear_out, 5 = residual stream at block entry (layer = n_blocks: before after_norm)."""
+        h, d = self.s.heads, self.s.d_model
+        n_att, n_ff = self.s.norm_names
+        out = {}
+        x, pos_emb = self.embed(x)
+        out[(0, 0)] = x
+        for i in range(self.s.layers):
+            out[(5, i)] = x
+            y = F.layer_norm(x, (d,), self.w(f"encoders.{i}.{n_att}.weight"), self.w(f"encoders.{i}.{n_att}.bias"), 1e-12)
+            out[(1, i)] = y
+            pre = f"encoders.{i}.self_attn"
+            out[(2, i)] = torch.cat([F.linear(y, self.w(f"{pre}.linear_{k}.weight"), self.w(f"{pre}.linear_{k}.bias")) for k in "qkv"], -1)
+            att = self.attention(i, y, pos_emb, mask)
+            # context = linear_out^-1 is not available; recompute it the way attention() does
+            out[(3, i)] = self._context(i, y, pos_emb, mask)
+            x = x + att
+            y = F.layer_norm(x, (d,), self.w(f"encoders.{i}.{n_ff}.weight"), self.w(f"encoders.{i}.{n_ff}.bias"), 1e-12)
+            x = x + self.ffn(i, y)
+        out[(5, self.s.layers)] = x
+        return out
+
+    def _context(self, i, x, pos_emb, mask):
+        h, d = self.s.heads, self.s.d_model
+        dk = d // h
+        pre = f"encoders.{i}.self_attn"
+        nb = x.size(0)
+        q = F.linear(x, self.w(f"{pre}.linear_q.weight"), self.w(f"{pre}.linear_q.bias")).view(nb, -1, h, dk)
+        k = F.linear(x, self.w(f"{pre}.linear_k.weight"), self.w(f"{pre}.linear_k.bias")).view(nb, -1, h, dk).transpose(1, 2)
+        v = F.linear(x, self.w(f"{pre}.linear_v.weight"), self.w(f"{pre}.linear_v.bias")).view(nb, -1, h, dk).transpose(1, 2)
+        p = F.linear(pos_emb, self.w(f"{pre}.linear_pos.weight")).view(pos_emb.size(0), -1, h, dk).transpose(1, 2)
+        q_u = (q + self.w(f"{pre}.pos_bias_u")).transpose(1, 2)
+        q_v = (q + self.w(f"{pre}.pos_bias_v")).transpose(1, 2)
+        scores = (torch.matmul(q_u, k.transpose(-2, -1)) + rel_shift(torch.matmul(q_v, p.transpose(-2, -1)))) / math.sqrt(dk)
+        m = mask.unsqueeze(1).eq(0)
+        scores = scores.masked_fill(m, float(np.finfo(np.float32).min))
+        attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
+        return torch.matmul(attn, v).transpose(1, 2).contiguous().view(nb, -1, d)
+
     def forward(self, x: torch.Tensor, mask: torch.Tensor, return_layers: bool = False):
         """x [B, T, idim], mask [B, 1 or T, T] (True = attend).  LayerNorm eps 1e-12 (funcodec/modules/layer_norm.py:22)."""
         d = self.s.d_model

@@ -201,6 +201,13 @@ def main():
         with open(path, "wt") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
 
+    if only is None or "keys" in only:
+        # names and shapes of the REAL model's state_dict for the recipe: the checkpoint-contract fixture of tests/test_laura.py
+        cfg = laura_recipe_config("laura")
+        model = build_reference_model(cfg, make_laura_state_dict(cfg, 0))
+        with open(os.path.join(GOLD, "state_dict_keys_laura.json"), "wt") as f:
+            json.dump({k: list(v.shape) for k, v in model.state_dict().items()}, f, indent=0, sort_keys=True)
+
     for c in CASES:
         if only is None or c[0] in only:
             manifest["cases"][c[0]] = run_case(*c)
