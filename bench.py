@@ -138,6 +138,222 @@ def pmc_traffic(kernel: str):
     return None
 
 
+def kernel_rooflines(prof, prof_steps):
+    """Per-kernel-class table of a fc_engine_profile pass + the two roofline objects (dominant MFMA-bound conv class against the
+    fp32 matrix peak; the HBM-bound thin classes against 8 TB/s)."""
+    out = {}
+    kern = []
+    for p in prof:
+        if p["launches"] == 0:
+            continue
+        ms = p["total_ms"]
+        tfl = p["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else None
+        gbs = p["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 and p["bytes"] else None
+        # which roof binds this class: algorithmic intensity against the ridge (157.3 TF / 8 TB/s = 19.7 FLOP/B)
+        bound = None
+        if p["bytes"] and p["kernel"].startswith(CONV_CLASSES):
+            bound = "mfma" if p["flops"] / p["bytes"] >= RIDGE else "hbm"
+        kern.append({"kernel": p["kernel"], "launches_per_step": p["launches"] // prof_steps,
+                     "ms_per_step": round(ms / prof_steps, 3),
+                     "avg_us_per_launch": round(ms * 1e3 / p["launches"], 2),
+                     "tflops": round(tfl, 2) if tfl else None,
+                     "alg_gbs": round(gbs, 1) if gbs else None,
+                     "bound": bound,
+                     "f32_frac": round(tfl / PEAK_F32_TFLOPS, 4) if tfl else None,
+                     "hbm_frac": round(gbs / 1e3 / PEAK_HBM_TBS, 4) if gbs else None})
+    convs = [k for k in kern if k["kernel"].startswith(CONV_CLASSES)]
+    mfma_bound = [k for k in convs if k["bound"] != "hbm"]
+    if mfma_bound:
+        dom = max(mfma_bound, key=lambda k: k["ms_per_step"])
+        conv_ms = sum(k["ms_per_step"] for k in convs)
+        conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith(CONV_CLASSES)) / prof_steps
+        traffic = pmc_traffic(dom["kernel"])
+        out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
+                           "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(dom["tflops"] / PEAK_F32_TFLOPS, 4),
+                           "traffic": (traffic or {}).get("bytes_per_launch"), "traffic_detail": traffic,
+                           "algorithmic_bytes_per_launch": round(dom["alg_gbs"] * 1e9 * dom["avg_us_per_launch"] * 1e-6) if dom["alg_gbs"] else None,
+                           "avg_us_per_launch": dom["avg_us_per_launch"],
+                           "launches_per_step": dom["launches_per_step"],
+                           "hbm_alg_gbs": dom["alg_gbs"],
+                           "all_conv_instantiations": {"ms_per_step": round(conv_ms, 3),
+                                                       "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                                       "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)},
+                           "note": "fp32-input MFMA (exact fp32, peak = fp32 vector peak); achieved = algorithmic FLOPs of this kernel's "
+                                   f"launches / sum of their HIP-event durations over a SEPARATE {prof_steps}-step pass (not the timed region)"}
+    hbm = [k for k in convs if k["bound"] == "hbm"]
+    if hbm:   # the HBM-bound (thin, C <= 64) classes: north_star's roof
+        hdom = max(hbm, key=lambda k: k["ms_per_step"])
+        hb_ms = sum(k["ms_per_step"] for k in hbm)
+        hb_by = sum(p["bytes"] for p in prof if any(p["kernel"] == k["kernel"] for k in hbm)) / prof_steps
+        htr = pmc_traffic(hdom["kernel"])
+        out["roofline_hbm"] = {"bound": "hbm", "kernel": hdom["kernel"], "achieved": hdom["alg_gbs"], "peak": PEAK_HBM_TBS * 1e3,
+                               "unit": "GB/s", "frac": hdom["hbm_frac"], "traffic": (htr or {}).get("bytes_per_launch"),
+                               "avg_us_per_launch": hdom["avg_us_per_launch"], "launches_per_step": hdom["launches_per_step"],
+                               "all_hbm_bound_conv_classes": {"ms_per_step": round(hb_ms, 3),
+                                                              "alg_gbs": round(hb_by / (hb_ms * 1e-3) / 1e9, 1),
+                                                              "frac": round(hb_by / (hb_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}}
+    out["kernels"] = kern
+    return out
+
+
+def freqcodec_side(config: str = "freqmpgr1", utts: int = 64, micro: int = 32, steps: int = 5, warmup: int = 2):
+    """Side measurement of BASELINE.json configs[3] (STFT-domain FreqCodec, batch 64 x 10 s on one GPU): the recipe net with
+    conv_group_ratio = tr_conv_group_ratio = 1 (the grouped, bandwidth-bound shape of the released "gr1" model)."""
+    from funcodec_amd.config import arch_from_config, recipe_config
+    from funcodec_amd.model import EncodecMI355X
+    from funcodec_amd.synth import make_freq_state_dict, synthetic_audio
+    cfg = recipe_config(config)
+    arch = arch_from_config(cfg)
+    model = EncodecMI355X(arch, "cuda:0")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, 0).items()})
+    eng = model.engine
+    eng.micro_batch = max(eng.micro_batch, micro)
+    wav = torch.from_numpy(synthetic_audio(utts, SAMPLES, 1234)).cuda()
+    n_q = arch.num_quantizers
+
+    def step():
+        for i in range(0, utts, micro):
+            r = eng.encode_decode(wav[i:i + micro], n_q, use_scale=True)
+        return r
+
+    eng.set_profiling(False)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.check_status()
+    assert bool(torch.isfinite(r["recon"]).all())
+    eng.set_profiling(True)
+    psteps = max(1, min(3, steps))
+    for _ in range(psteps):
+        eng.encode_decode(wav[:micro], n_q, use_scale=True)
+    prof = eng.read_profile()
+    eng.set_profiling(False)
+    work = eng.work(micro, SAMPLES, n_q)
+    nmb = utts / micro
+    tab = kernel_rooflines(prof, psteps)
+    out = {"workload": f"BASELINE.json configs[3] shape: FreqCodec mag_phase recipe + conv_group_ratio = tr_conv_group_ratio = 1 ({config}), "
+                       f"{utts} x 10 s on one GPU in engine calls of {micro}, n_q=32, run_mod=inference",
+           "value": round(utts * SAMPLES / 16000.0 / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+           "whole_step": {"tflops": round(work["total_flops"] * nmb / dt / 1e12, 2),
+                          "alg_hbm_tbs": round(work["total_bytes"] * nmb / dt / 1e12, 3),
+                          "frac_of_hbm_peak": round(work["total_bytes"] * nmb / dt / 1e12 / PEAK_HBM_TBS, 4)},
+           "roofline_hbm": tab.get("roofline_hbm"), "roofline": tab.get("roofline"),
+           "kernels": sorted(tab["kernels"], key=lambda k: -k["ms_per_step"])[:12]}
+    del model, eng
+    torch.cuda.empty_cache()
+    return out
+
+
+def laura_side(batch: int = 8, text_len: int = 100, prompt_frames: int = 75, new_frames: int = 250, steps: int = 3, warmup: int = 1,
+               cpu_sample: bool = True):
+    """Side measurement of BASELINE.json configs[4]: LauraTTS zero-shot generation, batch = 8 prompts on one GPU.  One step = the
+    whole Text2Audio flow for the batch with device-resident inputs: text encoder -> autoregressive decode_codec (prompt tokens +
+    `new_frames` new frames per prompt, top-k 25 sampling like the recipe's --sampling 25) -> fine codec predictor -> ds640 codec
+    decoder (decode_emb).  Synthetic seeded checkpoints of the recipe's sizes (88 M-parameter LauraTTS over a phoneme token list,
+    57.6 M ds640 codec)."""
+    from funcodec_amd.config import arch_from_config, recipe_config
+    from funcodec_amd.laura import LauraGenMI355X
+    from funcodec_amd.laura_config import laura_recipe_config, laura_spec_from_config
+    from funcodec_amd.model import EncodecMI355X
+    from funcodec_amd.synth import make_laura_state_dict, make_state_dict, synthetic_text
+    lcfg = laura_recipe_config("lauraphn")
+    spec = laura_spec_from_config(lcfg)
+    ccfg = recipe_config("ds640")
+    arch = arch_from_config(ccfg)
+    csd = make_state_dict(arch, 0)
+    lsd = make_laura_state_dict(lcfg, 0)
+    lsd["quantizer_codebook.embed"] = csd["quantizer.rq.model.embed"][: spec.num_quantizers].copy()
+    # fixed work per step: a random-weight LM would sample <eos> at random frames; its logits are pushed out of reach so that every
+    # prompt generates exactly `new_frames` frames (a trained model ends at <eos>; the per-frame cost is what is measured)
+    for g_ in range(spec.predict_nq):
+        lsd["codec_lm.decoder.bias"][g_ * (spec.codebook_size + 1) + spec.codebook_size] = -1e9
+    codec = EncodecMI355X(arch, "cuda:0")
+    codec.load_state_dict({k: torch.from_numpy(v) for k, v in csd.items()})
+    m = LauraGenMI355X(spec, "cuda:0", max_positions=2048)
+    m.load_state_dict(lsd)
+    lens = [text_len - 3 * (i % 4) for i in range(batch)]                      # ragged texts
+    ids = torch.from_numpy(synthetic_text(lcfg, batch, lens, 77)).cuda()
+    g = torch.Generator().manual_seed(5)
+    cont = torch.randint(0, spec.codebook_size, (batch, prompt_frames, spec.predict_nq), generator=g).cuda()
+    cl = [prompt_frames] * batch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+
+    def step(seed):
+        ev[0].record()
+        outs, _ = m.encode(ids, torch.tensor(lens))
+        ev[1].record()
+        tokens, out_lens = m.engine.decode_codec(outs, lens, new_frames, sampling=25, seed=seed, continual=cont, continual_lengths=cl)
+        ev[2].record()
+        emb = m.engine.codec_emb(outs, lens, tokens, out_lens)
+        ev[3].record()
+        wav = codec.engine.decode_emb(emb[:, prompt_frames:])                   # exclude_prompt: only the new frames are synthesised
+        ev[4].record()
+        return tokens, out_lens, wav
+
+    for i in range(warmup):
+        step(100 + i)
+    torch.cuda.synchronize()
+    phases = [0.0] * 4
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tokens, out_lens, wav = step(200 + i)
+        torch.cuda.synchronize()
+        for k in range(4):
+            phases[k] += ev[k].elapsed_time(ev[k + 1])
+    dt = (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(wav).all()) and all(v == prompt_frames + new_frames for v in out_lens), out_lens
+    hop = 640
+    gen_audio_s = batch * new_frames * hop / 16000.0
+    lm, d, ff, V = spec.codec_lm, spec.codec_lm.d_model, spec.codec_lm.ff, spec.lm_vocab
+    w_bytes = 4.0 * (lm.layers * (4 * d * d + 2 * d * ff) + V * d + d * spec.codebook_dim)          # LM weights streamed per decoding step
+    kv_bytes = sum(4.0 * lm.layers * 2 * d * (l + 2 + prompt_frames + new_frames / 2.0) for l in lens)   # average KV-cache read per step
+    ar_ms = phases[1] / steps
+    ar_step_us = ar_ms * 1e3 / new_frames
+    step_flops = 2.0 * batch * (lm.layers * (4 * d * d + 2 * d * ff) + V * d)
+    out = {"workload": f"BASELINE.json configs[4]: LauraTTS zero-shot generation, batch {batch} prompts (texts of {min(lens)}-{max(lens)} phonemes, "
+                       f"{prompt_frames}-frame prompt audio tokens), {new_frames} new frames (= {new_frames * hop / 16000.0:.0f} s) per prompt, top-k 25 "
+                       "sampling on the device, KV cache; text encoder + LM + fine predictor + ds640 codec decoder, fp32",
+           "value": round(gen_audio_s / dt, 1), "unit": "generated audio-s per wall-s",
+           "tokens_per_s": round(batch * new_frames / dt, 1), "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+           "phases_ms": {"text_encoder": round(phases[0] / steps, 3), "decode_codec": round(ar_ms, 3),
+                         "codec_emb": round(phases[2] / steps, 3), "codec_decoder": round(phases[3] / steps, 3)},
+           "decode_step_us": round(ar_step_us, 2),
+           "roofline": {"bound": "hbm", "kernel": "decoding step (64 launches: weight-streaming MFMA GEMVs + KV-cache attention)",
+                        "achieved": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                        "frac": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_step": round(w_bytes + kv_bytes), "weights_bytes": round(w_bytes), "kv_bytes_avg": round(kv_bytes),
+                        "step_tflops": round(step_flops / (ar_step_us * 1e-6) / 1e12, 3)}}
+    if cpu_sample:
+        # the reference's CPU path for the same prompts: no KV cache, batch 1 (oracle = ATen-CPU restatement, pinned bit-exact).
+        # Bounded sample: ONE prompt, 6 new frames at the benchmark's prefix length; per-token cost grows with the prefix.
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from laura_oracle import LauraOracle
+        orc = LauraOracle(lcfg, lsd)
+        threads = min(16, torch.get_num_threads())
+        old = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            emb0 = orc.token_embed(ids[:1, : lens[0]].cpu())
+            to = orc.encode(emb0, [lens[0]])[0]
+            t1 = time.perf_counter()
+            orc.decode_codec(to, 6, sampling=False, continual=cont[0].cpu().tolist())
+            cpu_dt = time.perf_counter() - t1
+        torch.set_num_threads(old)
+        out["cpu_baseline"] = {"value": round(6 / cpu_dt, 2), "unit": "tokens/s (one prompt)", "cores": threads, "kind": "port",
+                               "sample": f"oracle/laura_oracle.py decode_codec, 1 prompt ({lens[0]} phonemes + {prompt_frames} prompt frames), 6 greedy "
+                                         "frames, whole prefix re-scored per token like the reference (no KV cache)",
+                               "gpu_tokens_per_s_per_prompt": round(new_frames / dt, 1)}
+    del m, codec
+    torch.cuda.empty_cache()
+    return out
+
+
 def transfer_times(wav_dev: torch.Tensor, codes_dev: torch.Tensor, reps: int = 5):
     """H2D of this rank's wav batch and D2H of its code indices through pinned host buffers (reported, never
     part of `value`: the C-ABI boundary takes device pointers)."""
@@ -169,10 +385,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-event-profile", action="store_true", help="skip the separate per-kernel HIP-event pass (no `roofline`)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of the separate per-kernel pass")
-    ap.add_argument("--workload", choices=("encodec", "freqcodec"), default="encodec",
-                    help="encodec = the contract metric (BASELINE.json configs[1] / [2]); freqcodec = side measurement of configs[3]")
+    ap.add_argument("--workload", choices=("encodec", "freqcodec", "freqcodec_gr1", "laura"), default="encodec",
+                    help="encodec = the contract metric (BASELINE.json configs[1] / [2]); freqcodec / freqcodec_gr1 = side measurement of "
+                         "configs[3]; laura = side measurement of configs[4]")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] side measurements of the default run")
     args = ap.parse_args()
     global CONFIG, MICRO_BATCH
+    if args.workload in ("laura", "freqcodec_gr1"):      # side measurements on their own (one JSON line)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
+        torch.cuda.set_device(0)
+        res = laura_side(steps=max(1, args.steps), warmup=max(1, args.warmup), cpu_sample=not args.no_cpu_baseline) if args.workload == "laura" \
+            else freqcodec_side(steps=max(1, args.steps), warmup=max(1, args.warmup))
+        print(json.dumps(res), flush=True)
+        return
     if args.workload == "freqcodec" and not is_freq():
         CONFIG = "freqmp"
     if is_freq() and not os.environ.get("FC_BENCH_MICRO"):
@@ -299,58 +525,20 @@ def main():
         }
         out["transfers"] = transfer_times(wav, r["codes"])
         if prof:
-            kern = []
-            for p in prof:
-                if p["launches"] == 0:
-                    continue
-                ms = p["total_ms"]
-                tfl = p["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else None
-                gbs = p["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 and p["bytes"] else None
-                # which roof binds this class: algorithmic intensity against the ridge (157.3 TF / 8 TB/s = 19.7 FLOP/B)
-                bound = None
-                if p["bytes"] and p["kernel"].startswith(CONV_CLASSES):
-                    bound = "mfma" if p["flops"] / p["bytes"] >= RIDGE else "hbm"
-                kern.append({"kernel": p["kernel"], "launches_per_step": p["launches"] // prof_steps,
-                             "ms_per_step": round(ms / prof_steps, 3),
-                             "avg_us_per_launch": round(ms * 1e3 / p["launches"], 2),
-                             "tflops": round(tfl, 2) if tfl else None,
-                             "alg_gbs": round(gbs, 1) if gbs else None,
-                             "bound": bound,
-                             "f32_frac": round(tfl / PEAK_F32_TFLOPS, 4) if tfl else None,
-                             "hbm_frac": round(gbs / 1e3 / PEAK_HBM_TBS, 4) if gbs else None})
-            convs = [k for k in kern if k["kernel"].startswith(CONV_CLASSES)]
-            dom = max((k for k in convs if k["bound"] != "hbm"), key=lambda k: k["ms_per_step"])
-            conv_ms = sum(k["ms_per_step"] for k in convs)
-            conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith(CONV_CLASSES)) / prof_steps
-            traffic = pmc_traffic(dom["kernel"])
-            out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
-                               "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(dom["tflops"] / PEAK_F32_TFLOPS, 4),
-                               "traffic": (traffic or {}).get("bytes_per_launch"), "traffic_detail": traffic,
-                               "algorithmic_bytes_per_launch": round(dom["alg_gbs"] * 1e9 * dom["avg_us_per_launch"] * 1e-6) if dom["alg_gbs"] else None,
-                               "avg_us_per_launch": dom["avg_us_per_launch"],
-                               "launches_per_step": dom["launches_per_step"],
-                               "hbm_alg_gbs": dom["alg_gbs"],
-                               "all_conv_instantiations": {"ms_per_step": round(conv_ms, 3),
-                                                           "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                                                           "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)},
-                               "note": "fp32-input MFMA (exact fp32, peak = fp32 vector peak); achieved = algorithmic FLOPs of this kernel's "
-                                       f"launches / sum of their HIP-event durations over a SEPARATE {prof_steps}-step pass (not the timed region)"}
-            hbm = [k for k in convs if k["bound"] == "hbm"]
-            if hbm:   # the HBM-bound (thin, C <= 64) classes: north_star's roof
-                hdom = max(hbm, key=lambda k: k["ms_per_step"])
-                hb_ms = sum(k["ms_per_step"] for k in hbm)
-                hb_by = sum(p["bytes"] for p in prof if any(p["kernel"] == k["kernel"] for k in hbm)) / prof_steps
-                htr = pmc_traffic(hdom["kernel"])
-                out["roofline_hbm"] = {"bound": "hbm", "kernel": hdom["kernel"], "achieved": hdom["alg_gbs"], "peak": PEAK_HBM_TBS * 1e3,
-                                       "unit": "GB/s", "frac": hdom["hbm_frac"], "traffic": (htr or {}).get("bytes_per_launch"),
-                                       "avg_us_per_launch": hdom["avg_us_per_launch"], "launches_per_step": hdom["launches_per_step"],
-                                       "all_hbm_bound_conv_classes": {"ms_per_step": round(hb_ms, 3),
-                                                                      "alg_gbs": round(hb_by / (hb_ms * 1e-3) / 1e9, 1),
-                                                                      "frac": round(hb_by / (hb_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}}
-            out["kernels"] = kern
+            out.update(kernel_rooflines(prof, prof_steps))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and CONFIG == "ds640" and not args.no_secondary:
+            # the next scope rows, measured AFTER the headline timing so that they cannot disturb it
+            del model, eng
+            torch.cuda.empty_cache()
+            sec = {}
+            for key, fn in (("freqcodec_gr1_b64", lambda: freqcodec_side()), ("laura_tts_b8", lambda: laura_side(cpu_sample=not args.no_cpu_baseline))):
+                try:
+                    sec[key] = fn()
+                except Exception as ex:      # a side measurement must never take the contract line down with it
+                    sec[key] = {"error": f"{type(ex).__name__}: {ex}"}
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

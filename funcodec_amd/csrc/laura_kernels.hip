@@ -36,12 +36,12 @@ __device__ __forceinline__ float act_f(float v, int act) {
 
 // opt-in to > 64 KiB of dynamic LDS, once per (kernel, device)
 template <typename F>
-hipError_t big_lds(F kfn, std::atomic<unsigned long long>& done) {
+hipError_t big_lds(F kfn, std::atomic<unsigned long long>& done, int bytes = 160 * 1024) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_acquire) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if (e != hipSuccess) return e;
         done.fetch_or(bit, std::memory_order_release);
     }
@@ -722,10 +722,10 @@ hipError_t launch_attn_step(const AttnStep& a, hipStream_t st) {
     static std::atomic<unsigned long long> d64{0ull}, d32{0ull};
     hipError_t e;
     if (a.DK == 64) {
-        if ((e = big_lds(attn_step_kernel<64>, d64)) != hipSuccess) return e;
+        if ((e = big_lds(attn_step_kernel<64>, d64, 128 * 1024)) != hipSuccess) return e;     // + ~2 KiB of static LDS
         hipLaunchKernelGGL(attn_step_kernel<64>, dim3(a.H, a.B), dim3(256), lds, st, k);
     } else {
-        if ((e = big_lds(attn_step_kernel<32>, d32)) != hipSuccess) return e;
+        if ((e = big_lds(attn_step_kernel<32>, d32, 128 * 1024)) != hipSuccess) return e;
         hipLaunchKernelGGL(attn_step_kernel<32>, dim3(a.H, a.B), dim3(256), lds, st, k);
     }
     return hipGetLastError();
