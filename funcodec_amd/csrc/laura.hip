@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -542,31 +543,54 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     cx.check(lk::launch_sample(sm, cx.st), "sampling");
     const float xscale = sqrtf((float)d);
     int host_done = 0;
-    for (int s = 1; s < max_length && !cx.err; ++s) {
-        // one decoding step: the newest token of every utterance through the LM against its KV cache
-        cx.check(step_gemv(S.embed, nemb, B, nullptr, nullptr, 0.f, 0, 0, xs, d, cx.st), "embed GEMV");
-        cx.check(lk::launch_layernorm_rows(xs, S.eg, S.eb, 1e-5f, S.s.embed_relu, xscale, B, d, cx.st), "embed LayerNorm");
+    // one decoding step: the newest token of every utterance through the LM against its KV cache.  Every kernel reads its
+    // positions from device memory, so the launch sequence is identical from step to step.
+    auto run_step = [&](hipStream_t st) {
+        cx.check(step_gemv(S.embed, nemb, B, nullptr, nullptr, 0.f, 0, 0, xs, d, st), "embed GEMV");
+        cx.check(lk::launch_layernorm_rows(xs, S.eg, S.eb, 1e-5f, S.s.embed_relu, xscale, B, d, st), "embed LayerNorm");
         for (int i = 0; i < NL; ++i) {
             const Block& b = S.blocks[i];
             float* kc = kv.kc + (size_t)i * B * d * Tcap;
             float* vc = kv.vc + (size_t)i * B * d * Tcap;
-            cx.check(step_gemv(b.qkv, xs, B, b.n1g, b.n1b, 1e-12f, 0, 2, qb, d, cx.st, kc, vc, pos, d, Tcap), "QKV GEMV");
+            cx.check(step_gemv(b.qkv, xs, B, b.n1g, b.n1b, 1e-12f, 0, 2, qb, d, st, kc, vc, pos, d, Tcap), "QKV GEMV");
             lk::AttnStep a;
             a.q = qb; a.kc = kc; a.vc = vc; a.ptab = b.ptab; a.bias_u = b.bu; a.bias_v = b.bv; a.pos = pos; a.ctx = cb_;
             a.B = B; a.H = S.s.heads; a.DK = d / S.s.heads; a.Tcap = Tcap; a.R = e->R; a.PR = e->PR;
-            cx.check(lk::launch_attn_step(a, cx.st), "step attention");
-            cx.check(step_gemv(b.out, cb_, B, nullptr, nullptr, 0.f, 0, 1, xs, d, cx.st), "out GEMV");
-            cx.check(step_gemv(b.ff1, xs, B, b.n2g, b.n2b, 1e-12f, S.s.act, 0, hb, ff, cx.st), "FFN GEMV 1");
-            cx.check(step_gemv(b.ff2, hb, B, nullptr, nullptr, 0.f, 0, 1, xs, d, cx.st), "FFN GEMV 2");
+            cx.check(lk::launch_attn_step(a, st), "step attention");
+            cx.check(step_gemv(b.out, cb_, B, nullptr, nullptr, 0.f, 0, 1, xs, d, st), "out GEMV");
+            cx.check(step_gemv(b.ff1, xs, B, b.n2g, b.n2b, 1e-12f, S.s.act, 0, hb, ff, st), "FFN GEMV 1");
+            cx.check(step_gemv(b.ff2, hb, B, nullptr, nullptr, 0.f, 0, 1, xs, d, st), "FFN GEMV 2");
         }
-        cx.check(step_gemv(e->lm_decoder, xs, B, S.ag, S.ab, 1e-12f, 0, 0, lg, V, cx.st), "decoder GEMV");
-        cx.check(lk::launch_sample(sm, cx.st), "sampling");
-        if ((s & 15) == 15 && s + 1 < max_length) {      // all utterances finished? (one small read-back every 16 steps)
-            if (hipMemcpyAsync(&host_done, n_done, sizeof(int), hipMemcpyDeviceToHost, cx.st) != hipSuccess ||
-                hipStreamSynchronize(cx.st) != hipSuccess) { cx.err = 1; fail("decode_codec: status read-back failed"); break; }
-            if (host_done >= B) break;
+        cx.check(step_gemv(e->lm_decoder, xs, B, S.ag, S.ab, 1e-12f, 0, 0, lg, V, st), "decoder GEMV");
+        cx.check(lk::launch_sample(sm, st), "sampling");
+    };
+    auto all_done = [&]() -> bool {       // all utterances finished? (one small read-back)
+        if (hipMemcpyAsync(&host_done, n_done, sizeof(int), hipMemcpyDeviceToHost, cx.st) != hipSuccess ||
+            hipStreamSynchronize(cx.st) != hipSuccess) { cx.err = 1; fail("decode_codec: status read-back failed"); return true; }
+        return host_done >= B;
+    };
+    int s = 1;
+    if (s < max_length && !cx.err) { run_step(cx.st); ++s; }          // first step eagerly (also sets the kernels' LDS attributes)
+    // the remaining steps replay ONE captured HIP graph of the step (~64 small launches): the loop is launch-bound otherwise
+    static const bool graph_env = !(getenv("FC_LAURA_GRAPH") && atoi(getenv("FC_LAURA_GRAPH")) == 0);
+    hipGraphExec_t gexec = nullptr;
+    if (graph_env && cx.st != nullptr && max_length - s >= 4 && !cx.err) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(cx.st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            run_step(cx.st);
+            const hipError_t ec = hipStreamEndCapture(cx.st, &graph);
+            if (ec != hipSuccess || cx.err || hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess) gexec = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (cx.err) return 1;                                       // a launch failed while capturing
+            (void)hipGetLastError();
         }
     }
+    for (; s < max_length && !cx.err; ++s) {
+        if (gexec) cx.check(hipGraphLaunch(gexec, cx.st), "graph launch");
+        else run_step(cx.st);
+        if ((s & 15) == 15 && s + 1 < max_length && all_done()) break;
+    }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
     if (cx.err) return 1;
     std::vector<int> gen(B);
     HIP_TRY(hipMemcpyAsync(gen.data(), n_gen, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, cx.st));

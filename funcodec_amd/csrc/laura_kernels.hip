@@ -658,11 +658,18 @@ struct AttnStepArgs {
 
 template <int DK>
 __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
+    // Latency-bound (one query, a few hundred keys): everything is laid out so that a thread's loads are independent 16-byte
+    // pieces issued back to back.  Scores: wave w owns DK/4 of the dims, a lane 4 consecutive keys (K cache rows are key-
+    // contiguous; the position table is read backwards: key j sits at column R-1+pos-j); the 4 partial sums meet in LDS.
+    // Context: a thread owns 4 dims of every NG-th key (V cache rows are dim-contiguous).
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* sc = lds;                 // [Tcap]
+    const int T4 = a.Tcap;                           // multiple of 4
+    float* part = lds;                               // [4][T4]
+    float* sc = lds + 4 * T4;                        // [T4]
     __shared__ float qu[DK], qv[DK];
     __shared__ float wred[4];
-    __shared__ float part[4][DK];
+    constexpr int NG = 1024 / DK;                    // key groups of the context pass (16 for DK = 64, 32 for DK = 32)
+    __shared__ __attribute__((aligned(16))) float cred[NG][DK];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y, d = a.H * DK;
     const int p = a.pos[b], n = p + 1;
@@ -672,18 +679,34 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
         qv[tid] = q + a.bias_v[h * DK + tid];
     }
     __syncthreads();
+    constexpr int DW = DK / 4;                       // dims per wave
+    const float* kb = a.kc + ((size_t)b * d + h * DK + w * DW) * a.Tcap;
+    const float* pb = a.ptab + (size_t)(h * DK + w * DW) * a.PR + (a.R - 1) + p;
+    const int nquad = (n + 3) >> 2;
+    for (int qd = lane; qd < nquad; qd += 64) {
+        const int j0 = 4 * qd;
+        f32x4 kv[DW], pv[DW];
+#pragma unroll
+        for (int dd = 0; dd < DW; ++dd) {
+            kv[dd] = *(const f32x4*)(kb + (size_t)dd * a.Tcap + j0);
+            pv[dd] = *(const f32x4u*)(pb + (size_t)dd * a.PR - j0 - 3);     // columns of keys j0+3, j0+2, j0+1, j0
+        }
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dd = 0; dd < DW; ++dd) {
+            const float u = qu[w * DW + dd], v = qv[w * DW + dd];
+            acc[0] = fmaf(u, kv[dd][0], fmaf(v, pv[dd][3], acc[0]));
+            acc[1] = fmaf(u, kv[dd][1], fmaf(v, pv[dd][2], acc[1]));
+            acc[2] = fmaf(u, kv[dd][2], fmaf(v, pv[dd][1], acc[2]));
+            acc[3] = fmaf(u, kv[dd][3], fmaf(v, pv[dd][0], acc[3]));
+        }
+        *(f32x4*)(part + w * T4 + j0) = acc;
+    }
+    __syncthreads();
     const float scale = 1.f / sqrtf((float)DK);
-    const float* kb = a.kc + ((size_t)b * d + h * DK) * a.Tcap;
-    const float* pb = a.ptab + (size_t)(h * DK) * a.PR + (a.R - 1) + p;      // column of relative position p - j is this - j
     float m = -INFINITY;
     for (int j = tid; j < n; j += 256) {
-        float ac = 0.f, bd = 0.f;
-#pragma unroll 8
-        for (int dd = 0; dd < DK; ++dd) {
-            ac = fmaf(qu[dd], kb[(size_t)dd * a.Tcap + j], ac);
-            bd = fmaf(qv[dd], pb[(size_t)dd * a.PR - j], bd);
-        }
-        const float s = (ac + bd) * scale;
+        const float s = ((part[j] + part[T4 + j]) + (part[2 * T4 + j] + part[3 * T4 + j])) * scale;
         sc[j] = s;
         m = fmaxf(m, s);
     }
@@ -702,23 +725,36 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
     if (lane == 0) wred[w] = s;
     __syncthreads();
     const float inv = 1.f / (wred[0] + wred[1] + wred[2] + wred[3]);
-    // ctx: wave w takes keys j = w, w + 4, ...; lanes = dims (DK = 32: the two half-waves take alternate keys)
-    constexpr int JPW = 64 / DK;                    // keys per wave trip
-    const int dd = lane % DK, jo = lane / DK;
-    const float* vb = a.vc + (size_t)b * a.Tcap * d + h * DK + dd;
-    float acc = 0.f;
-    for (int j = w * JPW + jo; j < n; j += 4 * JPW) acc = fmaf(sc[j], vb[(size_t)j * d], acc);
-    if (JPW == 2) acc += __shfl_xor(acc, 32, 64);
-    if (lane < DK) part[w][lane] = acc;
+    // context
+    constexpr int NQ = DK / 4;                       // dim quads
+    const int dq = tid % NQ, jg = tid / NQ;
+    const float* vb = a.vc + (size_t)b * a.Tcap * d + h * DK + 4 * dq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int j = jg;
+    for (; j + 3 * NG < n; j += 4 * NG) {
+        const f32x4 v0 = *(const f32x4*)(vb + (size_t)j * d), v1 = *(const f32x4*)(vb + (size_t)(j + NG) * d);
+        const f32x4 v2 = *(const f32x4*)(vb + (size_t)(j + 2 * NG) * d), v3 = *(const f32x4*)(vb + (size_t)(j + 3 * NG) * d);
+        acc += sc[j] * v0;
+        acc += sc[j + NG] * v1;
+        acc += sc[j + 2 * NG] * v2;
+        acc += sc[j + 3 * NG] * v3;
+    }
+    for (; j < n; j += NG) acc += sc[j] * *(const f32x4*)(vb + (size_t)j * d);
+    *(f32x4*)&cred[jg][4 * dq] = acc;
     __syncthreads();
-    if (tid < DK) a.ctx[(size_t)b * d + h * DK + tid] = (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) * inv;
+    if (tid < DK) {
+        float o = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) o += cred[g][tid];
+        a.ctx[(size_t)b * d + h * DK + tid] = o * inv;
+    }
 }
 
 hipError_t launch_attn_step(const AttnStep& a, hipStream_t st) {
     if (a.DK != 64 && a.DK != 32) return hipErrorInvalidValue;
     AttnStepArgs k{a.q, a.kc, a.vc, a.ptab, a.bias_u, a.bias_v, a.pos, a.ctx, a.H, a.Tcap, a.R, a.PR};
-    const size_t lds = (size_t)a.Tcap * sizeof(float);
-    if (lds > 128 * 1024) return hipErrorInvalidValue;
+    const size_t lds = (size_t)5 * a.Tcap * sizeof(float);
+    if (lds > 120 * 1024 || a.Tcap % 4) return hipErrorInvalidValue;
     static std::atomic<unsigned long long> d64{0ull}, d32{0ull};
     hipError_t e;
     if (a.DK == 64) {
@@ -782,6 +818,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __shared__ int chosen[8];
     __shared__ float sh_f[2];
     __shared__ int sh_i[2];
+    __shared__ unsigned hist[256];
+    __shared__ float cval[256];
+    __shared__ int cidx[256];
+    __shared__ int ccount;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.x;
     const int G = a.K + 1, V = a.nq * G;
@@ -844,7 +884,67 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             __syncthreads();
             const float total = wred[0] + wred[1] + wred[2] + wred[3];
             int ncand = G;
-            if (a.mode >= 2) {
+            if (a.mode == 2 && a.ki <= 64) {
+                // top-k with a small k (the recipe samples with --sampling 25): radix-select the k-th largest logit (4 passes over
+                // 8-bit digits of the order-preserving integer image of the float), collect everything >= it, order those few by
+                // (probability descending, index ascending) with a counting rank -- no full sort of the 1025 logits
+                const int kk = a.ki < 1 ? 1 : a.ki;
+                unsigned lk[(FC_SAMPLE_MAXV + 255) / 256];
+                int nl = 0;
+                for (int v = tid; v < G; v += 256) {
+                    const unsigned u = __float_as_uint(x[v]);
+                    lk[nl++] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                }
+                unsigned prefix = 0u, mask = 0u;
+                int need = kk;
+                for (int shift = 24; shift >= 0; shift -= 8) {
+                    hist[tid] = 0u;
+                    __syncthreads();
+                    for (int i = 0; i < nl; ++i)
+                        if ((lk[i] & mask) == prefix) atomicAdd(&hist[(lk[i] >> shift) & 255u], 1u);
+                    __syncthreads();
+                    if (tid == 0) {
+                        int cum = 0, bin = 255;
+                        for (; bin > 0; --bin) {
+                            if (cum + (int)hist[bin] >= need) break;
+                            cum += (int)hist[bin];
+                        }
+                        sh_i[0] = bin;
+                        sh_i[1] = need - cum;
+                    }
+                    __syncthreads();
+                    prefix |= (unsigned)sh_i[0] << shift;
+                    need = sh_i[1];
+                    mask |= 255u << shift;
+                    __syncthreads();
+                }
+                if (tid == 0) ccount = 0;
+                __syncthreads();
+                {
+                    int i = 0;
+                    for (int v = tid; v < G; v += 256, ++i)
+                        if (lk[i] >= prefix) {
+                            const int slot = atomicAdd(&ccount, 1);
+                            if (slot < 256) { cval[slot] = val[v]; cidx[slot] = v; }
+                        }
+                }
+                __syncthreads();
+                const int nc = ccount < 256 ? ccount : 256;
+                float myv = 0.f;
+                int myi = 0, rank = 0;
+                if (tid < nc) {
+                    myv = cval[tid]; myi = cidx[tid];
+                    for (int c = 0; c < nc; ++c) {
+                        const float ov = cval[c];
+                        const int oi = cidx[c];
+                        rank += (ov > myv || (ov == myv && oi < myi)) ? 1 : 0;
+                    }
+                }
+                __syncthreads();
+                if (tid < nc) { val[rank] = myv; idx[rank] = myi; }
+                __syncthreads();
+                ncand = kk < nc ? kk : nc;
+            } else if (a.mode >= 2) {
                 // descending by probability, ties by index (topk / a stable descending sort): bitonic sort of 2048 pairs
                 for (int kk = 2; kk <= FC_SAMPLE_MAXV; kk <<= 1)
                     for (int j = kk >> 1; j > 0; j >>= 1) {

@@ -69,6 +69,7 @@ class LauraEngine:
         self._h = h
         self._ws: Optional[torch.Tensor] = None
         self._ws_need: Dict[tuple, int] = {}
+        self._side = None
 
     def _check(self, rc: int):
         if rc != 0:
@@ -186,10 +187,21 @@ class LauraEngine:
         logp = torch.zeros((B, max_length, self.spec.lm_vocab), dtype=torch.float32, device=self.device) if return_logp else None
         out_lens = (C.c_int32 * B)()
         ws = self._workspace(B, L, Cmax, max_length)
+        # the decoding loop replays a captured HIP graph of one step; the legacy default stream cannot be captured, so a caller on it
+        # is moved to a stream of the engine's own (ordered after / before the caller's stream; the call synchronises at its end anyway)
+        cur = torch.cuda.current_stream(self.device)
+        run = cur
+        if cur.cuda_stream == 0:
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+            run = self._side
+            run.wait_stream(cur)
         self._check(self.lib.fc_laura_decode_codec(self._h, _ptr(text_outs), _i32(text_lengths), B, L, _ptr(continual),
                                                    _i32(continual_lengths) if continual is not None else None, Cmax, int(max_length),
                                                    mode, k, p, int(seed) & (2 ** 64 - 1), _ptr(forced), _ptr(tokens), out_lens, _ptr(logp),
-                                                   _ptr(ws), ws.numel(), self._stream()))
+                                                   _ptr(ws), ws.numel(), C.c_void_p(run.cuda_stream)))
+        if run is not cur:
+            cur.wait_stream(run)
         lens = [int(v) for v in out_lens]
         return (tokens, lens, logp) if return_logp else (tokens, lens)
 
