@@ -102,6 +102,7 @@ struct fc_laura {
     Stack text_encoder, codec_lm, codec_encoder;
     Lin text_out, lm_decoder, codec_out;
     float *lm_emb = nullptr, *cb = nullptr, *tok_emb = nullptr, *pe_abs = nullptr;
+    float* lm_embed_wt = nullptr;      // codec_lm.encoder.embed.0.weight transposed [D][d] (the sampler's fused input layer)
     std::map<std::string, Lin*> lin_by_name;
     std::vector<void*> dev_allocs;
     int vocab() const { return arch.predict_nq * (arch.codebook_size + 1); }
@@ -487,8 +488,10 @@ int do_codec_emb(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* te
 }
 
 hipError_t step_gemv(const Lin& L, const float* x, int B, const float* gamma, const float* beta, float eps, int act, int mode, float* y,
-                     int ldy, hipStream_t st, float* kc = nullptr, float* vc = nullptr, const int* pos = nullptr, int d = 0, int Tcap = 0) {
+                     int ldy, hipStream_t st, float* kc = nullptr, float* vc = nullptr, const int* pos = nullptr, int d = 0, int Tcap = 0,
+                     const float* apart = nullptr, int H = 0, int DK = 0, int NS = 0) {
     lk::Gemv g;
+    g.apart = apart; g.H = H; g.DK = DK; g.NS = NS;
     g.x = x; g.wf = L.wf; g.bias = L.bias; g.gamma = gamma; g.beta = beta; g.eps = eps; g.act = act; g.mode = mode; g.y = y; g.ldy = ldy;
     g.kc = kc; g.vc = vc; g.pos = pos; g.d = d; g.Tcap = Tcap; g.B = B; g.K = L.cin; g.N = L.cout;
     return lk::launch_gemv(g, st);
@@ -522,7 +525,10 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     kv.vc = cx.alloc<float>((size_t)NL * B * d * Tcap);
     float* xs = cx.alloc<float>((size_t)16 * d);
     float* qb = cx.alloc<float>((size_t)16 * d);
-    float* cb_ = cx.alloc<float>((size_t)16 * d);
+    const int heads = S.s.heads, dkh = d / S.s.heads;
+    int NS = 256 / (B * heads);                 // key ranges per (utterance, head): fill the chip's 256 CUs
+    NS = NS < 1 ? 1 : (NS > 8 ? 8 : NS);
+    float* apart = cx.alloc<float>((size_t)16 * heads * 8 * (dkh + 2));
     float* hb = cx.alloc<float>((size_t)16 * ff);
     float* lg = cx.alloc<float>((size_t)16 * V);
     float* nemb = cx.alloc<float>((size_t)16 * D);
@@ -540,24 +546,25 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     sm.logits = lg; sm.B = B; sm.K = K; sm.nq = nq; sm.mode = mode; sm.ki = ki; sm.pf = pf; sm.seed = seed; sm.forced = forced;
     sm.max_steps = max_length; sm.tokens = tokens; sm.tok_stride = Cmax + max_length; sm.tok_off = cl; sm.n_gen = n_gen; sm.done = done;
     sm.n_done = n_done; sm.pos = pos; sm.step = step; sm.logp_out = step_logp; sm.cb = e->cb; sm.D = D; sm.next_emb = nemb;
+    // the sampler also runs the LM's input layer on the new token (Linear + LayerNorm + ReLU + x * sqrt(d)): xs is ready for block 0
+    sm.emb_wt = e->lm_embed_wt; sm.emb_bias = S.embed.bias; sm.emb_g = S.eg; sm.emb_b = S.eb; sm.dm = d; sm.emb_relu = S.s.embed_relu;
+    sm.xscale = sqrtf((float)d); sm.xs = xs;
     cx.check(lk::launch_sample(sm, cx.st), "sampling");
-    const float xscale = sqrtf((float)d);
     int host_done = 0;
     // one decoding step: the newest token of every utterance through the LM against its KV cache.  Every kernel reads its
     // positions from device memory, so the launch sequence is identical from step to step.
     auto run_step = [&](hipStream_t st) {
-        cx.check(step_gemv(S.embed, nemb, B, nullptr, nullptr, 0.f, 0, 0, xs, d, st), "embed GEMV");
-        cx.check(lk::launch_layernorm_rows(xs, S.eg, S.eb, 1e-5f, S.s.embed_relu, xscale, B, d, st), "embed LayerNorm");
         for (int i = 0; i < NL; ++i) {
             const Block& b = S.blocks[i];
             float* kc = kv.kc + (size_t)i * B * d * Tcap;
             float* vc = kv.vc + (size_t)i * B * d * Tcap;
             cx.check(step_gemv(b.qkv, xs, B, b.n1g, b.n1b, 1e-12f, 0, 2, qb, d, st, kc, vc, pos, d, Tcap), "QKV GEMV");
             lk::AttnStep a;
-            a.q = qb; a.kc = kc; a.vc = vc; a.ptab = b.ptab; a.bias_u = b.bu; a.bias_v = b.bv; a.pos = pos; a.ctx = cb_;
-            a.B = B; a.H = S.s.heads; a.DK = d / S.s.heads; a.Tcap = Tcap; a.R = e->R; a.PR = e->PR;
+            a.q = qb; a.kc = kc; a.vc = vc; a.ptab = b.ptab; a.bias_u = b.bu; a.bias_v = b.bv; a.pos = pos; a.part = apart; a.NS = NS;
+            a.B = B; a.H = heads; a.DK = dkh; a.Tcap = Tcap; a.R = e->R; a.PR = e->PR;
             cx.check(lk::launch_attn_step(a, st), "step attention");
-            cx.check(step_gemv(b.out, cb_, B, nullptr, nullptr, 0.f, 0, 1, xs, d, st), "out GEMV");
+            // linear_out reads the key-range partials and combines them while staging its input
+            cx.check(step_gemv(b.out, nullptr, B, nullptr, nullptr, 0.f, 0, 1, xs, d, st, nullptr, nullptr, nullptr, 0, 0, apart, heads, dkh, NS), "out GEMV");
             cx.check(step_gemv(b.ff1, xs, B, b.n2g, b.n2b, 1e-12f, S.s.act, 0, hb, ff, st), "FFN GEMV 1");
             cx.check(step_gemv(b.ff2, hb, B, nullptr, nullptr, 0.f, 0, 1, xs, d, st), "FFN GEMV 2");
         }
@@ -707,6 +714,14 @@ int fc_laura_finalize(fc_laura* e) {
             pe_dev[d] = p;
         }
         if (pack_stack(e, *S, pe_dev[d], nullptr, 0)) return 1;
+    }
+    {
+        const auto& W = e->host["codec_lm.encoder.embed.0.weight"].data;       // [d][D]
+        const int d = e->arch.codec_lm.d_model, D = e->arch.codebook_dim;
+        std::vector<float> wt((size_t)D * d);
+        for (int n = 0; n < d; ++n)
+            for (int k = 0; k < D; ++k) wt[(size_t)k * d + n] = W[(size_t)n * D + k];
+        if (upload(e, wt, &e->lm_embed_wt)) return 1;
     }
     if (pack_lin(e, e->text_out, false)) return 1;
     if (pack_lin(e, e->lm_decoder, true)) return 1;

@@ -79,6 +79,9 @@ struct Gemv {
     const int* pos = nullptr;
     int d = 0, Tcap = 0;
     int B = 0, K = 0, N = 0;
+    // x given as the key-range partials of the step attention (combined while staging): [B][H][NS][DK + 2], K = H * DK
+    const float* apart = nullptr;
+    int H = 0, DK = 0, NS = 0;
 };
 hipError_t launch_gemv(const Gemv& g, hipStream_t st);
 // rows of x [B][C] in place: [relu](LayerNorm(x)) * post_scale
@@ -90,7 +93,8 @@ struct AttnStep {
     const float *kc = nullptr, *vc = nullptr;   // caches of this layer: [B][d][Tcap], [B][Tcap][d]
     const float *ptab = nullptr, *bias_u = nullptr, *bias_v = nullptr;
     const int* pos = nullptr;       // device [B]: position of the query (keys 0 .. pos[b])
-    float* ctx = nullptr;           // [B][d]
+    float* part = nullptr;          // [B][H][NS][DK + 2]: per key range the unnormalised context, running max, sum of exponentials
+    int NS = 1;                     // key ranges per (utterance, head): B * H * NS workgroups
     int B = 0, H = 0, DK = 64, Tcap = 0, R = 0, PR = 0;
 };
 hipError_t launch_attn_step(const AttnStep& a, hipStream_t st);
@@ -115,6 +119,11 @@ struct Sample {
     const float* cb = nullptr;      // [nq_all][K][D] codebook table: next LM input = sum_k cb[k][tok_k]
     int D = 0;
     float* next_emb = nullptr;      // [B][D]
+    // optional fusion of the LM's input layer for the next step: xs[b] = [relu](LayerNorm_1e-5(W e + bias)) * xscale
+    const float *emb_wt = nullptr, *emb_bias = nullptr, *emb_g = nullptr, *emb_b = nullptr;   // emb_wt [D][dm] = W transposed
+    int dm = 0, emb_relu = 0;
+    float xscale = 1.f;
+    float* xs = nullptr;            // [B][dm]
 };
 hipError_t launch_sample(const Sample& s, hipStream_t st);
 

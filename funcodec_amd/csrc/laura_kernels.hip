@@ -524,6 +524,8 @@ struct GemvArgs {
     float *kc, *vc;
     const int* pos;
     int d, Tcap, B, K, N, XS;       // XS = LDS row stride of x
+    const float* apart;             // attention partials [B][H][NS][DK + 2] (x is then their combination), or null
+    int H, DK, NS;
 };
 
 template <int KS>
@@ -533,11 +535,39 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     float* red = lds + (a.B + 1) * a.XS;               // [KS][64][4]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, r16 = lane & 15;
     const int K = a.K, B = a.B, XS = a.XS;
-    for (int e = tid * 4; e < (B + 1) * K; e += 64 * KS * 4) {
-        const int b = e / K, k = e - b * K;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (b < B) v = *(const f32x4*)(a.x + (size_t)b * K + k);
-        *(f32x4*)(Xs + b * XS + k) = v;
+    const int tile = blockIdx.x;
+    const int nch = K / 16;                            // 16-wide k chunks of the row
+    const int cpw = nch / KS;                          // chunks per wave
+    // the weight fragments do not depend on x: request them first, the staging / LayerNorm of x runs under their latency
+    const float* wp = a.wf + ((size_t)tile * nch + (size_t)w * cpw) * 256 + lane * 4;
+    f32x4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < cpw) wv[u] = *(const f32x4*)(wp + (size_t)u * 256);
+    if (a.apart) {
+        // x[b][h * DK + dd] = combination of the NS key-range partials of head h (flash-decoding): o_s, running max m_s, sum l_s
+        const int PS = a.DK + 2;
+        for (int e = tid; e < B * K; e += 64 * KS) {
+            const int b = e / K, k = e - b * K, h = k / a.DK, dd = k - h * a.DK;
+            const float* pp = a.apart + ((size_t)(b * a.H + h) * a.NS) * PS;
+            float M = -INFINITY;
+            for (int sp = 0; sp < a.NS; ++sp) M = fmaxf(M, pp[sp * PS + a.DK]);
+            float L = 0.f, o = 0.f;
+            for (int sp = 0; sp < a.NS; ++sp) {
+                const float wgt = expf(pp[sp * PS + a.DK] - M);
+                L = fmaf(pp[sp * PS + a.DK + 1], wgt, L);
+                o = fmaf(pp[sp * PS + dd], wgt, o);
+            }
+            Xs[b * XS + k] = o / L;
+        }
+        for (int k = tid; k < K; k += 64 * KS) Xs[B * XS + k] = 0.f;
+    } else {
+        for (int e = tid * 4; e < (B + 1) * K; e += 64 * KS * 4) {
+            const int b = e / K, k = e - b * K;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < B) v = *(const f32x4*)(a.x + (size_t)b * K + k);
+            *(f32x4*)(Xs + b * XS + k) = v;
+        }
     }
     __syncthreads();
     if (a.gamma) {       // LayerNorm of every row, two-pass in LDS (one wave per row at a time)
@@ -553,14 +583,16 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
         }
         __syncthreads();
     }
-    const int tile = blockIdx.x;
-    const int nch = K / 16;                            // 16-wide k chunks of the row
-    const int cpw = nch / KS;                          // chunks per wave
-    const float* wp = a.wf + ((size_t)tile * nch + (size_t)w * cpw) * 256 + lane * 4;
     const float* xb = Xs + (r16 < B ? r16 : B) * XS + w * cpw * 16 + 4 * g;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < cpw; c0 += 8) {
-        f32x4 wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (u < cpw) {
+            const f32x4 xv = *(const f32x4*)(xb + u * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], xv[j], acc, 0, 0, 0);
+        }
+    for (int c0 = 8; c0 < cpw; c0 += 8) {              // rows wider than 8 chunks per wave (not used by the recipe's sizes)
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (c0 + u < cpw) wv[u] = *(const f32x4*)(wp + (size_t)(c0 + u) * 256);
@@ -601,7 +633,9 @@ hipError_t launch_gemv(const Gemv& g, hipStream_t st) {
     int KS = 16;
     while (KS > 1 && (nch % KS || nch / KS < 2)) KS >>= 1;     // >= 2 chunks per wave, K split evenly
     if (nch % KS) KS = 1;
-    GemvArgs a{g.x, g.wf, g.bias, g.gamma, g.beta, g.eps, g.act, g.mode, g.y, g.ldy, g.kc, g.vc, g.pos, g.d, g.Tcap, g.B, g.K, g.N, g.K + 4};
+    GemvArgs a{g.x, g.wf, g.bias, g.gamma, g.beta, g.eps, g.act, g.mode, g.y, g.ldy, g.kc, g.vc, g.pos, g.d, g.Tcap, g.B, g.K, g.N, g.K + 4,
+               g.apart, g.H, g.DK, g.NS};
+    if (g.apart && (g.H * g.DK != g.K || g.NS < 1)) return hipErrorInvalidValue;
     const size_t lds = ((size_t)(g.B + 1) * a.XS + (size_t)KS * 256) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(ceil_div_h(g.N, 16));
@@ -652,118 +686,130 @@ hipError_t launch_layernorm_rows(float* x, const float* gamma, const float* beta
 struct AttnStepArgs {
     const float *q, *kc, *vc, *ptab, *bias_u, *bias_v;
     const int* pos;
-    float* ctx;
-    int H, Tcap, R, PR;
+    float* part;         // [B][H][NS][DK + 2]: o[DK] (unnormalised), running max, sum of exponentials
+    int H, Tcap, R, PR, NS;
 };
 
+// One query (the newest token) of one (utterance, head) against ONE key range of the KV cache (flash-decoding split: NS ranges,
+// combined by the consumer, gemv_kernel's `apart` prologue).  The kernel is latency-bound, so every load of a thread is an
+// independent 16-byte piece and the K / position-table / V loads of the first pass are all in flight together:
+//   scores: thread (dg, q) owns DK/8 dims of 4 consecutive keys (K cache rows are key-contiguous; the position table is read
+//           backwards: key j sits at column R-1+pos-j); the 8 dim-group partials meet in LDS;
+//   context: thread (jg, dq) owns 4 dims of every 16th key (V cache rows are dim-contiguous).
 template <int DK>
 __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
-    // Latency-bound (one query, a few hundred keys): everything is laid out so that a thread's loads are independent 16-byte
-    // pieces issued back to back.  Scores: wave w owns DK/4 of the dims, a lane 4 consecutive keys (K cache rows are key-
-    // contiguous; the position table is read backwards: key j sits at column R-1+pos-j); the 4 partial sums meet in LDS.
-    // Context: a thread owns 4 dims of every NG-th key (V cache rows are dim-contiguous).
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int T4 = a.Tcap;                           // multiple of 4
-    float* part = lds;                               // [4][T4]
-    float* sc = lds + 4 * T4;                        // [T4]
+    constexpr int DG = 8, DPG = DK / DG;             // dim groups, dims per group
+    constexpr int NQ = DK / 4, NG = 256 / NQ;        // dim quads, key groups of the context pass
+    constexpr int CH = 128;                          // keys per pass
+    __shared__ __attribute__((aligned(16))) float part[DG][CH];
+    __shared__ float sc[CH];
     __shared__ float qu[DK], qv[DK];
     __shared__ float wred[4];
-    constexpr int NG = 1024 / DK;                    // key groups of the context pass (16 for DK = 64, 32 for DK = 32)
     __shared__ __attribute__((aligned(16))) float cred[NG][DK];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int h = blockIdx.x, b = blockIdx.y, d = a.H * DK;
+    const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, d = a.H * DK;
     const int p = a.pos[b], n = p + 1;
+    int chunk = ((n + a.NS - 1) / a.NS + 3) & ~3;    // keys per split, whole quads
+    const int k0 = sp * chunk;
+    const int k1 = k0 + chunk < n ? k0 + chunk : n;
+    float* out = a.part + ((size_t)(b * a.H + h) * a.NS + sp) * (DK + 2);
+    if (k0 >= k1) {                                  // empty range: weight 0 in the combination
+        if (tid < DK) out[tid] = 0.f;
+        if (tid == 0) { out[DK] = -INFINITY; out[DK + 1] = 0.f; }
+        return;
+    }
     if (tid < DK) {
         const float q = a.q[(size_t)b * d + h * DK + tid];
         qu[tid] = q + a.bias_u[h * DK + tid];
         qv[tid] = q + a.bias_v[h * DK + tid];
     }
-    __syncthreads();
-    constexpr int DW = DK / 4;                       // dims per wave
-    const float* kb = a.kc + ((size_t)b * d + h * DK + w * DW) * a.Tcap;
-    const float* pb = a.ptab + (size_t)(h * DK + w * DW) * a.PR + (a.R - 1) + p;
-    const int nquad = (n + 3) >> 2;
-    for (int qd = lane; qd < nquad; qd += 64) {
-        const int j0 = 4 * qd;
-        f32x4 kv[DW], pv[DW];
+    const int dg = tid >> 5, ql = tid & 31;          // scores: dim group, quad of the pass
+    const int dq = tid % NQ, jg = tid / NQ;          // context: dim quad, key group
+    const float* kb = a.kc + ((size_t)b * d + h * DK + dg * DPG) * a.Tcap;
+    const float* pb = a.ptab + (size_t)(h * DK + dg * DPG) * a.PR + (a.R - 1) + p;
+    const float* vb = a.vc + (size_t)b * a.Tcap * d + h * DK + 4 * dq;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o_acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = k0; c0 < k1; c0 += CH) {
+        const int cn = k1 - c0 < CH ? k1 - c0 : CH;  // keys of this pass
+        // ---- all loads of the pass: K / position rows for the scores, V rows for the context
+        const int j0 = c0 + 4 * ql;
+        const bool sq = 4 * ql < cn;
+        f32x4 kv[DPG], pv[DPG];
 #pragma unroll
-        for (int dd = 0; dd < DW; ++dd) {
-            kv[dd] = *(const f32x4*)(kb + (size_t)dd * a.Tcap + j0);
-            pv[dd] = *(const f32x4u*)(pb + (size_t)dd * a.PR - j0 - 3);     // columns of keys j0+3, j0+2, j0+1, j0
+        for (int dd = 0; dd < DPG; ++dd) {
+            kv[dd] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            pv[dd] = kv[dd];
+            if (sq) {
+                kv[dd] = *(const f32x4*)(kb + (size_t)dd * a.Tcap + j0);
+                pv[dd] = *(const f32x4u*)(pb + (size_t)dd * a.PR - j0 - 3);     // columns of keys j0+3, j0+2, j0+1, j0
+            }
         }
+        constexpr int NV = CH / NG;                  // V rows per thread and pass
+        f32x4 vv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int jj = jg + i * NG;
+            vv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (jj < cn) vv[i] = *(const f32x4*)(vb + (size_t)(c0 + jj) * d);
+        }
+        __syncthreads();                             // qu / qv visible (first pass); LDS of the previous pass free
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int dd = 0; dd < DW; ++dd) {
-            const float u = qu[w * DW + dd], v = qv[w * DW + dd];
+        for (int dd = 0; dd < DPG; ++dd) {
+            const float u = qu[dg * DPG + dd], v = qv[dg * DPG + dd];
             acc[0] = fmaf(u, kv[dd][0], fmaf(v, pv[dd][3], acc[0]));
             acc[1] = fmaf(u, kv[dd][1], fmaf(v, pv[dd][2], acc[1]));
             acc[2] = fmaf(u, kv[dd][2], fmaf(v, pv[dd][1], acc[2]));
             acc[3] = fmaf(u, kv[dd][3], fmaf(v, pv[dd][0], acc[3]));
         }
-        *(f32x4*)(part + w * T4 + j0) = acc;
+        *(f32x4*)&part[dg][4 * ql] = acc;
+        __syncthreads();
+        const float scale = 1.f / sqrtf((float)DK);
+        float s = -INFINITY;
+        if (tid < cn) {
+            float t = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < DG; ++gq) t += part[gq][tid];
+            s = t * scale;
+        }
+        float m = wave_max(s);
+        if (lane == 0) wred[w] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+        const float m_new = fmaxf(m_run, m);
+        const float e = tid < cn ? expf(s - m_new) : 0.f;
+        if (tid < CH) sc[tid] = e;
+        float l = wave_sum(e);
+        __syncthreads();                             // wred read by all; sc written
+        if (lane == 0) wred[w] = l;
+        __syncthreads();
+        const float corr = expf(m_run - m_new);      // 0 on the first pass (m_run = -inf)
+        l_run = l_run * corr + (wred[0] + wred[1] + wred[2] + wred[3]);
+        m_run = m_new;
+        o_acc *= corr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int jj = jg + i * NG;
+            if (jj < cn) o_acc += sc[jj] * vv[i];
+        }
     }
-    __syncthreads();
-    const float scale = 1.f / sqrtf((float)DK);
-    float m = -INFINITY;
-    for (int j = tid; j < n; j += 256) {
-        const float s = ((part[j] + part[T4 + j]) + (part[2 * T4 + j] + part[3 * T4 + j])) * scale;
-        sc[j] = s;
-        m = fmaxf(m, s);
-    }
-    m = wave_max(m);
-    if (lane == 0) wred[w] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-    __syncthreads();
-    float s = 0.f;
-    for (int j = tid; j < n; j += 256) {
-        const float e = expf(sc[j] - m);
-        sc[j] = e;
-        s += e;
-    }
-    s = wave_sum(s);
-    if (lane == 0) wred[w] = s;
-    __syncthreads();
-    const float inv = 1.f / (wred[0] + wred[1] + wred[2] + wred[3]);
-    // context
-    constexpr int NQ = DK / 4;                       // dim quads
-    const int dq = tid % NQ, jg = tid / NQ;
-    const float* vb = a.vc + (size_t)b * a.Tcap * d + h * DK + 4 * dq;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int j = jg;
-    for (; j + 3 * NG < n; j += 4 * NG) {
-        const f32x4 v0 = *(const f32x4*)(vb + (size_t)j * d), v1 = *(const f32x4*)(vb + (size_t)(j + NG) * d);
-        const f32x4 v2 = *(const f32x4*)(vb + (size_t)(j + 2 * NG) * d), v3 = *(const f32x4*)(vb + (size_t)(j + 3 * NG) * d);
-        acc += sc[j] * v0;
-        acc += sc[j + NG] * v1;
-        acc += sc[j + 2 * NG] * v2;
-        acc += sc[j + 3 * NG] * v3;
-    }
-    for (; j < n; j += NG) acc += sc[j] * *(const f32x4*)(vb + (size_t)j * d);
-    *(f32x4*)&cred[jg][4 * dq] = acc;
+    *(f32x4*)&cred[jg][4 * dq] = o_acc;
     __syncthreads();
     if (tid < DK) {
         float o = 0.f;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) o += cred[g][tid];
-        a.ctx[(size_t)b * d + h * DK + tid] = o * inv;
+        for (int gq = 0; gq < NG; ++gq) o += cred[gq][tid];
+        out[tid] = o;
     }
+    if (tid == 0) { out[DK] = m_run; out[DK + 1] = l_run; }
 }
 
 hipError_t launch_attn_step(const AttnStep& a, hipStream_t st) {
-    if (a.DK != 64 && a.DK != 32) return hipErrorInvalidValue;
-    AttnStepArgs k{a.q, a.kc, a.vc, a.ptab, a.bias_u, a.bias_v, a.pos, a.ctx, a.H, a.Tcap, a.R, a.PR};
-    const size_t lds = (size_t)5 * a.Tcap * sizeof(float);
-    if (lds > 120 * 1024 || a.Tcap % 4) return hipErrorInvalidValue;
-    static std::atomic<unsigned long long> d64{0ull}, d32{0ull};
-    hipError_t e;
-    if (a.DK == 64) {
-        if ((e = big_lds(attn_step_kernel<64>, d64, 128 * 1024)) != hipSuccess) return e;     // + ~2 KiB of static LDS
-        hipLaunchKernelGGL(attn_step_kernel<64>, dim3(a.H, a.B), dim3(256), lds, st, k);
-    } else {
-        if ((e = big_lds(attn_step_kernel<32>, d32, 128 * 1024)) != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_step_kernel<32>, dim3(a.H, a.B), dim3(256), lds, st, k);
-    }
+    if ((a.DK != 64 && a.DK != 32) || a.NS < 1 || a.Tcap % 4) return hipErrorInvalidValue;
+    AttnStepArgs k{a.q, a.kc, a.vc, a.ptab, a.bias_u, a.bias_v, a.pos, a.part, a.H, a.Tcap, a.R, a.PR, a.NS};
+    if (a.DK == 64) hipLaunchKernelGGL(attn_step_kernel<64>, dim3(a.H, a.B, a.NS), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(attn_step_kernel<32>, dim3(a.H, a.B, a.NS), dim3(256), 0, st, k);
     return hipGetLastError();
 }
 
@@ -805,6 +851,12 @@ struct SampleArgs {
     int D;
     float* next_emb;
     int B;
+    // fused input layer of the LM for the next step (TransformerEncoder_s0.embed, transformer_encoder.py:463-470):
+    // xs[b] = [relu](LayerNorm(W e + bias)) * xscale;  emb_wt [D][dm] (W transposed), null = not fused
+    const float *emb_wt, *emb_bias, *emb_g, *emb_b;
+    int dm, emb_relu;
+    float xscale;
+    float* xs;
 };
 
 #define FC_SAMPLE_MAXV 2048      // candidates per group, padded to a power of two for the bitonic sort (K + 1 <= 2048)
@@ -903,14 +955,26 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                     for (int i = 0; i < nl; ++i)
                         if ((lk[i] & mask) == prefix) atomicAdd(&hist[(lk[i] >> shift) & 255u], 1u);
                     __syncthreads();
-                    if (tid == 0) {
-                        int cum = 0, bin = 255;
-                        for (; bin > 0; --bin) {
-                            if (cum + (int)hist[bin] >= need) break;
-                            cum += (int)hist[bin];
+                    if (w == 0) {        // wave 0: lane l owns bins 4l .. 4l+3; suffix sums (bins above) by shuffles, then one lane walks its 4 bins
+                        const int h0 = (int)hist[4 * lane], h1 = (int)hist[4 * lane + 1], h2 = (int)hist[4 * lane + 2], h3 = (int)hist[4 * lane + 3];
+                        const int mine = h0 + h1 + h2 + h3;
+                        int incl = mine;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            const int t = __shfl_down(incl, o, 64);
+                            if (lane + o < 64) incl += t;
                         }
-                        sh_i[0] = bin;
-                        sh_i[1] = need - cum;
+                        const int above = incl - mine;               // entries in bins of higher lanes
+                        if (above < need && need <= incl) {
+                            int cum = above, bin = 4 * lane + 3;
+                            const int hh[4] = {h0, h1, h2, h3};
+                            for (; bin > 4 * lane; --bin) {
+                                if (cum + hh[bin & 3] >= need) break;
+                                cum += hh[bin & 3];
+                            }
+                            sh_i[0] = bin;
+                            sh_i[1] = need - cum;
+                        }
                     }
                     __syncthreads();
                     prefix |= (unsigned)sh_i[0] << shift;
@@ -981,19 +1045,35 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             for (int i = tid * CH; i < (tid + 1) * CH && i < ncand; ++i) cs += val[i];
             csum[tid] = cs;
             __syncthreads();
-            if (tid == 0) {
-                float tot = 0.f;
-                for (int i = 0; i < 256; ++i) tot += csum[i];
+            if (w == 0) {        // wave 0: lane l owns chunks 4l .. 4l+3; prefix sums by shuffles, then one lane walks its chunks / elements
+                const float c0 = csum[4 * lane], c1 = csum[4 * lane + 1], c2 = csum[4 * lane + 2], c3 = csum[4 * lane + 3];
+                const float mine = (c0 + c1) + (c2 + c3);
+                float incl = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const float t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const float tot = __shfl(incl, 63, 64);
                 const float u = philox_uniform(a.seed, (unsigned)step, (unsigned)b, (unsigned)k);
                 const float target = u * tot;
-                float run = 0.f;
-                int c = 0;
-                while (c < 255 && run + csum[c] <= target) { run += csum[c]; ++c; }
-                int i = c * CH;
-                const int iend = (c + 1) * CH < ncand ? (c + 1) * CH : ncand;
-                while (i + 1 < iend && run + val[i] <= target) { run += val[i]; ++i; }
-                if (i >= ncand) i = ncand - 1;
-                sh_i[1] = idx[i];
+                const float below = incl - mine;
+                // the lane whose range [below, incl) holds the target; rounding at the very top goes to the last non-empty lane
+                const unsigned long long nonempty = __ballot(mine > 0.f);
+                const unsigned long long ballot = __ballot(mine > 0.f && target >= below && target < incl);
+                const int owner = ballot ? (int)__ffsll((long long)ballot) - 1 : (nonempty ? 63 - __clzll((long long)nonempty) : 0);
+                if (lane == owner) {
+                    const float cc[4] = {c0, c1, c2, c3};
+                    float run = below;
+                    int c = 0;
+                    while (c < 3 && run + cc[c] <= target) { run += cc[c]; ++c; }
+                    int i = (4 * lane + c) * CH;
+                    const int iend = (4 * lane + c + 1) * CH < ncand ? (4 * lane + c + 1) * CH : ncand;
+                    while (i + 1 < iend && run + val[i] <= target) { run += val[i]; ++i; }
+                    if (i >= ncand) i = ncand - 1;
+                    if (i < 0) i = 0;
+                    sh_i[1] = idx[i];
+                }
             }
             __syncthreads();
             pick = sh_i[1];
@@ -1019,6 +1099,45 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 s = k == 0 ? v : s + v;
             }
             a.next_emb[(size_t)b * a.D + dd] = s;
+            val[dd] = s;                                   // val[] is free now: the embedding for the fused input layer
+        }
+        if (a.emb_wt) {
+            __syncthreads();
+            float yv[4];
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = tid + 256 * i;
+                yv[i] = 0.f;
+                if (n < a.dm) {
+                    float acc = a.emb_bias[n];
+                    for (int kk = 0; kk < a.D; ++kk) acc = fmaf(a.emb_wt[(size_t)kk * a.dm + n], val[kk], acc);
+                    yv[i] = acc;
+                    ps += acc;
+                }
+            }
+            ps = wave_sum(ps);
+            if (lane == 0) wred[w] = ps;
+            __syncthreads();
+            const float mean = (wred[0] + wred[1] + wred[2] + wred[3]) / (float)a.dm;
+            __syncthreads();
+            float pq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tid + 256 * i < a.dm) { const float dv = yv[i] - mean; pq += dv * dv; }
+            pq = wave_sum(pq);
+            if (lane == 0) wred[w] = pq;
+            __syncthreads();
+            const float rstd = 1.f / sqrtf((wred[0] + wred[1] + wred[2] + wred[3]) / (float)a.dm + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = tid + 256 * i;
+                if (n < a.dm) {
+                    float o = (yv[i] - mean) * rstd * a.emb_g[n] + a.emb_b[n];
+                    if (a.emb_relu) o = o > 0.f ? o : 0.f;
+                    a.xs[(size_t)b * a.dm + n] = o * a.xscale;
+                }
+            }
         }
     }
     __syncthreads();
@@ -1037,8 +1156,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
 
 hipError_t launch_sample(const Sample& s, hipStream_t st) {
     if (s.K + 1 > FC_SAMPLE_MAXV || s.nq > 8 || s.nq < 1) return hipErrorInvalidValue;
+    if (s.emb_wt && (s.dm > 1024 || s.D > FC_SAMPLE_MAXV)) return hipErrorInvalidValue;
     SampleArgs a{s.logits, s.K, s.nq, s.mode, s.ki, s.pf, s.seed, s.forced, s.max_steps, s.tokens, s.tok_stride, s.tok_off, s.n_gen,
-                 s.done, s.n_done, s.pos, s.step, s.logp_out, s.cb, s.D, s.next_emb, s.B};
+                 s.done, s.n_done, s.pos, s.step, s.logp_out, s.cb, s.D, s.next_emb, s.B,
+                 s.emb_wt, s.emb_bias, s.emb_g, s.emb_b, s.dm, s.emb_relu, s.xscale, s.xs};
     hipLaunchKernelGGL(sample_kernel, dim3(s.B), dim3(256), 0, st, a);
     return hipGetLastError();
 }
