@@ -545,22 +545,34 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     for (int u = 0; u < 8; ++u)
         if (u < cpw) wv[u] = *(const f32x4*)(wp + (size_t)u * 256);
     if (a.apart) {
-        // x[b][h * DK + dd] = combination of the NS key-range partials of head h (flash-decoding): o_s, running max m_s, sum l_s
+        // x[b][h * DK + dd] = combination of the NS key-range partials of head h (flash-decoding): o_s, running max m_s, sum l_s.
+        // First the B * H * NS normalised weights exp(m_s - M) / L (one thread per (b, h); red[] is free until the reduction)
         const int PS = a.DK + 2;
-        for (int e = tid; e < B * K; e += 64 * KS) {
-            const int b = e / K, k = e - b * K, h = k / a.DK, dd = k - h * a.DK;
-            const float* pp = a.apart + ((size_t)(b * a.H + h) * a.NS) * PS;
+        float* wn = red;
+        for (int e = tid; e < B * a.H; e += 64 * KS) {
+            const float* pp = a.apart + (size_t)e * a.NS * PS;
             float M = -INFINITY;
             for (int sp = 0; sp < a.NS; ++sp) M = fmaxf(M, pp[sp * PS + a.DK]);
-            float L = 0.f, o = 0.f;
+            float L = 0.f;
             for (int sp = 0; sp < a.NS; ++sp) {
                 const float wgt = expf(pp[sp * PS + a.DK] - M);
+                wn[e * a.NS + sp] = wgt;
                 L = fmaf(pp[sp * PS + a.DK + 1], wgt, L);
-                o = fmaf(pp[sp * PS + dd], wgt, o);
             }
-            Xs[b * XS + k] = o / L;
+            const float inv = 1.f / L;
+            for (int sp = 0; sp < a.NS; ++sp) wn[e * a.NS + sp] *= inv;
+        }
+        __syncthreads();
+        for (int e = tid; e < B * K; e += 64 * KS) {
+            const int b = e / K, k = e - b * K, h = k / a.DK, dd = k - h * a.DK;
+            const float* pp = a.apart + ((size_t)(b * a.H + h) * a.NS) * PS + dd;
+            const float* wq = wn + (b * a.H + h) * a.NS;
+            float o = 0.f;
+            for (int sp = 0; sp < a.NS; ++sp) o = fmaf(pp[sp * PS], wq[sp], o);
+            Xs[b * XS + k] = o;
         }
         for (int k = tid; k < K; k += 64 * KS) Xs[B * XS + k] = 0.f;
+        __syncthreads();                               // wn (= red) is reused by the reduction below
     } else {
         for (int e = tid * 4; e < (B + 1) * K; e += 64 * KS * 4) {
             const int b = e / K, k = e - b * K;
@@ -635,7 +647,7 @@ hipError_t launch_gemv(const Gemv& g, hipStream_t st) {
     if (nch % KS) KS = 1;
     GemvArgs a{g.x, g.wf, g.bias, g.gamma, g.beta, g.eps, g.act, g.mode, g.y, g.ldy, g.kc, g.vc, g.pos, g.d, g.Tcap, g.B, g.K, g.N, g.K + 4,
                g.apart, g.H, g.DK, g.NS};
-    if (g.apart && (g.H * g.DK != g.K || g.NS < 1)) return hipErrorInvalidValue;
+    if (g.apart && (g.H * g.DK != g.K || g.NS < 1 || g.B * g.H * g.NS > KS * 256)) return hipErrorInvalidValue;
     const size_t lds = ((size_t)(g.B + 1) * a.XS + (size_t)KS * 256) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(ceil_div_h(g.N, 16));
@@ -862,8 +874,8 @@ struct SampleArgs {
 #define FC_SAMPLE_MAXV 2048      // candidates per group, padded to a power of two for the bitonic sort (K + 1 <= 2048)
 
 __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
-    __shared__ float val[FC_SAMPLE_MAXV];
-    __shared__ int idx[FC_SAMPLE_MAXV];
+    __shared__ __attribute__((aligned(16))) float val[FC_SAMPLE_MAXV];
+    __shared__ __attribute__((aligned(16))) int idx[FC_SAMPLE_MAXV];
     __shared__ float csum[256];
     __shared__ float wred[4];
     __shared__ int wredi[4];
@@ -1103,6 +1115,31 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         }
         if (a.emb_wt) {
             __syncthreads();
+            // y[n] = bias[n] + sum_k W^T[k][n] e[k]: thread (output quad nq4, k part kp) takes 4 consecutive outputs over its share of
+            // the k range with independent 16-byte loads; the parts meet in LDS (idx[] reinterpreted, free now)
+            float* ysum = (float*)idx;                      // [dm] after the reduction
+            const int nquads = a.dm >> 2;                   // dm % 4 == 0
+            const int kparts = 256 / nquads > 0 ? 256 / nquads : 1;
+            const int nq4 = tid % nquads, kp = tid / nquads;
+            const int kper = (a.D + kparts - 1) / kparts;
+            f32x4 accq = {0.f, 0.f, 0.f, 0.f};
+            if (kp < kparts && tid < nquads * kparts) {
+                const int kb0 = kp * kper, kb1 = kb0 + kper < a.D ? kb0 + kper : a.D;
+                const float* wq = a.emb_wt + 4 * nq4;
+                int kk = kb0;
+                for (; kk + 8 <= kb1; kk += 8) {
+                    f32x4 wv8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wv8[u] = *(const f32x4*)(wq + (size_t)(kk + u) * a.dm);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) accq += val[kk + u] * wv8[u];
+                }
+                for (; kk < kb1; ++kk) accq += val[kk] * *(const f32x4*)(wq + (size_t)kk * a.dm);
+            }
+            __syncthreads();                                // everybody is done with idx[] (the sampler's candidate ids)
+            float* ypart = (float*)idx;                     // [kparts][dm], kparts * dm <= 2048 floats
+            if (tid < nquads * kparts) *(f32x4*)(ypart + kp * a.dm + 4 * nq4) = accq;
+            __syncthreads();
             float yv[4];
             float ps = 0.f;
 #pragma unroll
@@ -1111,11 +1148,12 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 yv[i] = 0.f;
                 if (n < a.dm) {
                     float acc = a.emb_bias[n];
-                    for (int kk = 0; kk < a.D; ++kk) acc = fmaf(a.emb_wt[(size_t)kk * a.dm + n], val[kk], acc);
+                    for (int q = 0; q < kparts; ++q) acc += ypart[q * a.dm + n];
                     yv[i] = acc;
                     ps += acc;
                 }
             }
+            (void)ysum;
             ps = wave_sum(ps);
             if (lane == 0) wred[w] = ps;
             __syncthreads();
@@ -1156,7 +1194,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
 
 hipError_t launch_sample(const Sample& s, hipStream_t st) {
     if (s.K + 1 > FC_SAMPLE_MAXV || s.nq > 8 || s.nq < 1) return hipErrorInvalidValue;
-    if (s.emb_wt && (s.dm > 1024 || s.D > FC_SAMPLE_MAXV)) return hipErrorInvalidValue;
+    if (s.emb_wt && (s.dm > 1024 || s.dm % 4 || s.D > FC_SAMPLE_MAXV)) return hipErrorInvalidValue;
     SampleArgs a{s.logits, s.K, s.nq, s.mode, s.ki, s.pf, s.seed, s.forced, s.max_steps, s.tokens, s.tok_stride, s.tok_off, s.n_gen,
                  s.done, s.n_done, s.pos, s.step, s.logp_out, s.cb, s.D, s.next_emb, s.B,
                  s.emb_wt, s.emb_bias, s.emb_g, s.emb_b, s.dm, s.emb_relu, s.xscale, s.xs};
