@@ -475,6 +475,8 @@ def main():
         dt = float(t.item())
     assert bool(torch.isfinite(r["recon"]).all())
     assert codes.shape[1] == total_utts
+    if world > 1:
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)     # ranks_seen
 
     # ---- separate pass: per-kernel-class HIP-event durations on the engine's stream (NOT inside the timed region above)
     prof, prof_steps = [], 0

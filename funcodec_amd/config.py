@@ -456,15 +456,15 @@ def recipe_config(name: str) -> Dict[str, Any]:
         cfg["model_conf"]["segment_dur"] = 0.5
         cfg["model_conf"]["overlap_ratio"] = 0.1
         return cfg
-    if name in ("ss320nc", "tinyssnc"):
+    if name in ("ss320nc", "tinyssnc", "ss640nc"):
         # egs/LibriTTS/codec/conf/soundstream_noncausal_16k_n32_600k_step.yaml:11-38: GroupNorm, non-causal, three residual
         # blocks per stage (dilations 1, 2, 4 -> the two-source GroupNorm chain across consecutive blocks), no sequence
         # model, 512-dim codebooks ("tinyssnc": the same shape, small)
-        cfg = recipe_config("ds320" if name == "ss320nc" else "tiny")
+        cfg = recipe_config({"ss320nc": "ds320", "ss640nc": "ds640"}.get(name, "tiny"))      # ss640nc: ..._step_ds640.yaml
         for k in ("encoder_conf", "decoder_conf"):
             cfg[k]["n_residual_layers"] = 3
             cfg[k]["seq_model"] = "none"
-        cfg["encoder_conf"]["dimension"] = 512 if name == "ss320nc" else 32
+        cfg["encoder_conf"]["dimension"] = 32 if name == "tinyssnc" else 512
         cfg["model_conf"]["odim"] = cfg["encoder_conf"]["dimension"]
         return cfg
     if name in ("ss320", "tinyss"):

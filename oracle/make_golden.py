@@ -70,6 +70,8 @@ CASES = [
     # GroupNorm chain across consecutive blocks) + 512-dim codebooks, no LSTM
     ("tinyssnc_b2_t600", "tinyssnc", 5, 1.0, "tones", 71, 2, 600, None),
     ("ss320nc_b1_t8000", "ss320nc", 0, 1.0, "noise", 72, 1, 8000, None),
+    # conf/soundstream_noncausal_16k_n32_600k_step_ds640.yaml: the same nets over the ds640 ratios
+    ("ss640nc_b1_t8000", "ss640nc", 0, 1.0, "noise", 73, 1, 8000, None),
     # the benchmark shape itself (BASELINE.json configs[1]): the first two utterances of bench.py's batch (seed 1234, 10 s)
     ("ds640_b2_t160000", "ds640", 0, 1.0, "noise", 1234, 2, 160000, None),
     # the reference's own demo recordings (real speech and music)
@@ -100,6 +102,10 @@ FREQ_CASES = [
     ("tinyfreqgr1_b2_t2500", "tinyfreqgr1", 7, "tones", 84, 2, 2500),
     # segmented mode (FreqCodec._encode / _decode with model_conf.segment_dur: 2400-sample frames, stride 2160, triangle overlap-add)
     ("tinyfreqseg_b2_t6000", "tinyfreqseg", 8, "tones", 85, 2, 6000),
+    # the reference's own demo recordings (real speech / music) through the FreqCodec recipe
+    ("freqmp_wav_libritts_5105", "freqmp", 0, "wav:libritts_5105", 0, 1, 18186),
+    ("freqmp_wav_libritts_8230", "freqmp", 0, "wav:libritts_8230", 0, 1, 29440),
+    ("freqmp_wav_jamendo_0027", "freqmp", 0, "wav:jamendo_0027", 0, 1, 160000),
     # pseudo-random FreqCodec architectures (config.py::fuzz_freq_recipe_config): n_fft 512 / 128 / 64, STFT hops 128 / 64 / 16, grouped convs,
     # two residual blocks per stage, kernel sizes 5 / 3, time ratios (1,2,1,1) / (2,1,2) / (1,1), 2-layer LSTMs
     ("freqfuzz3_b2_t3000", "freqfuzz3", 3, "tones", 96, 2, 3000),
@@ -276,7 +282,7 @@ def main():
             for k in ref_sd:
                 if k.startswith(("encoder.", "decoder.", "quantizer.")):
                     assert k in sd, f"reference key {k} missing from the synthetic checkpoint"
-            x = torch.from_numpy(synthetic_audio(B, T, aseed, akind))
+            x = torch.from_numpy(case_audio(akind, aseed, B, T))
             idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=None, use_scale=True, run_mod="inference")
             orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
             o = orc.inference(x, None, True)
@@ -313,6 +319,26 @@ def main():
                 keys = {k: list(v.shape) for k, v in ref_sd.items() if k.startswith(("encoder.", "decoder.", "quantizer."))}
                 with open(os.path.join(GOLD, "state_dict_keys_freqmp.json"), "wt") as f:
                     json.dump(keys, f, indent=0, sort_keys=True)
+        # ---- the benchmark-shape fixture under OTHER reference settings ("turn the tie argument into a committed fact"):
+        # the same two utterances with ONE thread, and utterance 1 alone (batch 1).  Frames whose codes differ between these runs
+        # of the REAL reference are ties the reference itself resolves differently; the engine may differ from the 8-thread
+        # fixture only there (tests/test_gpu_parity.py::test_full_size_matches_the_reference_golden_at_the_benchmark_shape).
+        if only is None or "ds640_b2_t160000_variants" in only:
+            s2t, cfg, sd = build_reference("ds640", 0, 1.0, tmp)
+            x = torch.from_numpy(synthetic_audio(2, 160000, 1234, "noise"))
+            nthreads = torch.get_num_threads()
+            torch.set_num_threads(1)
+            idx_t1 = s2t(x.unsqueeze(1), bit_width=None, run_mod="encode")[0][0]
+            torch.set_num_threads(nthreads)
+            idx_u1 = s2t(x[1:2].unsqueeze(1), bit_width=None, run_mod="encode")[0][0]
+            torch.set_num_threads(3)
+            idx_u1_t3 = s2t(x[1:2].unsqueeze(1), bit_width=None, run_mod="encode")[0][0]
+            torch.set_num_threads(nthreads)
+            np.savez_compressed(os.path.join(GOLD, "ds640_b2_t160000_variants.npz"), indices_threads1=idx_t1.numpy().astype(np.int16),
+                                indices_utt1_alone=idx_u1.numpy().astype(np.int16), indices_utt1_alone_threads3=idx_u1_t3.numpy().astype(np.int16))
+            manifest["cases"]["ds640_b2_t160000_variants"] = dict(kind="variants", of="ds640_b2_t160000", threads_default=nthreads,
+                                                                  runs=["indices_threads1", "indices_utt1_alone", "indices_utt1_alone_threads3"])
+            print("[golden] ds640_b2_t160000_variants: 1 thread / utterance 1 alone (default threads, 3 threads)")
         if only is not None:
             old = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
             old["cases"].update(manifest["cases"])

@@ -38,6 +38,21 @@ def main():
     torch.cuda.synchronize()
     model.engine.check_status()                                    # no barrier timeout went unnoticed
     assert codes.shape == (32, total, 100)
+    # one step shaped like bench.py's Config C path (BASELINE.json configs[2]): the ds640 net, this rank's utterances walked in
+    # micro-batches of 32 (two batch tiles of the persistent LSTM per recurrence step), the gather inside the step; scaled down
+    # to 40 utterances of 1 s per rank so that the first >= 2-GPU box to run the suite exercises the exact bench code path
+    arch_c = arch_from_config(recipe_config("ds640"))
+    model_c = EncodecMI355X(arch_c, f"cuda:{local}")
+    model_c.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(arch_c, 0).items()})
+    model_c.engine.micro_batch = 32
+    per = 40
+    wav_c = torch.from_numpy(synthetic_audio(per, 16000, 1234 + rank)).cuda()
+    parts = [model_c.engine.encode_decode(wav_c[i:i + 32], 32, use_scale=True)["codes"] for i in range(0, per, 32)]
+    codes_c = gather_codes(torch.cat(parts, 1), dist, shard_sizes=[per] * world)
+    torch.cuda.synchronize()
+    model_c.engine.check_status()
+    assert codes_c.shape == (32, per * world, 25), codes_c.shape
+    assert torch.equal(codes_c[:, rank * per:(rank + 1) * per], torch.cat(parts, 1))        # this rank's shard sits at its rank offset
     if rank == 0:
         single = model.engine.encode_decode(wav_all.cuda(), 32)    # the whole batch on ONE GPU
         assert torch.equal(single["codes"], codes), "gathered codes differ from the single-GPU result"

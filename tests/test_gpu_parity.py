@@ -12,7 +12,7 @@ from helpers import (audio, engine_for, golden, index_report, manifest, oracle_f
 
 pytestmark = pytest.mark.gpu
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg", "variants")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 FREQ = [n for n, c in MAN["cases"].items() if c.get("kind") == "freq"]
 
@@ -572,17 +572,14 @@ def test_e2e_against_oracle_fresh_inputs(cfg_name, seed, decay, B, T, kind, bw):
     wav = audio(B, T, 1000 + T, kind)
     o = orc.inference(wav, bit_width=bw, use_scale=True)
     ret = m.inference(wav.cuda().unsqueeze(1), bit_width=bw, use_scale=True)
-    rep = index_report(ret["code_indices"][0], o["code_indices"][0])
-    # Index parity vs the CPU path: the encoder outputs agree to ~1e-6, which can flip a near-tie
-    # (SURVEY.md §7-1).  Any flipped frame must be a near-tie in the ORACLE's own distances.
-    if rep["frames_bad"]:
-        _assert_flips_are_near_ties(orc.embed, o["encoder_out"], o["code_indices"][0], ret["code_indices"][0],
-                                    max_frames=max(1, rep["frames"] // 250))
-    else:
-        assert rms(ret["recon_speech"], o["recon_speech"]) < WAV_RMS_TOL
-        assert rms(ret["code_embeddings"][0][0], o["code_embeddings"][0][0]) == 0.0
+    # Index parity vs the CPU path: the encoder outputs agree to ~1e-6, which can flip a near-tie.  A flipped frame
+    # must be a PROVEN near-tie of the oracle's own distances, and the waveform is checked regardless (up to the tie).
+    enc = m.engine.encode(wav.cuda(), o["code_indices"][0].shape[0], want_enc_out=True)
+    got = dict(codes=ret["code_indices"][0], recon=ret["recon_speech"], enc_out=enc["enc_out"])
+    proofs = _check_against(orc.embed, got, o["code_indices"][0], o["encoder_out"], o["recon_speech"], m.engine.hop_length)
     assert ret["sub_quants"][0].shape == o["sub_quants"][0].shape
-    if not rep["frames_bad"]:
+    if not proofs:
+        assert rms(ret["code_embeddings"][0][0], o["code_embeddings"][0][0]) == 0.0
         assert rms(ret["sub_quants"][0], o["sub_quants"][0]) == 0.0
 
 
@@ -659,8 +656,15 @@ def test_freq_codec_against_reference_golden(name):
     m.engine.check_status()
     assert torch.equal(r2["codes"], r["codes"])
     assert tuple(r2["recon"].shape) == g["recon"].shape                 # (B, 1, min(T, decoded samples))
-    if not rep["mismatched_indices"]:
-        assert rms(r2["recon"], g["recon"]) < WAV_RMS_TOL * float(np.sqrt((g["recon"] ** 2).mean())) * 10
+    # the waveform is checked whether or not a frame flipped: whole utterances without a tie, up to the tie otherwise
+    flips = (r["codes"].cpu() != torch.from_numpy(g["indices"].astype(np.int64))).any(0).reshape(-1).nonzero().flatten().tolist()
+    Tf = g["indices"].shape[2]
+    tol = WAV_RMS_TOL * float(np.sqrt((g["recon"] ** 2).mean())) * 10
+    for b in range(c["batch"]):
+        cut = _prefix_before(flips, Tf, m.engine.hop_length, b)
+        n = g["recon"].shape[-1] if cut is None else min(cut, g["recon"].shape[-1])
+        if n > 0:
+            assert rms(r2["recon"][b, :, :n], g["recon"][b, :, :n]) < tol, (b, n)
     tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
     w2, emb = m.engine.decode_codes(tok)
     assert rms(emb, g["quantized"]) == 0.0
@@ -911,8 +915,22 @@ def test_full_size_matches_the_reference_golden_at_the_benchmark_shape(config_b)
     enc = m.engine.encode(wav[:2], 32, want_enc_out=True)
     assert torch.equal(enc["codes"], r["codes"][:, :2])
     got = dict(codes=r["codes"][:, :2], recon=r["recon"][:2], enc_out=enc["enc_out"])
-    proofs = _check_against(sd["quantizer.rq.model.embed"], got, g["indices"].astype(np.int64), g["encoder_out"], g["recon"], 640)
-    print(f"benchmark shape vs reference golden: {len(proofs)} tie frame(s) of 500: {proofs}")
+    # COMMITTED FACT instead of an argument: the same two utterances through the REAL reference with one thread, and utterance 1
+    # alone (tests/golden/ds640_b2_t160000_variants.npz).  Frames whose codes differ between those runs of the reference itself
+    # are ties it resolves differently; the engine may differ from the 8-thread fixture only on such frames.
+    v = golden("ds640_b2_t160000_variants")
+    ref = g["indices"].astype(np.int64)                                            # [32, 2, 250]
+    ref_disagrees = (v["indices_threads1"].astype(np.int64) != ref).any(0)         # [2, 250]
+    for key in ("indices_utt1_alone", "indices_utt1_alone_threads3"):
+        ref_disagrees[1] |= (v[key].astype(np.int64)[:, 0] != ref[:, 1]).any(0)
+    ours_differs = (r["codes"][:, :2].cpu().numpy() != ref).any(0)
+    assert ref_disagrees.sum() >= 1, "the fixture variants are expected to show the reference disagreeing with itself"
+    unexplained = ours_differs & ~ref_disagrees
+    print(f"benchmark shape: engine differs on frames {np.argwhere(ours_differs).tolist()}, the reference differs from itself on "
+          f"{np.argwhere(ref_disagrees).tolist()}")
+    proofs = _check_against(sd["quantizer.rq.model.embed"], got, ref, g["encoder_out"], g["recon"], 640)
+    assert int(unexplained.sum()) == 0 or proofs, "a differing frame that is neither a reference self-disagreement nor a proven tie"
+    print(f"benchmark shape vs reference golden: {len(proofs)} tie frame(s) of 500: {proofs}; unexplained by reference runs: {int(unexplained.sum())}")
     assert rms(enc["enc_out"], g["encoder_out"]) < 2e-5
     assert float(((r["scale"][:2].cpu() - torch.from_numpy(g["scale"])).abs() / torch.from_numpy(g["scale"])).max()) < 1e-5
     if not proofs:

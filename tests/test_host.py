@@ -137,7 +137,7 @@ def test_config_defaults_follow_the_reference_constructor():
         cfg["decoder_conf"][key] = val
         with pytest.raises(NotImplementedError):
             arch_from_config(cfg)
-    for name in ("ss320nc", "tinyssnc", "ds640seg"):                   # the accepted noncausal SoundStream / segmented recipes
+    for name in ("ss320nc", "tinyssnc", "ss640nc", "ds640seg"):                   # the accepted noncausal SoundStream / segmented recipes
         arch_from_config(recipe_config(name))
     bad = arch_from_config(recipe_config("tiny"))
     bad.codebook_size = 192                                            # > 128 and not a multiple of 128: refused at create time

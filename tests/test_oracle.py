@@ -7,7 +7,7 @@ import torch
 from helpers import audio, golden, index_report, manifest, oracle_for, rms
 
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg", "variants")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 SAME_BUILD = torch.__version__ == MAN["torch"]
 
