@@ -47,6 +47,7 @@ class Speech2Token:
             streaming: bool = False,
             sampling_rate: int = 24_000,
             bit_width: int = 24_000,
+            check_status: bool = True,
     ):
         if dtype not in ("float16", "float32", "float64"):
             raise ValueError(f"dtype must be float16, float32 or float64, got {dtype!r}")
@@ -61,6 +62,11 @@ class Speech2Token:
         self.device = device
         self.dtype = dtype
         self.already_stat_flops = False
+        # device-side failures (an out-of-range code index, which the reference's F.embedding raises on; a persistent-LSTM barrier
+        # timeout) are recorded by the kernels and can only be read after the stream has drained: by default every call ends with
+        # that check, like the reference raises in line.  check_status=False keeps calls asynchronous (the caller then uses
+        # model.engine.check_status() itself).
+        self.check_status = check_status
 
     @torch.no_grad()
     def __call__(
@@ -93,6 +99,8 @@ class Speech2Token:
             speech = speech[:, :, :nq]
             logging.info("use %d quantizers.", speech.shape[-1])
             ret = self.model.inference_decoding(speech)
+        if self.check_status:
+            self.model.engine.check_status(sync=True)
         if self.dtype != "float32":
             td = getattr(torch, self.dtype)
             cast = lambda t: t.to(td) if isinstance(t, torch.Tensor) and t.is_floating_point() else t   # noqa: E731

@@ -47,11 +47,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         out = os.environ["FC_BUILD_OUT"]
     if not force and not defines and out == LIB_PATH and not needs_build():
         return LIB_PATH
-    tag = "".join(c if c.isalnum() else "_" for c in os.path.basename(out))
-    obj_dir = os.path.join(OBJ_DIR, tag)
-    os.makedirs(obj_dir, exist_ok=True)
+    # objects are cached per (output name, compile flags): a build with other -D switches must never reuse these objects
+    import hashlib
     hipcc = _hipcc()
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + defines
+    tag = "".join(c if c.isalnum() else "_" for c in os.path.basename(out)) + "_" + hashlib.sha1(" ".join(base[1:]).encode()).hexdigest()[:10]
+    obj_dir = os.path.join(OBJ_DIR, tag)
+    os.makedirs(obj_dir, exist_ok=True)
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
 
     def compile_one(src: str) -> str:
@@ -68,10 +70,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(compile_one, srcs))
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    # link next to the target and rename over it: a process dlopen-ing the library concurrently sees the old or the new file, never
+    # a half-written one
+    tmp_out = f"{out}.{os.getpid()}.tmp"
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_out] + objs
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True)
+    os.replace(tmp_out, out)
     return out
 
 

@@ -156,6 +156,21 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
                         ("activation", "ELU"), ("final_activation", None), ("trim_right_ratio", 1.0)):
             if conf.get(key, ok) != ok:
                 raise _unsupported(f"{which}.{key}", conf[key])
+    # every key of the 2-D nets is either plumbed into the architecture or refused here: nothing is silently ignored
+    known_enc = {"ratios", "norm", "norm_params", "causal", "n_filters", "dimension", "n_residual_layers", "activation", "activation_params",
+                 "kernel_size", "last_kernel_size", "residual_kernel_size", "dilation_base", "pad_mode", "true_skip", "compress", "seq_model",
+                 "seq_layer_num", "res_seq", "conv_group_ratio", "input_size"}
+    known_dec = (known_enc - {"dimension"}) | {"channels", "final_activation", "final_activation_params", "trim_right_ratio",
+                                              "last_out_padding", "tr_conv_group_ratio"}
+    for which, conf, known in (("encoder_conf", enc, known_enc), ("decoder_conf", dec, known_dec)):
+        for key in conf:
+            if key not in known:
+                raise _unsupported(f"{which}.{key}", conf[key], "unknown key of the 2-D SEANet nets")
+    lop = dec.get("last_out_padding", [(0, 1), (0, 0)])
+    if [list(p_) for p_ in lop] != [[0, 1], [0, 0]]:
+        raise _unsupported("decoder_conf.last_out_padding", lop, "the engine builds the default [(0, 1), (0, 0)] (seanet_decoder.py:260)")
+    if dec.get("final_activation_params", None) not in (None, {}):
+        raise _unsupported("decoder_conf.final_activation_params", dec.get("final_activation_params"))
     domain = list(m.get("codec_domain", ["time", "time"]))
     if domain != ["mag_phase", "mag_phase"]:
         # mag_angle was built and measured in round 2, then removed: torch.angle of the first STFT frame (reflect padding makes it
@@ -210,6 +225,10 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         enc_conv_group_ratio=int(enc.get("conv_group_ratio", -1)), dec_conv_group_ratio=int(dec.get("conv_group_ratio", -1)),
         dec_tr_conv_group_ratio=int(dec.get("tr_conv_group_ratio", -1)),
     )
+    if arch.stft_hop < 1 or arch.stft_hop > arch.n_fft // 2:
+        # torch.istft checks the window envelope (NOLA, > 1e-11); a periodic Hann window's squared overlap-add reaches ~0 between
+        # frames once the hop exceeds n_fft / 2, where the reference raises instead of returning audio
+        raise _unsupported("model_conf.domain_conf.hop_length", arch.stft_hop, "must be in [1, n_fft / 2] (torch.istft's window-envelope check)")
     if arch.segment_dur is not None and not (arch.segment_dur > 0 and 0 <= arch.overlap_ratio < 1):
         raise _unsupported("model_conf.segment_dur/overlap_ratio", (arch.segment_dur, arch.overlap_ratio))
     if arch.segment_length is not None and arch.segment_length <= arch.n_fft // 2:
@@ -305,6 +324,10 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         segment_dur=None if segment_dur is None else float(segment_dur),
         overlap_ratio=0.01 if overlap_ratio is None else float(overlap_ratio),
     )
+    if arch.stft_hop < 1 or arch.stft_hop > arch.n_fft // 2:
+        # torch.istft checks the window envelope (NOLA, > 1e-11); a periodic Hann window's squared overlap-add reaches ~0 between
+        # frames once the hop exceeds n_fft / 2, where the reference raises instead of returning audio
+        raise _unsupported("model_conf.domain_conf.hop_length", arch.stft_hop, "must be in [1, n_fft / 2] (torch.istft's window-envelope check)")
     if arch.segment_dur is not None and not (arch.segment_dur > 0 and 0 <= arch.overlap_ratio < 1):
         raise _unsupported("model_conf.segment_dur/overlap_ratio", (arch.segment_dur, arch.overlap_ratio))
     return arch

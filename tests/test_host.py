@@ -139,6 +139,19 @@ def test_config_defaults_follow_the_reference_constructor():
             arch_from_config(cfg)
     for name in ("ss320nc", "tinyssnc", "ss640nc", "ds640seg"):                   # the accepted noncausal SoundStream / segmented recipes
         arch_from_config(recipe_config(name))
+    # FreqCodec: decoder keys the engine hard-wires are refused when they differ, unknown keys too, and an STFT hop whose window
+    # envelope reaches zero (torch.istft raises there)
+    for mut in (lambda c: c["decoder_conf"].update(last_out_padding=[(0, 0), (0, 0)]),
+                lambda c: c["decoder_conf"].update(some_future_key=1),
+                lambda c: c["encoder_conf"].update(some_future_key=1),
+                lambda c: c["model_conf"].update(domain_conf={"n_fft": 512, "hop_length": 512})):
+        cfg = recipe_config("freqmp")
+        mut(cfg)
+        with pytest.raises(NotImplementedError):
+            arch_from_config(cfg)
+    cfg = recipe_config("freqmp")
+    cfg["decoder_conf"]["last_out_padding"] = [[0, 1], [0, 0]]          # the default, spelt as yaml spells it
+    arch_from_config(cfg)
     bad = arch_from_config(recipe_config("tiny"))
     bad.codebook_size = 192                                            # > 128 and not a multiple of 128: refused at create time
     with pytest.raises(EngineError, match="codebook_size"):
