@@ -181,6 +181,20 @@ def kernel_rooflines(prof, prof_steps):
                                                        "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS, 4)},
                            "note": "fp32-input MFMA (exact fp32, peak = fp32 vector peak); achieved = algorithmic FLOPs of this kernel's "
                                    f"launches / sum of their HIP-event durations over a SEPARATE {prof_steps}-step pass (not the timed region)"}
+    # `roofline` describes the DOMINANT kernel of the step = the class with the largest share of the step's kernel time, whatever it
+    # is.  On Config B that is the persistent LSTM recurrence (latency-bound: priced against the fp32 matrix peak like the convs);
+    # the dominant implicit-GEMM conv class keeps its own object (`roofline_conv`).
+    top = max(kern, key=lambda k: k["ms_per_step"]) if kern else None
+    if top is not None and "roofline" in out and top["kernel"] != out["roofline"]["kernel"] and top["tflops"]:
+        out["roofline_conv"] = out["roofline"]
+        out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(top["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": None,
+                           "avg_us_per_launch": top["avg_us_per_launch"], "launches_per_step": top["launches_per_step"],
+                           "ms_per_step": top["ms_per_step"],
+                           "share_of_kernel_time": round(top["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in kern)), 4),
+                           "note": "top kernel class of the step by time.  lstm_persist_kernel: one launch = the whole 2-layer recurrence of a SLSTM "
+                                   "block; algorithmic FLOPs = 2 * B * 4H * 3H per wavefront step; it is bound by the per-step hidden-state exchange "
+                                   "(a grid-wide all-gather + barrier per step), not by the matrix pipe: frac is its distance from the fp32 MFMA roof"}
     hbm = [k for k in convs if k["bound"] == "hbm"]
     if hbm:   # the HBM-bound (thin, C <= 64) classes: north_star's roof
         hdom = max(hbm, key=lambda k: k["ms_per_step"])

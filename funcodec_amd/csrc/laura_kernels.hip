@@ -55,53 +55,67 @@ hipError_t big_lds(F kfn, std::atomic<unsigned long long>& done, int bytes = 160
 // funcodec/modules/layer_norm.py:22, 1e-5 in the input layers).  One thread column per time step (coalesced over t), the C
 // channels split over 4 thread rows; two-pass mean / variance in fp32.
 // =====================================================================================================================
+// round 3: a workgroup = 16 time steps x 16 channel groups; a thread keeps its C / 16 values in registers (one read of the tensor, one
+// write) and the statistics meet in LDS.  The first version (64 time steps x 4 channel groups, three passes over global memory) ran
+// 56 workgroups for a batch of 8 x 430 columns and took ~100 us per call.
+template <int CPT>                                     // channels per thread = C / 16 (<= CPT)
 __global__ __launch_bounds__(256) void layernorm_fm_kernel(const float* __restrict__ x, const float* __restrict__ add, float* sum_out,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                            int relu, float post_scale, float* __restrict__ y, int C, int T) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, cg = threadIdx.x >> 6;
-    const int t = blockIdx.x * 64 + tx, b = blockIdx.y;
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + tx, b = blockIdx.y;
     const bool ok = t < T;
     const size_t base = (size_t)b * C * T + (ok ? t : 0);
-    const int c0 = cg * (C / 4), c1 = cg == 3 ? C : c0 + C / 4;
+    const int cpt = C / 16, c0 = cg * cpt;
+    float v[CPT];
     float s = 0.f;
-    for (int c = c0; c < c1; ++c) {
-        float v = x[base + (size_t)c * T];
-        if (add) v += add[base + (size_t)c * T];
-        if (sum_out && ok) sum_out[base + (size_t)c * T] = v;
-        s += v;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        v[i] = 0.f;
+        if (i < cpt) {
+            float u = x[base + (size_t)(c0 + i) * T];
+            if (add) u += add[base + (size_t)(c0 + i) * T];
+            v[i] = u;
+            s += u;
+        }
     }
     red[cg][tx] = s;
     __syncthreads();
-    const float mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
+    float tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tot += red[g][tx];
+    const float mean = tot / (float)C;
     __syncthreads();
-    const float* src = sum_out ? sum_out : x;        // sum_out == x (in place) or a separate buffer: both hold x + add now
     float q = 0.f;
-    for (int c = c0; c < c1; ++c) {
-        float v = src[base + (size_t)c * T];
-        if (add && !sum_out) v += add[base + (size_t)c * T];
-        const float dv = v - mean;
-        q += dv * dv;
-    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (i < cpt) { const float dv = v[i] - mean; q += dv * dv; }
     red[cg][tx] = q;
     __syncthreads();
-    const float var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)C;
-    const float rstd = 1.f / sqrtf(var + eps);
+    tot = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) tot += red[g][tx];
+    const float rstd = 1.f / sqrtf(tot / (float)C + eps);
     if (!ok) return;
-    for (int c = c0; c < c1; ++c) {
-        float v = src[base + (size_t)c * T];
-        if (add && !sum_out) v += add[base + (size_t)c * T];
-        float o = (v - mean) * rstd * gamma[c] + beta[c];
-        if (relu) o = o > 0.f ? o : 0.f;
-        y[base + (size_t)c * T] = o * post_scale;
-    }
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+        if (i < cpt) {
+            const int c = c0 + i;
+            if (sum_out) sum_out[base + (size_t)c * T] = v[i];
+            float o = (v[i] - mean) * rstd * gamma[c] + beta[c];
+            if (relu) o = o > 0.f ? o : 0.f;
+            y[base + (size_t)c * T] = o * post_scale;
+        }
 }
 
 hipError_t launch_layernorm_fm(const float* x, const float* add, float* sum_out, const float* gamma, const float* beta, float eps,
                                int relu, float post_scale, float* y, int B, int C, int T, hipStream_t st) {
-    if (C % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_fm_kernel, dim3(ceil_div_h(T, 64), B), dim3(256), 0, st, x, add, sum_out, gamma, beta, eps, relu,
-                       post_scale, y, C, T);
+    if (C % 16 || C > 1024) return hipErrorInvalidValue;
+    const dim3 grid(ceil_div_h(T, 16), B);
+    if (C <= 128) hipLaunchKernelGGL(layernorm_fm_kernel<8>, grid, dim3(256), 0, st, x, add, sum_out, gamma, beta, eps, relu, post_scale, y, C, T);
+    else if (C <= 512) hipLaunchKernelGGL(layernorm_fm_kernel<32>, grid, dim3(256), 0, st, x, add, sum_out, gamma, beta, eps, relu, post_scale, y, C, T);
+    else hipLaunchKernelGGL(layernorm_fm_kernel<64>, grid, dim3(256), 0, st, x, add, sum_out, gamma, beta, eps, relu, post_scale, y, C, T);
     return hipGetLastError();
 }
 
@@ -528,7 +542,10 @@ struct GemvArgs {
     int H, DK, NS;
 };
 
-template <int KS>
+// CPW = 16-wide k chunks per wave as a compile-time constant (2 or 8 for every layer of the recipe): the weight loads are then
+// unconditional straight-line code.  Under a run-time count every load sat behind its own `if`, and hipcc waits for a conditional
+// load right where it is issued (DESIGN.md §5, round-2 finding) -- the "prefetch" was eight serialised round trips.  CPW = 0: generic.
+template <int KS, int CPW>
 __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* Xs = lds;                                   // [B + 1][XS], row B = zeros
@@ -537,13 +554,13 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     const int K = a.K, B = a.B, XS = a.XS;
     const int tile = blockIdx.x;
     const int nch = K / 16;                            // 16-wide k chunks of the row
-    const int cpw = nch / KS;                          // chunks per wave
+    const int cpw = CPW ? CPW : nch / KS;              // chunks per wave
     // the weight fragments do not depend on x: request them first, the staging / LayerNorm of x runs under their latency
     const float* wp = a.wf + ((size_t)tile * nch + (size_t)w * cpw) * 256 + lane * 4;
-    f32x4 wv[8];
+    constexpr int NPRE = CPW ? CPW : 1;
+    f32x4 wv[CPW ? CPW : 8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-        if (u < cpw) wv[u] = *(const f32x4*)(wp + (size_t)u * 256);
+    for (int u = 0; u < NPRE; ++u) wv[u] = *(const f32x4*)(wp + (size_t)u * 256);
     if (a.apart) {
         // x[b][h * DK + dd] = combination of the NS key-range partials of head h (flash-decoding): o_s, running max m_s, sum l_s.
         // First the B * H * NS normalised weights exp(m_s - M) / L (one thread per (b, h); red[] is free until the reduction)
@@ -576,8 +593,8 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     } else {
         for (int e = tid * 4; e < (B + 1) * K; e += 64 * KS * 4) {
             const int b = e / K, k = e - b * K;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b < B) v = *(const f32x4*)(a.x + (size_t)b * K + k);
+            f32x4 v = *(const f32x4*)(a.x + (size_t)(b < B ? b : B - 1) * K + k);      // unconditional load, the zero row by select
+            if (b >= B) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             *(f32x4*)(Xs + b * XS + k) = v;
         }
     }
@@ -598,13 +615,12 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     const float* xb = Xs + (r16 < B ? r16 : B) * XS + w * cpw * 16 + 4 * g;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-        if (u < cpw) {
-            const f32x4 xv = *(const f32x4*)(xb + u * 16);
+    for (int u = 0; u < NPRE; ++u) {
+        const f32x4 xv = *(const f32x4*)(xb + u * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], xv[j], acc, 0, 0, 0);
-        }
-    for (int c0 = 8; c0 < cpw; c0 += 8) {              // rows wider than 8 chunks per wave (not used by the recipe's sizes)
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], xv[j], acc, 0, 0, 0);
+    }
+    for (int c0 = NPRE; c0 < cpw; c0 += 8) {           // generic form: the remaining chunks in batches of up to 8
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (c0 + u < cpw) wv[u] = *(const f32x4*)(wp + (size_t)(c0 + u) * 256);
@@ -651,12 +667,21 @@ hipError_t launch_gemv(const Gemv& g, hipStream_t st) {
     const size_t lds = ((size_t)(g.B + 1) * a.XS + (size_t)KS * 256) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(ceil_div_h(g.N, 16));
-    static std::atomic<unsigned long long> d16{0ull}, d8{0ull}, d4{0ull}, d2{0ull}, d1{0ull};
+    static std::atomic<unsigned long long> d16[3], d8[3], d4[3], d2[3], d1[3];
     hipError_t e;
 #define FC_GEMV_CASE(ks, flag)                                                            \
     if (KS == ks) {                                                                       \
-        if ((e = big_lds(gemv_kernel<ks>, flag)) != hipSuccess) return e;                 \
-        hipLaunchKernelGGL(gemv_kernel<ks>, grid, dim3(64 * ks), lds, st, a);             \
+        const int cpw = nch / ks;                                                         \
+        if (cpw == 2) {                                                                   \
+            if ((e = big_lds(gemv_kernel<ks, 2>, flag[0])) != hipSuccess) return e;       \
+            hipLaunchKernelGGL((gemv_kernel<ks, 2>), grid, dim3(64 * ks), lds, st, a);    \
+        } else if (cpw == 8) {                                                            \
+            if ((e = big_lds(gemv_kernel<ks, 8>, flag[1])) != hipSuccess) return e;       \
+            hipLaunchKernelGGL((gemv_kernel<ks, 8>), grid, dim3(64 * ks), lds, st, a);    \
+        } else {                                                                          \
+            if ((e = big_lds(gemv_kernel<ks, 0>, flag[2])) != hipSuccess) return e;       \
+            hipLaunchKernelGGL((gemv_kernel<ks, 0>), grid, dim3(64 * ks), lds, st, a);    \
+        }                                                                                 \
         return hipGetLastError();                                                         \
     }
     FC_GEMV_CASE(16, d16)
@@ -747,23 +772,21 @@ __global__ __launch_bounds__(256) void attn_step_kernel(AttnStepArgs a) {
         // ---- all loads of the pass: K / position rows for the scores, V rows for the context
         const int j0 = c0 + 4 * ql;
         const bool sq = 4 * ql < cn;
+        // straight-line loads with clamped addresses: hipcc waits for a load under a run-time condition right where it is issued, which
+        // would serialise the round trips this kernel exists to overlap.  Quads / rows past the range read key c0 and are never used.
+        const int jq = sq ? j0 : c0;
         f32x4 kv[DPG], pv[DPG];
 #pragma unroll
         for (int dd = 0; dd < DPG; ++dd) {
-            kv[dd] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            pv[dd] = kv[dd];
-            if (sq) {
-                kv[dd] = *(const f32x4*)(kb + (size_t)dd * a.Tcap + j0);
-                pv[dd] = *(const f32x4u*)(pb + (size_t)dd * a.PR - j0 - 3);     // columns of keys j0+3, j0+2, j0+1, j0
-            }
+            kv[dd] = *(const f32x4*)(kb + (size_t)dd * a.Tcap + jq);
+            pv[dd] = *(const f32x4u*)(pb + (size_t)dd * a.PR - jq - 3);     // columns of keys jq+3, jq+2, jq+1, jq
         }
         constexpr int NV = CH / NG;                  // V rows per thread and pass
         f32x4 vv[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int jj = jg + i * NG;
-            vv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (jj < cn) vv[i] = *(const f32x4*)(vb + (size_t)(c0 + jj) * d);
+            vv[i] = *(const f32x4*)(vb + (size_t)(c0 + (jj < cn ? jj : 0)) * d);
         }
         __syncthreads();                             // qu / qv visible (first pass); LDS of the previous pass free
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1127,12 +1150,19 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 const int kb0 = kp * kper, kb1 = kb0 + kper < a.D ? kb0 + kper : a.D;
                 const float* wq = a.emb_wt + 4 * nq4;
                 int kk = kb0;
-                for (; kk + 8 <= kb1; kk += 8) {
-                    f32x4 wv8[8];
+                for (; kk + 16 <= kb1; kk += 16) {          // 16 independent 16-byte loads in flight (the table is cold in L2 every step)
+                    f32x4 wv16[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) wv8[u] = *(const f32x4*)(wq + (size_t)(kk + u) * a.dm);
+                    for (int u = 0; u < 16; ++u) wv16[u] = *(const f32x4*)(wq + (size_t)(kk + u) * a.dm);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) accq += val[kk + u] * wv8[u];
+                    for (int u = 0; u < 16; ++u) accq += val[kk + u] * wv16[u];
+                }
+                for (; kk + 4 <= kb1; kk += 4) {
+                    f32x4 wv4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) wv4[u] = *(const f32x4*)(wq + (size_t)(kk + u) * a.dm);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) accq += val[kk + u] * wv4[u];
                 }
                 for (; kk < kb1; ++kk) accq += val[kk] * *(const f32x4*)(wq + (size_t)kk * a.dm);
             }
