@@ -23,6 +23,7 @@ class FcArch(C.Structure):
         ("model_type", C.c_int32), ("input_channels", C.c_int32), ("n_fft", C.c_int32), ("stft_hop", C.c_int32),
         ("ratios_f", C.c_int32 * FC_MAX_RATIOS),
         ("enc_conv_group_ratio", C.c_int32), ("dec_conv_group_ratio", C.c_int32), ("dec_tr_conv_group_ratio", C.c_int32),
+        ("codec_dim", C.c_int32), ("codec_range", C.c_float),
     ]
 
 

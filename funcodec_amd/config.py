@@ -39,7 +39,8 @@ class ArchSpec:
     gn_eps: float = 1e-5
     # quantizer (CostumeQuantizer -> ResidualVectorQuantizer)
     codebook_size: int = 1024
-    codebook_dim: int = 128
+    codebook_dim: int = 128                       # dims the codebooks live in (= codec_dim when the quantiser projects, else dimension)
+    codec_range: Optional[float] = None           # CostumeQuantizer: quantiser input = tanh(x) * codec_range (costume_quantizer.py:32-35)
     num_quantizers: int = 32
     encoder_hop_length: int = 320
     quantizer_sampling_rate: int = 16000
@@ -281,10 +282,13 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     # the decoder's input_size is injected by build_model from quantizer.output_size()
     # (gan_speech_codec.py:325-329) == encoder dimension when codec_dim is unset
     dimension = int(enc.get("dimension", 128))
-    if q.get("codec_dim", None) not in (None, dimension):
-        raise _unsupported("quantizer_conf.codec_dim", q["codec_dim"], "input/output projections not built")
-    if q.get("codec_range", None) is not None:
-        raise _unsupported("quantizer_conf.codec_range", q["codec_range"])
+    codec_dim = q.get("codec_dim", None)
+    codec_dim = dimension if codec_dim is None else int(codec_dim)
+    if codec_dim not in (16, 32, 64, 128, 256, 512):
+        raise _unsupported("quantizer_conf.codec_dim", q.get("codec_dim"), "the quantiser kernels are built for 16/32/64/128/256/512 dims")
+    codec_range = q.get("codec_range", None)
+    if codec_range is not None and not float(codec_range) > 0:
+        raise _unsupported("quantizer_conf.codec_range", codec_range)
     if q.get("q0_ds_ratio", 1) != 1:
         raise _unsupported("quantizer_conf.q0_ds_ratio", q["q0_ds_ratio"])
     # decoder_conf values that differ from encoder_conf are refused (shared()), never silently ignored
@@ -314,7 +318,8 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         elu_alpha=float(act_params.get("alpha", 1.0)),
         gn_eps=float(norm_params.get("eps", 1e-5)),
         codebook_size=int(q.get("codebook_size", 1024)),
-        codebook_dim=int(enc.get("dimension", 128)),
+        codebook_dim=codec_dim,
+        codec_range=None if codec_range is None else float(codec_range),
         num_quantizers=int(q.get("num_quantizers", 8)),
         encoder_hop_length=int(q.get("encoder_hop_length", 320)),
         quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
@@ -469,6 +474,15 @@ def recipe_config(name: str) -> Dict[str, Any]:
         return fuzz_recipe_config(int(name[4:]))
     if name.startswith(("freqmp", "tinyfreq", "freqfuzz")):
         return freq_recipe_config(name)
+    if name in ("ds320cd64", "tinycd"):   # CostumeQuantizer with codec_dim != input_size and a tanh range (costume_quantizer.py:23-35)
+        cfg = recipe_config("ds320" if name == "ds320cd64" else "tiny")
+        cfg["quantizer_conf"]["codec_dim"] = 64 if name == "ds320cd64" else 32
+        cfg["quantizer_conf"]["codec_range"] = 2.5
+        return cfg
+    if name == "tinyrange":               # tanh range without a projection
+        cfg = recipe_config("tiny")
+        cfg["quantizer_conf"]["codec_range"] = 1.5
+        return cfg
     if name == "ds320seg":   # ds320 run in the segmented overlap-add mode (0.5 s frames, 10 % overlap)
         cfg = recipe_config("ds320")
         cfg["model_conf"]["segment_dur"] = 0.5

@@ -136,6 +136,9 @@ struct fc_engine {
     std::map<std::string, ResBlock*> res_by_prefix;
     // STFT-domain codec (arch.model_type == 1)
     ConvLayer enc2_first, dec2_last, stft, istft;
+    ConvLayer q_in, q_out;                                                 // CostumeQuantizer.input_proj / output_proj as k = 1 GEMMs (codec_dim != dimension)
+    bool q_proj = false;
+    int cdim() const { return q_proj ? arch.codec_dim : arch.dimension; }
     std::vector<std::vector<ConvLayer>> dec_up_phases;                    // decoder stage s: one transposed 1-D GEMM per frequency phase
     int halo2 = 3;                                                        // frequency halo rows of the 2-D activations
     float* win2 = nullptr;                                                // squared Hann window [n_fft] (istft envelope)                       // "encoder.model.1" -> block (fc_resblock_forward)
@@ -250,6 +253,22 @@ void add_conv2d_expect(fc_engine* e, ConvLayer& L) {
     e->by_prefix[L.prefix] = &L;
 }
 
+// CostumeQuantizer (costume_quantizer.py:7-55): the codebooks, and with codec_dim != input_size the two Linears around them
+void add_quantizer_expect(fc_engine* e) {
+    const fc_arch& a = e->arch;
+    e->q_proj = a.codec_dim > 0 && a.codec_dim != a.dimension;
+    if (e->q_proj) {
+        e->q_in = mk_conv("quantizer.input_proj", a.dimension, a.codec_dim, 1, 1, false, false, true);
+        e->q_out = mk_conv("quantizer.output_proj", a.codec_dim, a.dimension, 1, 1, false, false, true);
+        e->q_in.has_norm = e->q_out.has_norm = false;
+        e->expected.push_back({"quantizer.input_proj.weight", {a.codec_dim, a.dimension}});
+        e->expected.push_back({"quantizer.input_proj.bias", {a.codec_dim}});
+        e->expected.push_back({"quantizer.output_proj.weight", {a.dimension, a.codec_dim}});
+        e->expected.push_back({"quantizer.output_proj.bias", {a.dimension}});
+    }
+    e->expected.push_back({"quantizer.rq.model.embed", {a.num_quantizers, a.codebook_size, e->cdim()}});
+}
+
 void build_plan_2d(fc_engine* e) {
     const fc_arch& a = e->arch;
     const int nf = a.n_filters, nres = a.n_residual_layers;
@@ -353,7 +372,7 @@ void build_plan_2d(fc_engine* e) {
         for (auto& R : S.res) { add_conv2d_expect(e, R.block1); add_conv2d_expect(e, R.block3); add_conv2d_expect(e, R.shortcut); }
     }
     add_conv2d_expect(e, e->dec2_last);
-    e->expected.push_back({"quantizer.rq.model.embed", {a.num_quantizers, a.codebook_size, a.dimension}});
+    add_quantizer_expect(e);
 }
 
 void build_plan(fc_engine* e) {
@@ -474,7 +493,7 @@ void build_plan(fc_engine* e) {
         for (auto& R : S.res) { add_conv_expect(e, R.shortcut); add_conv_expect(e, R.block1); add_conv_expect(e, R.block3); }
     }
     add_conv_expect(e, e->dec_last);
-    e->expected.push_back({"quantizer.rq.model.embed", {a.num_quantizers, a.codebook_size, a.dimension}});
+    add_quantizer_expect(e);
 }
 
 // ---- weight packing -------------------------------------------------------------------------------
@@ -1434,19 +1453,44 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
         }
     }
     Act last = e->arch.model_type == 1 ? run_encoder_2d(e, cx, wav, T, sc) : run_encoder(e, cx, wav, T, sc);
-    float* emb = enc_out ? enc_out : cx.alloc<float>((size_t)B * Tf * D);
-    float* qbdt = cx.alloc<float>((size_t)B * D * Tf);
-    cx.launches += 2;
-    cx.rvq_flops += 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D;
+    const int Dc = e->cdim();
+    const bool ranged = e->arch.codec_range > 0.f;
+    float* emb = enc_out ? enc_out : ((e->q_proj || ranged) && !enc_out ? nullptr : cx.alloc<float>((size_t)B * Tf * D));
+    // quantiser input rows [B*Tf][Dc]: the encoder output itself, or input_proj(...) / tanh(...) * range of it (costume_quantizer.py:84-87)
+    Act pj;
+    if (e->q_proj) pj = run_conv(e, cx, e->q_in, src_of(last), fc::Src(), 0, Tf);
+    float* xq = (e->q_proj || ranged) ? cx.alloc<float>((size_t)B * Tf * Dc) : emb;
+    float* quant_c = e->q_proj ? cx.alloc<float>((size_t)B * Tf * Dc) : quantized;       // quantised rows in codebook space
+    float* qbdt_c = cx.alloc<float>((size_t)B * Dc * Tf);
+    cx.launches += 2 + (ranged ? 1 : 0);
+    cx.rvq_flops += 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * Dc;
     if (!cx.dry && !cx.err) {
         if (last.T != Tf) return fail("internal: frame count mismatch");
         // encoder output permuted to [B,Tf,D] (seanet_encoder.py:175) with the last GroupNorm applied
-        if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, emb, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
+        if (emb && fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, emb, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
             return fail("combine launch failed");
-        ProfSpan sp(e, cx, e->profiling ? e->prof_class(kRvqClass) : 0, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * D, 0.0);
-        if (fc::launch_rvq_encode(emb, B * Tf, D, e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quantized, qbdt,
+        if (e->q_proj) {
+            if (fc::launch_combine(src_of(pj), fc::Src(), 0, 1.f, nullptr, B, Dc, Tf, Tf, xq, (long long)Tf * Dc, 1, Dc, cx.st) != hipSuccess)
+                return fail("combine launch failed");
+        } else if (ranged) {
+            if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, xq, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
+                return fail("combine launch failed");
+        }
+        if (ranged && fc::launch_tanh_range(xq, (size_t)B * Tf * Dc, e->arch.codec_range, cx.st) != hipSuccess) return fail("tanh launch failed");
+        ProfSpan sp(e, cx, e->profiling ? e->prof_class(kRvqClass) : 0, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * Dc, 0.0);
+        if (fc::launch_rvq_encode(xq, B * Tf, Dc, e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quant_c, qbdt_c,
                                   sub_quants, Tf, cx.st) != hipSuccess)
             return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256,512})");
+    }
+    float* qbdt = qbdt_c;
+    if (e->q_proj) {       // output_proj (costume_quantizer.py:92-94): decoder input [B][D][Tf] and the returned embeddings [B][Tf][D]
+        fc::Src qs; qs.ptr = qbdt_c; qs.used = 1;
+        Act qo = run_conv(e, cx, e->q_out, qs, fc::Src(), 0, Tf);
+        qbdt = qo.raw;
+        cx.launches++;
+        if (!cx.dry && !cx.err && quantized &&
+            fc::launch_combine(src_of(qo), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, quantized, (long long)Tf * D, 1, D, cx.st) != hipSuccess)
+            return fail("combine launch failed");
     }
     if (quant_bdt_out) *quant_bdt_out = qbdt;
     return cx.err;
@@ -1520,6 +1564,11 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (arch->n_filters % 2) return fail("n_filters must be even");
     const int D = arch->dimension;
     if (!(D == 16 || D == 32 || D == 64 || D == 128 || D == 256 || D == 512)) return fail("dimension must be one of 16/32/64/128/256/512");
+    if (arch->codec_dim < 0 || arch->codec_range < 0.f) return fail("fc_arch.codec_dim / codec_range must be >= 0");
+    if (arch->codec_dim > 0) {
+        const int Dc = arch->codec_dim;
+        if (!(Dc == 16 || Dc == 32 || Dc == 64 || Dc == 128 || Dc == 256 || Dc == 512)) return fail("codec_dim must be one of 16/32/64/128/256/512");
+    }
     if (arch->codebook_size % 64 || (arch->codebook_size > 128 && arch->codebook_size % 128))
         return fail("codebook_size must be a multiple of 64, and of 128 above 128 (8 waves x 16-code tiles)");
     if (arch->lstm_layers > 0 && ((arch->n_filters << arch->n_ratios) % 16)) return fail("LSTM width must be a multiple of 16");
@@ -1684,7 +1733,11 @@ int fc_engine_finalize(fc_engine* e) {
     if (pack_lstm(e, e->dec_lstm)) return 1;
     // codebooks + |e|^2 (EuclideanCodebook.quantize ddp_core_vq.py:185: embed.pow(2).sum(0)); sequential d, squares rounded
     const auto& E = e->host["quantizer.rq.model.embed"].data;
-    const int nq = e->arch.num_quantizers, K = e->arch.codebook_size, D = e->arch.dimension;
+    const int nq = e->arch.num_quantizers, K = e->arch.codebook_size, D = e->cdim();
+    if (e->q_proj) {       // Linear weights [out][in] are the k = 1 GEMM's [M][cin][1]
+        if (pack_gemm(e, e->q_in, e->host["quantizer.input_proj.weight"].data, e->host["quantizer.input_proj.bias"].data)) return 1;
+        if (pack_gemm(e, e->q_out, e->host["quantizer.output_proj.weight"].data, e->host["quantizer.output_proj.bias"].data)) return 1;
+    }
     std::vector<float> en((size_t)nq * K);
     for (size_t r = 0; r < (size_t)nq * K; ++r) {
         volatile float s = 0.f;
@@ -1784,10 +1837,17 @@ int fc_decode_codes(fc_engine* e, const int64_t* codes, int B, int Tf, int n_q, 
     if (!codes || !wav || B <= 0 || Tf <= 0 || out_len <= 0) return fail("bad argument");
     if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
     Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
-    const int D = e->arch.dimension;
-    float* z = cx.alloc<float>((size_t)B * D * Tf);
+    const int D = e->arch.dimension, Dc = e->cdim();
+    float* z = cx.alloc<float>((size_t)B * Dc * Tf);
     if (cx.err) return 1;
-    HIP_TRY(fc::launch_rvq_decode(codes, B, Tf, n_q, D, e->arch.codebook_size, e->cb, emb_out, z, e->status_dev, cx.st));
+    HIP_TRY(fc::launch_rvq_decode(codes, B, Tf, n_q, Dc, e->arch.codebook_size, e->cb, e->q_proj ? nullptr : emb_out, z, e->status_dev, cx.st));
+    if (e->q_proj) {       // CostumeQuantizer.decode (costume_quantizer.py:114-119): output_proj on the summed code vectors
+        fc::Src qs; qs.ptr = z; qs.used = 1;
+        Act qo = run_conv(e, cx, e->q_out, qs, fc::Src(), 0, Tf);
+        if (cx.err) return 1;
+        if (emb_out) HIP_TRY(fc::launch_combine(src_of(qo), fc::Src(), 0, 1.f, nullptr, B, D, Tf, Tf, emb_out, (long long)Tf * D, 1, D, cx.st));
+        z = qo.raw;
+    }
     return do_decode(e, cx, z, Tf, nullptr, out_len, wav);
 }
 
@@ -1812,7 +1872,7 @@ int fc_rvq_encode(fc_engine* e, const float* x, int N, int n_q, int64_t* codes, 
     (void)workspace; (void)workspace_bytes;
     if (!x || !codes || N <= 0) return fail("bad argument");
     if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
-    HIP_TRY(fc::launch_rvq_encode(x, N, e->arch.dimension, e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quantized,
+    HIP_TRY(fc::launch_rvq_encode(x, N, e->cdim(), e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quantized,
                                   nullptr, nullptr, N, (hipStream_t)stream));
     return 0;
 }

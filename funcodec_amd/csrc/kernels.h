@@ -109,6 +109,9 @@ hipError_t launch_combine(const Src& s0, const Src& s1, int elu, float alpha, co
                           int B, int C, int Tsrc, int Tcopy, float* out,
                           long long o_sB, long long o_sC, long long o_sT, hipStream_t st);
 
+// x = tanh(x) * range in place over n floats (CostumeQuantizer.input_act, costume_quantizer.py:32-35,66-67)
+hipError_t launch_tanh_range(float* x, size_t n, float range, hipStream_t st);
+
 // scale[b] = 1e-8 + sqrt(mean_t x[b][t]^2)
 hipError_t launch_volume(const float* wav, int B, int T, float* scale, hipStream_t st);
 

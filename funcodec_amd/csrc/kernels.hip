@@ -1850,6 +1850,16 @@ static int lstm_persist_groups(int B, int H) { return (H == 512 && B > 16) ? 2 :
 __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
 }
+__global__ __launch_bounds__(256) void tanh_range_kernel(float* __restrict__ x, size_t n, float range) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = tanhf(x[i]) * range;
+}
+hipError_t launch_tanh_range(float* x, size_t n, float range, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(tanh_range_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, range);
+    return hipGetLastError();
+}
 hipError_t launch_zero_fill(float* p, size_t n, hipStream_t st) {
     if (n == 0) return hipSuccess;
     size_t blocks = (n + 255) / 256;

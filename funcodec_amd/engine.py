@@ -90,6 +90,8 @@ class CodecEngine:
             a.ratios_f[i] = int(r)
         a.enc_conv_group_ratio, a.dec_conv_group_ratio = arch.enc_conv_group_ratio, arch.dec_conv_group_ratio
         a.dec_tr_conv_group_ratio = arch.dec_tr_conv_group_ratio
+        a.codec_dim = arch.codebook_dim if arch.codebook_dim != arch.dimension else 0
+        a.codec_range = float(arch.codec_range or 0.0)
         h = C.c_void_p()
         self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
         self._h = h
@@ -222,7 +224,7 @@ class CodecEngine:
         dev = self.device
         codes = torch.empty((n_q, B, Tf), dtype=torch.int64, device=dev)
         quant = torch.empty((B, Tf, D), dtype=torch.float32, device=dev)
-        subq = torch.empty((n_q, B, D, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
+        subq = torch.empty((n_q, B, self.arch.codebook_dim, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
         scale = torch.empty((B,), dtype=torch.float32, device=dev) if self.arch.audio_normalize else None
         enc = torch.empty((B, Tf, D), dtype=torch.float32, device=dev) if want_enc_out else None
         ws = self._workspace(B, T)
@@ -243,7 +245,7 @@ class CodecEngine:
         dev = self.device
         codes = torch.empty((n_q, B, Tf), dtype=torch.int64, device=dev)
         quant = torch.empty((B, Tf, D), dtype=torch.float32, device=dev)
-        subq = torch.empty((n_q, B, D, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
+        subq = torch.empty((n_q, B, self.arch.codebook_dim, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
         scale = torch.empty((B,), dtype=torch.float32, device=dev) if self.arch.audio_normalize else None
         recon = torch.empty((B, 1, min(T, self.decoded_samples(Tf))), dtype=torch.float32, device=dev)   # like recon[:, :, :T] of the reference
         ws = self._workspace(B, T)
@@ -316,6 +318,8 @@ class CodecEngine:
     def rvq_encode(self, x: torch.Tensor, n_q: int):
         x = self._dev(x, torch.float32)
         N, D = x.shape
+        if D != self.arch.codebook_dim:
+            raise EngineError(f"rvq_encode: rows must have {self.arch.codebook_dim} dims, got {D}")
         codes = torch.empty((n_q, N), dtype=torch.int64, device=self.device)
         quant = torch.empty((N, D), dtype=torch.float32, device=self.device)
         self._check(self.lib.fc_rvq_encode(self._h, _ptr(x), N, n_q, _ptr(codes), _ptr(quant), None, 0, self._stream()))

@@ -181,5 +181,10 @@ def expected_tensors(a: ArchSpec) -> Dict[str, Tuple[int, ...]]:
                 out[f"{op.key}.weight_hh_l{l}"] = (4 * h, h)
                 out[f"{op.key}.bias_ih_l{l}"] = (4 * h,)
                 out[f"{op.key}.bias_hh_l{l}"] = (4 * h,)
+    if a.codebook_dim != a.dimension:     # CostumeQuantizer.input_proj / output_proj (costume_quantizer.py:27-30)
+        out["quantizer.input_proj.weight"] = (a.codebook_dim, a.dimension)
+        out["quantizer.input_proj.bias"] = (a.codebook_dim,)
+        out["quantizer.output_proj.weight"] = (a.dimension, a.codebook_dim)
+        out["quantizer.output_proj.bias"] = (a.dimension,)
     out["quantizer.rq.model.embed"] = (a.num_quantizers, a.codebook_size, a.codebook_dim)
     return out

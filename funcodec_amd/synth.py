@@ -60,6 +60,10 @@ def make_state_dict(arch: ArchSpec, seed: int = 0, codebook_sigma_decay: float =
                 sd[f"{op.key}.bias_ih_l{l}"] = uni((4 * h,), bound)
                 sd[f"{op.key}.bias_hh_l{l}"] = uni((4 * h,), bound)
     nq, K, D = arch.num_quantizers, arch.codebook_size, arch.codebook_dim
+    if D != arch.dimension:
+        for nm, (o, i) in (("input_proj", (D, arch.dimension)), ("output_proj", (arch.dimension, D))):
+            sd[f"quantizer.{nm}.weight"] = uni((o, i), 1.0 / np.sqrt(i))
+            sd[f"quantizer.{nm}.bias"] = uni((o,), 1.0 / np.sqrt(i))
     sig = (codebook_sigma_decay ** np.arange(nq, dtype=np.float64)).astype(np.float32)[:, None, None]
     embed = rng.standard_normal((nq, K, D)).astype(np.float32) * sig
     pfx = "quantizer.rq.model"

@@ -71,6 +71,10 @@ typedef struct fc_arch {
     int32_t enc_conv_group_ratio;   /* encoder_conf.conv_group_ratio */
     int32_t dec_conv_group_ratio;   /* decoder_conf.conv_group_ratio */
     int32_t dec_tr_conv_group_ratio;/* decoder_conf.tr_conv_group_ratio */
+    /* ABI version 5: CostumeQuantizer's optional projection / range (funcodec/models/quantizer/costume_quantizer.py:23-35,63-73,84-87) */
+    int32_t codec_dim;              /* quantizer_conf.codec_dim: 0 (or = dimension) = none; else the codebooks live in codec_dim dims behind
+                                       input_proj / output_proj Linears (checkpoint keys quantizer.input_proj.*, quantizer.output_proj.*) */
+    float   codec_range;            /* quantizer_conf.codec_range: 0 = none; else the quantiser input is tanh(x) * codec_range */
 } fc_arch;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */

@@ -80,6 +80,10 @@ CASES = [
     ("ds640_wav_jamendo_0027", "ds640", 0, 1.0, "wav:jamendo_0027", 0, 1, 160000, None),
     ("ds320_wav_libritts_5105", "ds320", 0, 1.0, "wav:libritts_5105", 0, 1, 18186, None),
     ("ds320_wav_libritts_8230", "ds320", 0, 1.0, "wav:libritts_8230", 0, 1, 29440, None),
+    # CostumeQuantizer with codec_dim != input_size (input_proj / output_proj Linears) and codec_range (tanh * range), costume_quantizer.py:23-35
+    ("tinycd_b2_t900", "tinycd", 12, 1.0, "tones", 101, 2, 900, None),
+    ("tinyrange_b2_t640", "tinyrange", 13, 1.0, "noise", 103, 2, 640, None),
+    ("ds320cd64_b1_t8000", "ds320cd64", 0, 1.0, "noise", 102, 1, 8000, 8000),
     # pseudo-random small architectures (funcodec_amd/config.py::fuzz_recipe_config): ratios like 3 / 5 / 8, kernel sizes 3 / 5 / 7,
     # compress 1 / 4, 1- and 2-layer LSTMs, dilation bases 1 / 3, ELU alpha 0.7, GroupNorm eps 1e-3, audio_normalize off ...
     ("fuzz2_b2_t5000", "fuzz2", 2, 1.0, "tones", 91, 2, 5000, None),       # GroupNorm, ratios 8,5,3,3, compress 4, 1-layer LSTM(256)

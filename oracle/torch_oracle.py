@@ -211,6 +211,11 @@ class Oracle:
         """DistributedResidualVectorQuantization.forward ddp_core_vq.py:367-418 (eval branch) through
         CostumeQuantizer.inference costume_quantizer.py:77-96.  emb [B,Tf,D] ->
         quantized [B,Tf,D], indices [n_q,B,Tf] i64, sub_quants [n_q,B,D,Tf]."""
+        qc = self.cfg.get("quantizer_conf", {})
+        if "quantizer.input_proj.weight" in self.sd:              # CostumeQuantizer.inference :84-87
+            emb = F.linear(emb, self.sd["quantizer.input_proj.weight"], self.sd["quantizer.input_proj.bias"])
+        if qc.get("codec_range", None) is not None:
+            emb = torch.tanh(emb) * qc["codec_range"]
         x = emb.permute(0, 2, 1)                                  # [B,D,T]
         residual = x
         out = torch.zeros_like(x)
@@ -229,7 +234,10 @@ class Oracle:
             out = out + quant
             all_idx.append(ind)
             all_sub.append(quant)
-        return out.permute(0, 2, 1), torch.stack(all_idx), torch.stack(all_sub)
+        quantized = out.permute(0, 2, 1)
+        if "quantizer.output_proj.weight" in self.sd:             # :92-94
+            quantized = F.linear(quantized, self.sd["quantizer.output_proj.weight"], self.sd["quantizer.output_proj.bias"])
+        return quantized, torch.stack(all_idx), torch.stack(all_sub)
 
     @torch.no_grad()
     def rvq_decode(self, codes: torch.Tensor) -> torch.Tensor:
@@ -237,6 +245,8 @@ class Oracle:
         out = torch.tensor(0.0)
         for i, ind in enumerate(codes):
             out = out + F.embedding(ind, self.embed[i]).permute(0, 2, 1)
+        if "quantizer.output_proj.weight" in self.sd:             # CostumeQuantizer.decode :114-119
+            out = F.linear(out.transpose(1, 2), self.sd["quantizer.output_proj.weight"], self.sd["quantizer.output_proj.bias"]).transpose(1, 2)
         return out
 
     # -- Encodec.inference* --------------------------------------------------------------------

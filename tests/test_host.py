@@ -109,7 +109,8 @@ def test_arch_from_recipe_configs():
     lambda c: (c["encoder_conf"].update(norm="layer_norm"), c["decoder_conf"].update(norm="layer_norm")),
     lambda c: c.update(model="freqcodec"),
     lambda c: c["model_conf"].update(segment_dur=1.0, overlap_ratio=1.5),
-    lambda c: c["quantizer_conf"].update(codec_dim=64),
+    lambda c: c["quantizer_conf"].update(codec_dim=48),                          # a width the quantiser kernels are not built for
+    lambda c: c["quantizer_conf"].update(codec_range=-1.0),
     lambda c: c["decoder_conf"].update(ratios=[8, 5, 4]),
 ])
 def test_out_of_scope_configs_are_refused(mut):
@@ -137,6 +138,12 @@ def test_config_defaults_follow_the_reference_constructor():
         cfg["decoder_conf"][key] = val
         with pytest.raises(NotImplementedError):
             arch_from_config(cfg)
+    a = arch_from_config(recipe_config("ds320cd64"))                    # CostumeQuantizer projection + tanh range
+    assert (a.dimension, a.codebook_dim, a.codec_range) == (128, 64, 2.5)
+    from funcodec_amd.plan import expected_tensors as _et
+    assert _et(a)["quantizer.input_proj.weight"] == (64, 128) and _et(a)["quantizer.rq.model.embed"] == (32, 1024, 64)
+    eng = CodecEngine(a)
+    assert eng.expected_tensors()["quantizer.output_proj.weight"] == (128, 64)
     for name in ("ss320nc", "tinyssnc", "ss640nc", "ds640seg"):                   # the accepted noncausal SoundStream / segmented recipes
         arch_from_config(recipe_config(name))
     # FreqCodec: decoder keys the engine hard-wires are refused when they differ, unknown keys too, and an STFT hop whose window

@@ -5,6 +5,18 @@ import sqlite3
 import sys
 
 
+def demangle(names):
+    import shutil
+    import subprocess
+    tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
+    try:
+        out = subprocess.run([tool], input="\n".join(n.replace(".kd", "") for n in names), capture_output=True, text=True, check=True).stdout
+        res = out.strip("\n").split("\n")
+        return res if len(res) == len(names) else list(names)
+    except Exception:
+        return list(names)
+
+
 def main():
     path = sys.argv[1]
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 30
@@ -13,6 +25,8 @@ def main():
     rows = cur.execute("""select s.kernel_name, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), max(d.end - d.start)
                           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
                           group by s.kernel_name order by 3 desc""").fetchall()
+    dn = demangle([r[0] for r in rows])
+    rows = [(re.sub(r"^void ", "", re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", d)),) + tuple(r[1:]) for d, r in zip(dn, rows)]
     tot = sum(r[2] for r in rows)
     print(f"total kernel time {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} launches")
     lines = ["Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs"]
