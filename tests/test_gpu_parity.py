@@ -685,7 +685,9 @@ def test_freq_codec_against_reference_golden(name):
         cut = _prefix_before(flips, Tf, m.engine.hop_length, b)
         n = g["recon"].shape[-1] if cut is None else min(cut, g["recon"].shape[-1])
         if n > 0 and not ill:
-            assert rms(r2["recon"][b, :, :n], g["recon"][b, :, :n]) < tol, (b, n)
+            # no flip: the tight bar (1e-3 of the signal's RMS).  With a flipped frame elsewhere the GroupNorm(1, C) statistics of every
+            # decoder layer span the whole utterance, so the prefix moves by ~1 / frames of the flip's effect: north_star's absolute bar
+            assert rms(r2["recon"][b, :, :n], g["recon"][b, :, :n]) < (tol if cut is None else WAV_RMS_TOL), (b, n)
     tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
     w2, emb = m.engine.decode_codes(tok)
     assert rms(emb, g["quantized"]) == 0.0
