@@ -6,6 +6,7 @@
 #include "laura_kernels.h"
 
 #include <atomic>
+#include <cstdlib>
 
 namespace fc {
 namespace laura {
@@ -540,6 +541,7 @@ struct GemvArgs {
     int d, Tcap, B, K, N, XS;       // XS = LDS row stride of x
     const float* apart;             // attention partials [B][H][NS][DK + 2] (x is then their combination), or null
     int H, DK, NS;
+    int ablate;                     // FC_GEMV_ABLATE (tuning aid): 1 no x loads, 2 no weight loads, 4 no LayerNorm, 8 no MFMAs
 };
 
 // CPW = 16-wide k chunks per wave as a compile-time constant (2 or 8 for every layer of the recipe): the weight loads are then
@@ -560,32 +562,58 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     constexpr int NPRE = CPW ? CPW : 1;
     f32x4 wv[CPW ? CPW : 8];
 #pragma unroll
-    for (int u = 0; u < NPRE; ++u) wv[u] = *(const f32x4*)(wp + (size_t)u * 256);
+    for (int u = 0; u < NPRE; ++u) wv[u] = (a.ablate & 2) ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(wp + (size_t)u * 256);
+    // epilogue operands (bias, the residual row for mode 1, the cache position for mode 2) requested NOW: fetched at the end of the kernel
+    // they are two serial memory round trips with nothing left to overlap them (measured: ~1.5 us of an 8 us kernel)
+    const int eb = r16 < B ? r16 : 0, en0 = tile * 16 + 4 * g;
+    float ebias[4], eold[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = en0 + r < a.N ? en0 + r : a.N - 1;
+        ebias[r] = a.bias[n];
+        eold[r] = a.mode == 1 ? a.y[(size_t)eb * a.ldy + n] : 0.f;
+    }
+    const int epos = a.mode == 2 ? a.pos[eb] : 0;
     if (a.apart) {
         // x[b][h * DK + dd] = combination of the NS key-range partials of head h (flash-decoding): o_s, running max m_s, sum l_s.
         // First the B * H * NS normalised weights exp(m_s - M) / L (one thread per (b, h); red[] is free until the reduction)
         const int PS = a.DK + 2;
         float* wn = red;
+        // NS <= 8 key ranges; every loop below runs its 8 trips with clamped indices so that the loads are unconditional and
+        // independent (a run-time trip count made each partial its own serialised round trip: 11 us instead of 5 for this kernel)
         for (int e = tid; e < B * a.H; e += 64 * KS) {
             const float* pp = a.apart + (size_t)e * a.NS * PS;
+            float mv[8], lv[8];
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) {
+                const int sc = sp < a.NS ? sp : a.NS - 1;
+                mv[sp] = pp[sc * PS + a.DK];
+                lv[sp] = pp[sc * PS + a.DK + 1];
+            }
             float M = -INFINITY;
-            for (int sp = 0; sp < a.NS; ++sp) M = fmaxf(M, pp[sp * PS + a.DK]);
-            float L = 0.f;
-            for (int sp = 0; sp < a.NS; ++sp) {
-                const float wgt = expf(pp[sp * PS + a.DK] - M);
-                wn[e * a.NS + sp] = wgt;
-                L = fmaf(pp[sp * PS + a.DK + 1], wgt, L);
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) M = fmaxf(M, sp < a.NS ? mv[sp] : -INFINITY);
+            float L = 0.f, wg[8];
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) {
+                wg[sp] = sp < a.NS ? expf(mv[sp] - M) : 0.f;
+                L = fmaf(lv[sp], wg[sp], L);
             }
             const float inv = 1.f / L;
-            for (int sp = 0; sp < a.NS; ++sp) wn[e * a.NS + sp] *= inv;
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) wn[e * 8 + sp] = wg[sp] * inv;
         }
         __syncthreads();
         for (int e = tid; e < B * K; e += 64 * KS) {
             const int b = e / K, k = e - b * K, h = k / a.DK, dd = k - h * a.DK;
             const float* pp = a.apart + ((size_t)(b * a.H + h) * a.NS) * PS + dd;
-            const float* wq = wn + (b * a.H + h) * a.NS;
+            const float* wq = wn + (b * a.H + h) * 8;
+            float ov[8];
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) ov[sp] = pp[(sp < a.NS ? sp : a.NS - 1) * PS];
             float o = 0.f;
-            for (int sp = 0; sp < a.NS; ++sp) o = fmaf(pp[sp * PS], wq[sp], o);
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) o = fmaf(ov[sp], wq[sp], o);        // weights of ranges >= NS are 0
             Xs[b * XS + k] = o;
         }
         for (int k = tid; k < K; k += 64 * KS) Xs[B * XS + k] = 0.f;
@@ -593,13 +621,13 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     } else {
         for (int e = tid * 4; e < (B + 1) * K; e += 64 * KS * 4) {
             const int b = e / K, k = e - b * K;
-            f32x4 v = *(const f32x4*)(a.x + (size_t)(b < B ? b : B - 1) * K + k);      // unconditional load, the zero row by select
+            f32x4 v = (a.ablate & 1) ? (f32x4){1.f, 0.f, 1.f, 0.f} : *(const f32x4*)(a.x + (size_t)(b < B ? b : B - 1) * K + k);      // unconditional load, the zero row by select
             if (b >= B) v = (f32x4){0.f, 0.f, 0.f, 0.f};
             *(f32x4*)(Xs + b * XS + k) = v;
         }
     }
     __syncthreads();
-    if (a.gamma) {       // LayerNorm of every row, two-pass in LDS (one wave per row at a time)
+    if (a.gamma && !(a.ablate & 4)) {       // LayerNorm of every row, two-pass in LDS (one wave per row at a time)
         for (int b = w; b < B; b += KS) {
             float* xr = Xs + b * XS;
             float s = 0.f;
@@ -617,6 +645,7 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
         const f32x4 xv = *(const f32x4*)(xb + u * 16);
+        if (a.ablate & 8) { acc += wv[u] * xv[0]; continue; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[u][j], xv[j], acc, 0, 0, 0);
     }
@@ -639,14 +668,14 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
     for (int u = 1; u < KS; ++u) s += *(const f32x4*)(red + (u * 64 + lane) * 4);
     const int b = r16;
     if (b >= B) return;
-    const int p = a.mode == 2 ? a.pos[b] : 0;
+    const int p = epos;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int n = tile * 16 + 4 * g + r;
         if (n >= a.N) continue;
-        float v = act_f(s[r] + a.bias[n], a.act);
+        float v = act_f(s[r] + ebias[r], a.act);
         if (a.mode == 0) a.y[(size_t)b * a.ldy + n] = v;
-        else if (a.mode == 1) a.y[(size_t)b * a.ldy + n] += v;
+        else if (a.mode == 1) a.y[(size_t)b * a.ldy + n] = eold[r] + v;
         else {
             if (n < a.d) a.y[(size_t)b * a.ldy + n] = v;
             else if (n < 2 * a.d) a.kc[((size_t)b * a.d + (n - a.d)) * a.Tcap + p] = v;
@@ -658,16 +687,19 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
 hipError_t launch_gemv(const Gemv& g, hipStream_t st) {
     if (g.B < 1 || g.B > 16 || g.K % 16 || g.K < 16) return hipErrorInvalidValue;
     const int nch = g.K / 16;
-    int KS = 16;
+    static const int ks_cap = getenv("FC_GEMV_KS") ? atoi(getenv("FC_GEMV_KS")) : 16;     // tuning aid: waves per workgroup
+    int KS = ks_cap >= 1 && ks_cap <= 16 ? ks_cap : 16;
     while (KS > 1 && (nch % KS || nch / KS < 2)) KS >>= 1;     // >= 2 chunks per wave, K split evenly
     if (nch % KS) KS = 1;
     GemvArgs a{g.x, g.wf, g.bias, g.gamma, g.beta, g.eps, g.act, g.mode, g.y, g.ldy, g.kc, g.vc, g.pos, g.d, g.Tcap, g.B, g.K, g.N, g.K + 4,
-               g.apart, g.H, g.DK, g.NS};
-    if (g.apart && (g.H * g.DK != g.K || g.NS < 1 || g.B * g.H * g.NS > KS * 256)) return hipErrorInvalidValue;
+               g.apart, g.H, g.DK, g.NS, 0};
+    static const int ablate = getenv("FC_GEMV_ABLATE") ? atoi(getenv("FC_GEMV_ABLATE")) : 0;
+    a.ablate = ablate;
+    if (g.apart && (g.H * g.DK != g.K || g.NS < 1 || g.NS > 8 || g.B * g.H * 8 > KS * 256)) return hipErrorInvalidValue;
     const size_t lds = ((size_t)(g.B + 1) * a.XS + (size_t)KS * 256) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid(ceil_div_h(g.N, 16));
-    static std::atomic<unsigned long long> d16[3], d8[3], d4[3], d2[3], d1[3];
+    static std::atomic<unsigned long long> d16[6], d8[6], d4[6], d2[6], d1[6];
     hipError_t e;
 #define FC_GEMV_CASE(ks, flag)                                                            \
     if (KS == ks) {                                                                       \
@@ -678,6 +710,15 @@ hipError_t launch_gemv(const Gemv& g, hipStream_t st) {
         } else if (cpw == 8) {                                                            \
             if ((e = big_lds(gemv_kernel<ks, 8>, flag[1])) != hipSuccess) return e;       \
             hipLaunchKernelGGL((gemv_kernel<ks, 8>), grid, dim3(64 * ks), lds, st, a);    \
+        } else if (cpw == 4) {                                                            \
+            if ((e = big_lds(gemv_kernel<ks, 4>, flag[3])) != hipSuccess) return e;       \
+            hipLaunchKernelGGL((gemv_kernel<ks, 4>), grid, dim3(64 * ks), lds, st, a);    \
+        } else if (cpw == 16) {                                                           \
+            if ((e = big_lds(gemv_kernel<ks, 16>, flag[4])) != hipSuccess) return e;      \
+            hipLaunchKernelGGL((gemv_kernel<ks, 16>), grid, dim3(64 * ks), lds, st, a);   \
+        } else if (cpw == 32) {                                                           \
+            if ((e = big_lds(gemv_kernel<ks, 32>, flag[5])) != hipSuccess) return e;      \
+            hipLaunchKernelGGL((gemv_kernel<ks, 32>), grid, dim3(64 * ks), lds, st, a);   \
         } else {                                                                          \
             if ((e = big_lds(gemv_kernel<ks, 0>, flag[2])) != hipSuccess) return e;       \
             hipLaunchKernelGGL((gemv_kernel<ks, 0>), grid, dim3(64 * ks), lds, st, a);    \
@@ -938,11 +979,18 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     for (int k = 0; k < a.nq; ++k) {
         const float* x = lg + k * G;
         // ---- group maximum and its FIRST index (greedy: weighted_scores.topk(1))
+        // the group's logits, once, as 8 unconditional clamped loads per thread (a `for (v = tid; v < G; v += 256)` loop waits for
+        // every load before the next: three such passes per group were most of this kernel's 33 us)
+        constexpr int XPT = FC_SAMPLE_MAXV / 256;
+        float xr[XPT];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) { const int v = tid + 256 * i; xr[i] = x[v < G ? v : G - 1]; }
         float m = -INFINITY;
         int mi = 0x7fffffff;
-        for (int v = tid; v < G; v += 256) {
-            const float xv = x[v];
-            if (xv > m) { m = xv; mi = v; }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int v = tid + 256 * i;
+            if (v < G && xr[i] > m) { m = xr[i]; mi = v; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -960,8 +1008,10 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         if (a.mode != 0) {
             // unnormalised probabilities exp(x - max) (the normaliser cancels in every mode except the nucleus threshold)
             float s = 0.f;
-            for (int v = tid; v < FC_SAMPLE_MAXV; v += 256) {
-                const float e = v < G ? expf(x[v] - m) : -1.f;       // padding sorts last
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int v = tid + 256 * i;
+                const float e = v < G ? expf(xr[i] - m) : -1.f;      // padding sorts last
                 val[v] = e;
                 idx[v] = v;
                 if (v < G) s += e;
@@ -976,19 +1026,22 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 // 8-bit digits of the order-preserving integer image of the float), collect everything >= it, order those few by
                 // (probability descending, index ascending) with a counting rank -- no full sort of the 1025 logits
                 const int kk = a.ki < 1 ? 1 : a.ki;
-                unsigned lk[(FC_SAMPLE_MAXV + 255) / 256];
+                unsigned lk[XPT];
                 int nl = 0;
-                for (int v = tid; v < G; v += 256) {
-                    const unsigned u = __float_as_uint(x[v]);
-                    lk[nl++] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+#pragma unroll
+                for (int i = 0; i < XPT; ++i) {
+                    const unsigned u = __float_as_uint(xr[i]);
+                    lk[i] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    if (tid + 256 * i < G) nl = i + 1;
                 }
                 unsigned prefix = 0u, mask = 0u;
                 int need = kk;
                 for (int shift = 24; shift >= 0; shift -= 8) {
                     hist[tid] = 0u;
                     __syncthreads();
-                    for (int i = 0; i < nl; ++i)
-                        if ((lk[i] & mask) == prefix) atomicAdd(&hist[(lk[i] >> shift) & 255u], 1u);
+#pragma unroll
+                    for (int i = 0; i < XPT; ++i)
+                        if (i < nl && (lk[i] & mask) == prefix) atomicAdd(&hist[(lk[i] >> shift) & 255u], 1u);
                     __syncthreads();
                     if (w == 0) {        // wave 0: lane l owns bins 4l .. 4l+3; suffix sums (bins above) by shuffles, then one lane walks its 4 bins
                         const int h0 = (int)hist[4 * lane], h1 = (int)hist[4 * lane + 1], h2 = (int)hist[4 * lane + 2], h3 = (int)hist[4 * lane + 3];
@@ -1019,13 +1072,13 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 }
                 if (tid == 0) ccount = 0;
                 __syncthreads();
-                {
-                    int i = 0;
-                    for (int v = tid; v < G; v += 256, ++i)
-                        if (lk[i] >= prefix) {
-                            const int slot = atomicAdd(&ccount, 1);
-                            if (slot < 256) { cval[slot] = val[v]; cidx[slot] = v; }
-                        }
+#pragma unroll
+                for (int i = 0; i < XPT; ++i) {
+                    const int v = tid + 256 * i;
+                    if (i < nl && lk[i] >= prefix) {
+                        const int slot = atomicAdd(&ccount, 1);
+                        if (slot < 256) { cval[slot] = val[v]; cidx[slot] = v; }
+                    }
                 }
                 __syncthreads();
                 const int nc = ccount < 256 ? ccount : 256;
