@@ -12,16 +12,20 @@ OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/rp -o out --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rp.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --stats -d $OUT/rp -o out --output-format csv -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/bench_under_rocprof.json 2> $OUT/rp.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile --no-secondary > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o out --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile --no-secondary > /dev/null 2> $OUT/pmc_write.err
 python $R/tools/trace_summary.py $(ls $OUT/rp/*kernel_trace.csv | head -1) > $OUT/last_step_per_launch.txt 2>&1
 python $R/tools/profile_post.py $OUT
-# side measurement of the next scope row (BASELINE.json configs[3] shape): FreqCodec recipe, 64 x 10 s
-python $R/bench.py --workload freqcodec --steps 5 --warmup 2 > $OUT/bench_freqcodec.json 2> $OUT/bench_freqcodec.err
-rocprofv3 --kernel-trace --stats -d $OUT/rpf -o out --output-format csv -- python $R/bench.py --workload freqcodec --steps 2 --warmup 1 --no-cpu-baseline --no-event-profile > /dev/null 2> $OUT/rpf.err
-cp $(ls $OUT/rpf/*kernel_stats.csv | head -1) $OUT/kernel_stats_freqcodec.csv
+# side measurements of the next scope rows on their own (BASELINE.json configs[3] shape with grouped convs, configs[4])
+python $R/bench.py --workload freqcodec_gr1 --steps 5 --warmup 2 > $OUT/bench_freqcodec_gr1.json 2> $OUT/bench_freqcodec_gr1.err
+rocprofv3 --kernel-trace --stats -d $OUT/rpf -o out --output-format csv -- python $R/bench.py --workload freqcodec_gr1 --steps 2 --warmup 1 > /dev/null 2> $OUT/rpf.err
+cp $(ls $OUT/rpf/*kernel_stats.csv | head -1) $OUT/kernel_stats_freqcodec_gr1.csv
 rm -rf $OUT/rpf
+python $R/bench.py --workload laura --steps 5 --warmup 2 > $OUT/bench_laura.json 2> $OUT/bench_laura.err
+rocprofv3 --kernel-trace --stats -d $OUT/rpl -o out --output-format csv -- python $R/bench.py --workload laura --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/rpl.err
+cp $(ls $OUT/rpl/*kernel_stats.csv | head -1) $OUT/kernel_stats_laura.csv
+rm -rf $OUT/rpl
 ls -la $OUT | head -30
 # keep the merge-back small: raw traces are large
 rm -rf $OUT/rp/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write
