@@ -324,6 +324,41 @@ def test_decode_is_batch_independent_and_reproducible():
 
 
 @pytest.mark.gpu
+def test_step_form_long_sequences_against_full_sequence_oracle():
+    """16 utterances (the step form's maximum), recipe-size LM, 300 teacher-forced steps: the KV-cached step form at key counts where
+    the step attention walks SEVERAL 128-key passes per key range (B x H = 128 workgroup slots -> 2 ranges of ~160 keys) and the
+    full-sequence attention spans 21 key tiles, against the oracle's one-pass scores of the same sequences."""
+    from laura_oracle import LauraOracle
+    cfg = laura_recipe_config("lauraphn")
+    spec = laura_spec_from_config(cfg)
+    sd = make_laura_state_dict(cfg, 1)
+    from funcodec_amd.laura import LauraGenMI355X
+    m = LauraGenMI355X(spec, "cuda:0", max_positions=512)
+    m.load_state_dict(sd)
+    orc = LauraOracle(cfg, sd)
+    B, steps = 16, 300
+    lens = [10 + (3 * i) % 17 for i in range(B)]
+    ids = synthetic_text(cfg, B, lens, 41)
+    rng = np.random.Generator(np.random.PCG64(9))
+    forced = rng.integers(0, spec.codebook_size, size=(B, steps, spec.predict_nq)).astype(np.int64)
+    with torch.no_grad():
+        outs, _ = m.encode(torch.from_numpy(ids), torch.tensor(lens))
+        _, out_lens, slp = m.engine.decode_codec(outs, lens, steps, sampling=False, forced=torch.from_numpy(forced), return_logp=True)
+        assert all(v == steps for v in out_lens)
+        full = m.engine.lm_logprobs(outs, lens, torch.from_numpy(forced), [steps] * B).cpu()
+        slp = slp.cpu()
+        for b in range(B):
+            p0 = lens[b] + 1
+            # the engine's two forms agree with each other at every step ...
+            assert float((slp[b] - full[b, p0: p0 + steps]).abs().max()) < 1e-4, b
+        for b in (0, 7, 15):         # ... and with the CPU oracle (three utterances: ~1 s each on the host)
+            seq = orc.llm_input(outs[b, : lens[b]].cpu(), torch.from_numpy(forced[b]))
+            ref = orc.lm_score_all(seq, 1 + lens[b])
+            p0 = lens[b] + 1
+            assert float((slp[b] - ref[p0: p0 + steps]).abs().max()) < LOGP_TOL, b
+
+
+@pytest.mark.gpu
 def test_device_sampler_follows_the_step_distribution():
     """Device-side sampling against the oracle's restatement of LauraGenModel.sampling_ids on the SAME scores: for top-k the drawn
     ids must lie in the reference's candidate set, and over many seeds the empirical distribution of the first sampled token
