@@ -232,3 +232,75 @@ def inference_func(output_dir: Optional[str] = None, batch_size: int = 1, dtype:
         return [{"key": "utt1", "value": ret_val}]
 
     return _forward
+
+
+def inference(output_dir: Optional[str], batch_size: int = 1, dtype: str = "float32", ngpu: int = 1, seed: int = 0, num_workers: int = 0,
+              log_level: Union[int, str] = "INFO", data_path_and_name_and_type=None, key_file: Optional[str] = None,
+              config_file: Optional[str] = None, model_file: Optional[str] = None, model_tag: Optional[str] = None,
+              allow_variable_data_keys: bool = True, streaming: bool = False, **kwargs):
+    """bin/text2audio_inference.py:360-397."""
+    pipeline = inference_func(output_dir=output_dir, batch_size=batch_size, dtype=dtype, ngpu=ngpu, seed=seed, num_workers=num_workers,
+                              log_level=log_level, key_file=key_file, config_file=config_file, model_file=model_file, model_tag=model_tag,
+                              allow_variable_data_keys=allow_variable_data_keys, streaming=streaming,
+                              **{k: v for k, v in kwargs.items() if k not in ("raw_inputs", "mode", "gpuid_list")})
+    return pipeline(data_path_and_name_and_type, raw_inputs=kwargs.get("raw_inputs", None))
+
+
+def _int_or_float_or_bool(value: str):
+    """funcodec/utils/types.py int_or_float_or_bool: "true"/"false" -> bool, "25" -> int, "0.8" -> float (the --sampling argument)."""
+    v = value.strip().lower()
+    if v in ("true", "false"):
+        return v == "true"
+    try:
+        return int(v)
+    except ValueError:
+        return float(v)
+
+
+def get_parser():
+    """Same flags as the reference's CLI (bin/text2audio_inference.py:400-536); `python -m funcodec_amd.bin.text2audio_inference ...`
+    accepts the command lines of egs/LibriTTS/text2speech_laura/demo.sh (minus --tokenize_to_phone true: pass phoneme strings)."""
+    def str2bool(v):
+        return str(v).lower() in ("true", "1", "yes")
+
+    p = argparse.ArgumentParser(description="Text to audio generation", formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--log_level", type=lambda x: x.upper(), default="INFO", choices=("CRITICAL", "ERROR", "WARNING", "INFO", "DEBUG", "NOTSET"))
+    p.add_argument("--output_dir", type=str, required=False)
+    p.add_argument("--ngpu", type=int, default=1)
+    p.add_argument("--gpuid_list", type=str, default="0")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--dtype", default="float32", choices=["float16", "float32", "float64"])
+    p.add_argument("--num_workers", type=int, default=0)
+    g = p.add_argument_group("Input data related")
+    g.add_argument("--data_path_and_name_and_type", type=str, required=False, action="append")
+    g.add_argument("--raw_inputs", type=str, required=False, action="append")
+    g.add_argument("--key_file", type=str, default=None)
+    g.add_argument("--allow_variable_data_keys", type=str2bool, default=False)
+    g = p.add_argument_group("The model configuration related")
+    g.add_argument("--mode", type=str, default="inference mode")
+    g.add_argument("--config_file", type=str)
+    g.add_argument("--model_file", type=str)
+    g.add_argument("--model_tag", type=str)
+    p.add_argument("--batch_size", type=int, default=1)
+    p.add_argument("--beam_size", type=int, default=1)
+    g.add_argument("--text_emb_model", type=str, default="./exp/t5-base")
+    g.add_argument("--sampling", type=_int_or_float_or_bool, default="true")
+    g.add_argument("--codec_config_file", type=str, default=None)
+    g.add_argument("--codec_model_file", type=str, default=None)
+    g.add_argument("--continual", type=int, default=0)
+    g.add_argument("--tokenize_to_phone", type=str2bool, default=False)
+    g.add_argument("--exclude_prompt", type=str2bool, default=True)
+    return p
+
+
+def main(cmd=None):
+    args = get_parser().parse_args(cmd)
+    kwargs = vars(args)
+    gpuid = kwargs["gpuid_list"].split(",")[0] or "0"          # one process drives one GPU (bin/text2audio_inference.py:545-556)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(gpuid))
+    inference(**kwargs)
+
+
+if __name__ == "__main__":
+    main()

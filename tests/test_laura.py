@@ -150,6 +150,23 @@ def test_library_exports_the_laura_entry_points():
     assert declared == {n for n in _lib.SYMBOLS if n.startswith("fc_laura_")}
 
 
+def test_text2audio_cli_parser_and_sampling_argument():
+    """`--sampling` is the reference's int_or_float_or_bool (25 -> top-k, 0.8 -> nucleus, true / false -> softmax / greedy) and maps
+    onto the engine's (mode, k, p); the CLI takes demo.sh's command line."""
+    from funcodec_amd.bin.text2audio_inference import get_parser
+    from funcodec_amd.laura import sampling_args
+    a = get_parser().parse_args(["--config_file", "c.yaml", "--model_file", "m.pth", "--codec_config_file", "cc.yaml", "--codec_model_file",
+                                 "cm.pth", "--sampling", "25", "--continual", "2500", "--raw_inputs", "text", "--raw_inputs", "prompt text",
+                                 "--raw_inputs", "p.wav", "--output_dir", "out", "--log_level", "warning"])
+    assert a.sampling == 25 and isinstance(a.sampling, int) and a.continual == 2500 and a.raw_inputs == ["text", "prompt text", "p.wav"]
+    assert sampling_args(a.sampling) == (2, 25, 0.0)
+    assert sampling_args(True) == (1, 0, 0.0) and sampling_args(False) == (0, 0, 0.0) and sampling_args(0.8) == (3, 0, 0.8)
+    assert get_parser().parse_args(["--sampling", "false"]).sampling is False
+    assert get_parser().parse_args(["--sampling", "0.9"]).sampling == 0.9
+    with pytest.raises(NotImplementedError):
+        sampling_args("nucleus")
+
+
 def test_laura_engine_refuses_cpu():
     from funcodec_amd.engine import EngineError
     from funcodec_amd.laura import LauraEngine
