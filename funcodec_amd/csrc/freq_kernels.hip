@@ -228,20 +228,31 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
     if (live) {
         // the stride between the FO rows' windows is a run-time value; the reference's 2-D nets use sf == KF / 2 for strided layers and
         // sf == 1 otherwise, which is what the (row, output) -> tap table below is unrolled for
-#pragma unroll
-        for (int r = 0; r < KF + (FO - 1) * (KF >= 4 ? KF / 2 : 1); ++r) {
+        constexpr int NR = KF + (FO - 1) * (KF >= 4 ? KF / 2 : 1);
+        // round 3: the NEXT input row's loads are requested before the current row is activated and multiplied (two register sets): as
+        // one straight-line block per row the loads of row r + 1 were issued only after row r's ~150 VALU instructions had retired
+        f32x4 rbuf0[2][CPG][NV], rbuf1[2][DUAL ? CPG : 1][NV];
+        auto load_row = [&](int r, int slot) __attribute__((always_inline)) {
             int rr = fo0 * sf + r;
             rr = rr > row_max ? row_max : rr;
-            f32x4 r0[CPG][NV], r1[DUAL ? CPG : 1][NV];
 #pragma unroll
             for (int ci = 0; ci < CPG; ++ci) {   // straight-line loads of the whole input row
                 const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)ci * p.Tin + qsafe;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    r0[ci][v] = *(const f32x4u*)(p.src0 + off + 4 * v);
-                    if (DUAL) r1[ci][v] = *(const f32x4u*)(p.src1 + off + 4 * v);
+                    rbuf0[slot][ci][v] = *(const f32x4u*)(p.src0 + off + 4 * v);
+                    if (DUAL) rbuf1[slot][ci][v] = *(const f32x4u*)(p.src1 + off + 4 * v);
                 }
             }
+        };
+        load_row(0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            int rr = fo0 * sf + r;
+            rr = rr > row_max ? row_max : rr;
+            if (r + 1 < NR) load_row(r + 1, (r + 1) & 1);
+            f32x4 (&r0)[CPG][NV] = rbuf0[r & 1];
+            f32x4 (&r1)[DUAL ? CPG : 1][NV] = rbuf1[r & 1];
 #pragma unroll
             for (int ci = 0; ci < CPG; ++ci) {
                 const float2 A = a0 ? a0[ci] : make_float2(1.f, 0.f);
