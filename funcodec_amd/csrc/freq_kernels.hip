@@ -446,11 +446,14 @@ __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
             }
             if (row_ok) {
                 float* orow = p.out + (size_t)b * p.out_sB + ((size_t)fo * p.cout + co) * p.Tout;
+                const int to0 = tu0 - p.trimL;
+                if (to0 >= 0 && to0 + 3 < p.Tout) *(f32x4u*)(orow + to0) = (f32x4){ov[0], ov[1], ov[2], ov[3]};     // one 16-byte store (round 3)
+                else
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int to = tu0 + j - p.trimL;
-                    if (to >= 0 && to < p.Tout) orow[to] = ov[j];
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        const int to = to0 + j;
+                        if (to >= 0 && to < p.Tout) orow[to] = ov[j];
+                    }
             }
         }
     }
