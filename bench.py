@@ -128,14 +128,39 @@ def pmc_traffic(kernel: str):
     if not files:
         return None
     try:
+        base = kernel.split("<")[0]
         for k in json.load(open(files[-1]))["per_kernel"]:
-            if k["kernel"] == kernel and k["launches"]:
+            if (k["kernel"] == kernel or (base == "lstm_persist_kernel" and k["kernel"].startswith(base))) and k["launches"]:
                 return {"bytes_per_launch": round((2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0 / k["launches"]),
                         "fetch_x2_gb": round(2.0 * k["fetch_kb"] * 1024.0 / 1e9, 3), "write_gb": round(k["write_kb"] * 1024.0 / 1e9, 3),
                         "launches": k["launches"], "source": os.path.basename(files[-1])}
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def laura_step_pmc_traffic():
+    """HBM bytes per LauraTTS decoding step from the committed PMC table (tools/pmc_laura.sh -> profiles/r*_pmc_laura.txt): the step
+    kernels' (fetch x 2 + write) x launches, divided by the number of sampler launches (one per step).  None without the profile."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_laura.txt")))
+    if not files:
+        return None
+    tot, steps = 0.0, 0
+    for ln in open(files[-1]):
+        f = ln.split()
+        if len(f) < 8 or not f[0].startswith("fc::laura::"):
+            continue
+        # columns: kernel(may hold a space after a comma) ... launches us GHz busy insts fetchMB writeMB
+        try:
+            launches, fetch_mb, write_mb = int(f[-7]), float(f[-2]), float(f[-1])
+        except ValueError:
+            continue
+        if any(k in ln for k in ("gemv_kernel", "attn_step_kernel", "sample_kernel", "layernorm_rows_kernel")):
+            tot += launches * (fetch_mb + write_mb) * 1e6
+        if "sample_kernel" in ln:
+            steps = launches
+    return {"bytes_per_step": round(tot / steps), "source": os.path.basename(files[-1])} if steps else None
 
 
 def kernel_rooflines(prof, prof_steps):
@@ -187,8 +212,10 @@ def kernel_rooflines(prof, prof_steps):
     top = max(kern, key=lambda k: k["ms_per_step"]) if kern else None
     if top is not None and "roofline" in out and top["kernel"] != out["roofline"]["kernel"] and top["tflops"]:
         out["roofline_conv"] = out["roofline"]
+        ttr = pmc_traffic(top["kernel"])
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(top["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": None,
+                           "frac": round(top["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": (ttr or {}).get("bytes_per_launch"),
+                           "traffic_detail": ttr,
                            "avg_us_per_launch": top["avg_us_per_launch"], "launches_per_step": top["launches_per_step"],
                            "ms_per_step": top["ms_per_step"],
                            "share_of_kernel_time": round(top["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in kern)), 4),
@@ -338,9 +365,10 @@ def laura_side(batch: int = 8, text_len: int = 100, prompt_frames: int = 75, new
            "phases_ms": {"text_encoder": round(phases[0] / steps, 3), "decode_codec": round(ar_ms, 3),
                          "codec_emb": round(phases[2] / steps, 3), "codec_decoder": round(phases[3] / steps, 3)},
            "decode_step_us": round(ar_step_us, 2),
-           "roofline": {"bound": "hbm", "kernel": "decoding step (64 launches: weight-streaming MFMA GEMVs + KV-cache attention)",
+           "roofline": {"bound": "hbm", "kernel": "decoding step (62 launches: weight-streaming MFMA GEMVs + KV-cache attention)",
                         "achieved": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
-                        "frac": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4), "traffic": None,
+                        "frac": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4),
+                        "traffic": (laura_step_pmc_traffic() or {}).get("bytes_per_step"), "traffic_detail": laura_step_pmc_traffic(),
                         "algorithmic_bytes_per_step": round(w_bytes + kv_bytes), "weights_bytes": round(w_bytes), "kv_bytes_avg": round(kv_bytes),
                         "step_tflops": round(step_flops / (ar_step_us * 1e-6) / 1e12, 3)}}
     if batch == 8:
