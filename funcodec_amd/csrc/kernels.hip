@@ -1659,7 +1659,10 @@ hipError_t launch_lstm_wave(const float* const* w, const float* const* bias, con
 // -------------------------------------------------------------------------------------------------
 struct LstmPersistArgs {
     const float *w0, *w1, *bias1, *xproj;
-    float* hist;         // [BH zeros][T x BH: h0(0..T-1)][T x BH: h1(0..T-1)]
+    float* hist;         // [BH zeros][T x BH: h0(0..T-1)][T x BH: h1(0..T-1)], BH = 16 * tiles * H; one slot = [batch tile][H/4][16 rows][4 units]:
+                         // the 64 lanes of a consumer's B-fragment load read 1 KiB of CONTIGUOUS memory (lane (g, r) = 16 bytes at 16*lane),
+                         // and the 64 producer lanes of a workgroup write one contiguous 256-byte piece.  (Row-major [B][H] put the 16 lanes
+                         // of a fragment row 4 KiB apart -- every lane of a load on its own cache line: 7.2 us per step instead of 5.1.)
     float* y;
     unsigned* sync;      // 16 counters at [32*i], error flag at [512]; zeroed by the caller before every launch
     unsigned* status;    // host-visible engine status words (kernels.h FC_STATUS_*), or null
@@ -1670,10 +1673,16 @@ struct LstmPersistArgs {
 };
 
 constexpr int kLstmSyncWords = 1024;
+// profiling builds only (FC_BUILD_DEFINES="FC_LSTM_ABL=<mask>", results are garbage): 1 no critical-path MFMAs, 2 no hidden-state loads,
+// 4 no shadow MFMAs, 8 no y stores, 16 no store drain before the arrival.  Compile time, because a run-time branch around the loads
+// would make hipcc wait for them at the join.
+#ifndef FC_LSTM_ABL
+#define FC_LSTM_ABL 0
+#endif
 
 // split grid barrier: arrive (after this workgroup's stores have drained) ... independent work ... wait
 __device__ __forceinline__ void lstm_barrier_arrive(unsigned* sync, int blk) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its own write-through stores
+    if (!(FC_LSTM_ABL & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its own write-through stores
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(sync + 32 * (blk & 15), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1712,7 +1721,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     unsigned* const sync = p.sync + (size_t)grp * kLstmSyncWords;
     const unsigned arrivals = (unsigned)wgs >> 4;    // per counter per step
     const int kslice = NS * 16;                      // H / 4 waves
-    const size_t BH = (size_t)B * H;
+    const int tile0 = grp;                           // first batch tile of this group (groups > 1 run with NBT == 1)
+    const size_t BH = (size_t)16 * (p.groups > 1 ? p.groups : NBT) * H;   // floats per history slot (batch padded to whole tiles)
     // ---- weights -> registers (once)
     f32x4 a0[NS], a1i[NS], a1h[NS];
     {
@@ -1748,7 +1758,8 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
         for (int nb = 0; nb < NBT; ++nb) {
             const int brow = brow0 + nb * 16 + r16;
             const bool bvalid = brow < B;
-            const size_t hoff = (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
+            // rows >= B of the last tile are never written: their columns compute values nobody stores (MFMA columns are independent)
+            const size_t hoff = (size_t)(tile0 + nb) * 16 * H + (size_t)wid * kslice * 16 + 4 * lane;
             f32x4 xp = {0.f, 0.f, 0.f, 0.f};
             if (wid == 0 && act0)
                 xp = *(const f32x4*)(p.xproj + ((size_t)s * B + (bvalid ? brow : 0)) * 4 * H + (size_t)blk * 16 + 4 * g);
@@ -1760,8 +1771,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             // of loads and 2.1 us of MFMAs ran back to back).  Columns of rows >= B read row 0 and compute values nobody stores.
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
-                b0[q] = *(const f32x4*)(h0in + hoff + 16 * q);
-                b1[q] = *(const f32x4*)(h1in + hoff + 16 * q);
+                if (FC_LSTM_ABL & 2) { b0[q] = (f32x4){0.f, 0.f, 0.f, 0.f}; b1[q] = b0[q]; continue; }
+                b0[q] = *(const f32x4*)(h0in + hoff + 256 * q);
+                b1[q] = *(const f32x4*)(h1in + hoff + 256 * q);
             }
             // four accumulators (layer 0 / layer 1 x even / odd k slice); the ISSUE order interleaves them so that two
             // MFMAs on the same accumulator are never back to back, the order WITHIN each accumulator is that of
@@ -1769,7 +1781,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             f32x4 c0a = {0.f, 0.f, 0.f, 0.f}, c0b = {0.f, 0.f, 0.f, 0.f};
             f32x4 c1a = pa[nb], c1b = pb[nb];
 #pragma unroll
-            for (int q = 0; q < NS; q += 2) {
+            for (int q = 0; q < ((FC_LSTM_ABL & 1) ? 0 : NS); q += 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     c0a = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q][j], b0[q][j], c0a, 0, 0, 0);
@@ -1796,8 +1808,9 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
                     const float hn = go * tanh_f(cn);
                     cst[nb] = cn;
                     const size_t ci = (size_t)brow * H + (size_t)blk * 4 + g;
-                    if (layer == 0) __hip_atomic_store(&h0o[ci], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else { __hip_atomic_store(&h1o[ci], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); p.y[ci * T + (s - 2)] = hn; }
+                    const size_t hi = (size_t)(tile0 + nb) * 16 * H + ((size_t)blk * 16 + r16) * 4 + g;
+                    if (layer == 0) __hip_atomic_store(&h0o[hi], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else { __hip_atomic_store(&h1o[hi], hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (!(FC_LSTM_ABL & 8)) p.y[ci * T + (s - 2)] = hn; }
                 }
             }
             __syncthreads();
@@ -1809,18 +1822,16 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
         if (s >= 1) {
 #pragma unroll
             for (int nb = 0; nb < NBT; ++nb) {
-                const int brow = brow0 + nb * 16 + r16;
-                const bool bvalid = brow < B;
-                const size_t hoff = (size_t)(bvalid ? brow : 0) * H + wid * kslice + 4 * g;
+                const size_t hoff = (size_t)(tile0 + nb) * 16 * H + (size_t)wid * kslice * 16 + 4 * lane;
                 f32x4 b0l[NBT == 1 ? 1 : NS];
                 f32x4 (&b0)[NS] = *(NBT == 1 ? &b0keep : (f32x4 (*)[NS])&b0l);
                 if (NBT > 1) {                        // several batch tiles: re-read (L2 hit) instead of holding NBT x 64 registers
 #pragma unroll
-                    for (int q = 0; q < NS; ++q) b0[q] = *(const f32x4*)(h0in + hoff + 16 * q);
+                    for (int q = 0; q < NS; ++q) b0[q] = *(const f32x4*)(h0in + hoff + 256 * q);
                 }
                 f32x4 c1a = {0.f, 0.f, 0.f, 0.f}, c1b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int q = 0; q < NS; q += 2) {
+                for (int q = 0; q < ((FC_LSTM_ABL & 4) ? 0 : NS); q += 2) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         c1a = __builtin_amdgcn_mfma_f32_16x16x4f32(a1i[q][j], b0[q][j], c1a, 0, 0, 0);
@@ -1868,8 +1879,10 @@ hipError_t launch_zero_fill(float* p, size_t n, hipStream_t st) {
     return hipGetLastError();
 }
 
-size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)(2 * T + 1) * B * H; }
-size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)B * H; }
+// history slots hold whole 16-row batch tiles (LstmPersistArgs::hist)
+static size_t lstm_persist_slot_floats(int B, int H) { return (size_t)16 * ((B + 15) / 16) * H; }
+size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)(2 * T + 1) * lstm_persist_slot_floats(B, H); }
+size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + lstm_persist_slot_floats(B, H); }
 
 // `state`: lstm_persist_state_floats() floats whose first lstm_persist_clear_floats() are zero (barrier words + the
 // all-zero initial hidden state)

@@ -365,7 +365,7 @@ class CodecEngine:
         if want is None or want[1] != H:
             raise EngineError(f"lstm {prefix!r}: expected input [B, {want[1] if want else '?'}, T], got {tuple(x.shape)}")
         y = torch.empty_like(x)
-        need = (T * B * 4 * H + 3 * B * H + B * H * T) * 4 * self.arch.lstm_layers + (1 << 20)
+        need = (T * B * 4 * H + 3 * B * H + B * H * T + (2 * T + 1) * 16 * ((B + 15) // 16) * H) * 4 * self.arch.lstm_layers + (1 << 20)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         ws = self._ws

@@ -341,6 +341,33 @@ def test_decode_is_batch_independent_and_reproducible():
 
 
 @pytest.mark.gpu
+def test_limits_fail_loudly_and_leave_the_engine_usable():
+    """What does not fit the engine's position tables / batch limit is an EngineError carrying the reason, never a truncated result,
+    and the engine answers the next call as before; the smallest inputs (one text token, one step) work."""
+    from funcodec_amd.engine import EngineError
+    name = "laura_tiny_b3"
+    c, cfg, spec, sd, text, _ = case_inputs(name)
+    g = golden(name)
+    m = laura_engine(name)                      # max_positions = 256
+    lens = c["text_lengths"]
+    outs = torch.from_numpy(g["text_outs"])
+    ref = m.engine.decode_codec(outs, lens, 6, sampling=False)
+    with pytest.raises(EngineError, match="max_positions"):
+        m.engine.decode_codec(outs, lens, 256, sampling=False)
+    with pytest.raises(EngineError, match="max_positions"):
+        m.encode(torch.from_numpy(synthetic_text(cfg, 1, [300], 3)), torch.tensor([300]))
+    with pytest.raises(EngineError, match="at most"):
+        m.engine.decode_codec(outs[:1].repeat(17, 1, 1), [lens[0]] * 17, 4, sampling=False)
+    again = m.engine.decode_codec(outs, lens, 6, sampling=False)
+    assert torch.equal(ref[0], again[0]) and ref[1] == again[1]
+    one = torch.from_numpy(synthetic_text(cfg, 1, [1], 5))
+    o1, l1 = m.encode(one, torch.tensor([1]))
+    assert o1.shape[:2] == (1, 1) and bool(torch.isfinite(o1).all())
+    t, ol = m.engine.decode_codec(o1, [1], 1, sampling=False)
+    assert ol == [1] and t.shape[1] >= 1
+
+
+@pytest.mark.gpu
 def test_step_form_long_sequences_against_full_sequence_oracle():
     """16 utterances (the step form's maximum), recipe-size LM, 300 teacher-forced steps: the KV-cached step form at key counts where
     the step attention walks SEVERAL 128-key passes per key range (B x H = 128 workgroup slots -> 2 ranges of ~160 keys) and the
@@ -392,6 +419,10 @@ def test_device_sampler_follows_the_step_distribution():
     N = 400
     counts = np.zeros(9)
     top5 = set(p0.topk(5)[1].tolist())
+    top100 = set(p0.topk(100)[1].tolist())
+    sv, si = p0.sort(descending=True, stable=True)
+    nucleus = set(si[: int((torch.cumsum(sv, 0) < 0.7).sum()) + 2].tolist())
+    seen100, seen_n = set(), set()
     for s in range(N):
         t, _ = m.engine.decode_codec(outs, [lens[0]], 1, sampling=True, seed=1000 + s)
         tid = int(t[0, 0, 0])
@@ -400,6 +431,14 @@ def test_device_sampler_follows_the_step_distribution():
         if s < 60:
             t5, _ = m.engine.decode_codec(outs, [lens[0]], 1, sampling=5, seed=s)
             assert int(t5[0, 0, 0]) in top5
+            # k > 64 takes the sampler's sort path instead of the radix select; a float is nucleus sampling (the shortest prefix
+            # of the descending sort whose mass reaches p; one more candidate allowed for a cumulative sum rounding across p)
+            t100, _ = m.engine.decode_codec(outs, [lens[0]], 1, sampling=100, seed=s)
+            assert int(t100[0, 0, 0]) in top100
+            tn, _ = m.engine.decode_codec(outs, [lens[0]], 1, sampling=0.7, seed=s)
+            assert int(tn[0, 0, 0]) in nucleus
+            seen100.add(int(t100[0, 0, 0])); seen_n.add(int(tn[0, 0, 0]))
+    assert len(seen100) > 5 and len(seen_n) > 1, (seen100, seen_n)      # they do sample, not return the arg-max
     expect = np.concatenate([p0[top8].numpy(), [1.0 - float(p0[top8].sum())]]) * N
     chi2 = float(((counts - expect) ** 2 / np.maximum(expect, 1e-9)).sum())
     assert chi2 < 27.9, (chi2, counts, expect)        # chi-square, 8 degrees of freedom, p = 0.0005

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import torch
 from helpers import engine_for
 
-which = sys.argv[1] if len(sys.argv) > 1 else "encoder"
+which = {"encoder": "encoder.model.16.lstm", "decoder": "decoder.model.1.lstm"}.get(sys.argv[1] if len(sys.argv) > 1 else "encoder", sys.argv[1] if len(sys.argv) > 1 else "")
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 250
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
 m = engine_for(os.environ.get("FC_CFG", "ds640"), 0)
