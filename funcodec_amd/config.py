@@ -195,8 +195,16 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
 
     ratios2 = shared("ratios", [[4, 1], [4, 1], [4, 2], [4, 1]])
     dimension = int(enc.get("dimension", 128))
-    if q.get("codec_dim", None) not in (None, dimension) or q.get("codec_range", None) is not None or q.get("q0_ds_ratio", 1) != 1:
-        raise _unsupported("quantizer_conf.codec_dim/codec_range/q0_ds_ratio", (q.get("codec_dim"), q.get("codec_range"), q.get("q0_ds_ratio")))
+    if q.get("q0_ds_ratio", 1) != 1:
+        raise _unsupported("quantizer_conf.q0_ds_ratio", q.get("q0_ds_ratio"))
+    # CostumeQuantizer's projection / tanh range (costume_quantizer.py:23-35), as for the time-domain codec
+    codec_dim = q.get("codec_dim", None)
+    codec_dim = dimension if codec_dim is None else int(codec_dim)
+    if codec_dim not in (16, 32, 64, 128, 256, 512):
+        raise _unsupported("quantizer_conf.codec_dim", q.get("codec_dim"), "the quantiser kernels are built for 16/32/64/128/256/512 dims")
+    codec_range = q.get("codec_range", None)
+    if codec_range is not None and not float(codec_range) > 0:
+        raise _unsupported("quantizer_conf.codec_range", codec_range)
     if int(shared("n_residual_layers", 1)) != 1 and int(shared("dilation_base", 2)) != 1:
         raise _unsupported("n_residual_layers/dilation_base", (enc.get("n_residual_layers"), enc.get("dilation_base")))
     dc = dict(m.get("domain_conf", {}) or {})
@@ -218,7 +226,8 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         dilation_base=int(shared("dilation_base", 2)), compress=int(shared("compress", 2)),
         lstm_layers=int(shared("seq_layer_num", 2)) if seq_model == "lstm" else 0, lstm_skip=bool(shared("res_seq", True)),
         elu_alpha=float(act_params.get("alpha", 1.0)), gn_eps=float(norm_params.get("eps", 1e-5)),
-        codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=dimension, num_quantizers=int(q.get("num_quantizers", 8)),
+        codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=codec_dim, num_quantizers=int(q.get("num_quantizers", 8)),
+        codec_range=None if codec_range is None else float(codec_range),
         encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
         use_ddp=bool(q.get("use_ddp", True)), norm="time_group_norm", causal=False,
         segment_dur=None if seg is None else float(seg), overlap_ratio=0.01 if ov is None else float(ov),
@@ -392,6 +401,8 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
     if name.startswith("freqfuzz"):
         return fuzz_freq_recipe_config(int(name[8:]))
+    cd = name.endswith("cd")                          # CostumeQuantizer projection to codec_dim = 32 + tanh range (costume_quantizer.py:23-35)
+    name = name[:-2] if cd else name
     seg = name.endswith("seg")                        # FreqCodec._encode / _decode in segmented mode: 0.15 s frames, 10 % overlap
     name = name[:-3] if seg else name
     angle = name.endswith("ang")                      # freqcodec_mag_angle_16k_n32_600k_step.yaml (refused by arch_from_config)
@@ -416,13 +427,16 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
             dec.update(n_filters=8)
         enc.update(conv_group_ratio=gr)
         dec.update(conv_group_ratio=gr, tr_conv_group_ratio=gr)
+    qc = {"codebook_size": 64 if tiny else 1024, "num_quantizers": 4 if tiny else 32, "ema_decay": 0.99,
+          "kmeans_init": True, "sampling_rate": 16000, "quantize_dropout": True,
+          "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 640 if ds640 else 320}
+    if cd:
+        qc.update(codec_dim=32, codec_range=2.0)
     return {
         "input_size": 2 if angle else 3, "sampling_rate": 16000,
         "encoder": "encodec_seanet_encoder_2d", "encoder_conf": enc,
         "quantizer": "costume_quantizer",
-        "quantizer_conf": {"codebook_size": 64 if tiny else 1024, "num_quantizers": 4 if tiny else 32, "ema_decay": 0.99,
-                           "kmeans_init": True, "sampling_rate": 16000, "quantize_dropout": True,
-                           "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 640 if ds640 else 320},
+        "quantizer_conf": qc,
         "decoder": "encodec_seanet_decoder_2d", "decoder_conf": dec,
         "discriminator": "multiple_disc", "discriminator_conf": {"disc_conf_list": []},
         "model": "freq_codec",

@@ -186,7 +186,14 @@ def make_freq_state_dict(cfg: Dict[str, Any], seed: int = 0) -> Dict[str, np.nda
         sd[f"{key}.norm.weight"] = (1.0 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
         sd[f"{key}.norm.bias"] = (0.1 * rng.standard_normal(cout)).astype(np.float32)
     q = cfg["quantizer_conf"]
-    nq, K, D = q["num_quantizers"], q["codebook_size"], cfg["encoder_conf"].get("dimension", 128)
+    dim = cfg["encoder_conf"].get("dimension", 128)
+    nq, K, D = q["num_quantizers"], q["codebook_size"], q.get("codec_dim") or dim
+    if D != dim:      # CostumeQuantizer.input_proj / output_proj (costume_quantizer.py:27-30); drawn AFTER everything else so that the
+        prng = np.random.Generator(np.random.PCG64(seed + 7919))       # checkpoints of the configs without a projection do not change
+        for nm, (o, i) in (("input_proj", (D, dim)), ("output_proj", (dim, D))):
+            b = 1.0 / np.sqrt(i)
+            sd[f"quantizer.{nm}.weight"] = prng.uniform(-b, b, size=(o, i)).astype(np.float32)
+            sd[f"quantizer.{nm}.bias"] = prng.uniform(-b, b, size=(o,)).astype(np.float32)
     embed = rng.standard_normal((nq, K, D)).astype(np.float32)
     pfx = "quantizer.rq.model"
     sd[f"{pfx}.inited"] = np.ones((nq, 1), np.float32)

@@ -106,6 +106,8 @@ FREQ_CASES = [
     ("tinyfreqgr1_b2_t2500", "tinyfreqgr1", 7, "tones", 84, 2, 2500),
     # segmented mode (FreqCodec._encode / _decode with model_conf.segment_dur: 2400-sample frames, stride 2160, triangle overlap-add)
     ("tinyfreqseg_b2_t6000", "tinyfreqseg", 8, "tones", 85, 2, 6000),
+    # CostumeQuantizer's input / output projection (codec_dim = 32 != dimension = 16) and tanh range behind the 2-D encoder
+    ("tinyfreqcd_b2_t2000", "tinyfreqcd", 9, "tones", 86, 2, 2000),
     # the reference's own demo recordings (real speech / music) through the FreqCodec recipe
     ("freqmp_wav_libritts_5105", "freqmp", 0, "wav:libritts_5105", 0, 1, 18186),
     ("freqmp_wav_libritts_8230", "freqmp", 0, "wav:libritts_8230", 0, 1, 29440),

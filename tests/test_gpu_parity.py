@@ -652,6 +652,8 @@ def test_freq_codec_against_reference_golden(name):
     # fp32 FFT is replaced by the exact transform.  Bins near the FFT's rounding floor carry phases made of rounding noise (10 % of the
     # bins of the band-limited jamendo recording sit below 1e-3: 5.7e-4; speech and synthetic cases: 1e-6 .. 3e-5), so a fixture pins
     # any second implementation only down to that number.
+    # with CostumeQuantizer's projection the quantised embedding leaves a GEMM (output_proj): float-close instead of bit-exact
+    qtol = 1e-5 * float(np.sqrt((g["quantized"] ** 2).mean())) if m.arch.codebook_dim != m.arch.dimension else 0.0
     noise = float(c.get("stft_self_noise", 0.0))
     assert rms(r["enc_out"], g["encoder_out"]) < max(1e-4, 2.0 * noise)
     ill = noise > 1e-4
@@ -672,7 +674,7 @@ def test_freq_codec_against_reference_golden(name):
         _assert_flips_are_near_ties(freq_state_for(c["config"], c["weight_seed"])[2]["quantizer.rq.model.embed"], g["encoder_out"],
                                     g["indices"].astype(np.int64), r["codes"], got_enc=r["enc_out"], max_frames=1)
     else:
-        assert rms(r["quantized"], g["quantized"]) == 0.0
+        assert rms(r["quantized"], g["quantized"]) <= qtol
     r2 = m.engine.encode_decode(wav, c["n_q"], use_scale=True)
     m.engine.check_status()
     assert ill or torch.equal(r2["codes"], r["codes"])
@@ -690,9 +692,10 @@ def test_freq_codec_against_reference_golden(name):
             assert rms(r2["recon"][b, :, :n], g["recon"][b, :, :n]) < (tol if cut is None else WAV_RMS_TOL), (b, n)
     tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
     w2, emb = m.engine.decode_codes(tok)
-    assert rms(emb, g["quantized"]) == 0.0
+    assert rms(emb, g["quantized"]) <= qtol
     w3 = m.engine.decode_emb(torch.from_numpy(g["quantized"]))
-    assert w2.shape[-1] == m.engine.decoded_samples(g["indices"].shape[2]) and torch.equal(w2, w3)
+    assert w2.shape[-1] == m.engine.decoded_samples(g["indices"].shape[2])
+    assert torch.equal(w2, w3) if qtol == 0.0 else rms(w2, w3) < 1e-5 * float(w3.pow(2).mean().sqrt())
     n = g["recon"].shape[-1]
     sc = torch.from_numpy(g["scale"]).view(-1, 1, 1) if "scale" in g else 1.0
     assert rms(w2.cpu()[:, :, :n] * sc, g["recon"]) < WAV_RMS_TOL * float(np.sqrt((g["recon"] ** 2).mean())) * 10
