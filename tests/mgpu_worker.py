@@ -39,15 +39,18 @@ def main():
     model.engine.check_status()                                    # no barrier timeout went unnoticed
     assert codes.shape == (32, total, 100)
     # one step shaped like bench.py's Config C path (BASELINE.json configs[2]): the ds640 net, this rank's utterances walked in
-    # micro-batches of 32 (two batch tiles of the persistent LSTM per recurrence step), the gather inside the step; scaled down
-    # to 40 utterances of 1 s per rank so that the first >= 2-GPU box to run the suite exercises the exact bench code path
+    # micro-batches of 16 like bench.py, plus one call of 32 (two batch tiles of the persistent LSTM per recurrence step: the other
+    # instantiation), the gather inside the step; scaled down to 40 utterances of 1 s per rank so that the first >= 2-GPU box to run
+    # the suite exercises the exact bench code path
     arch_c = arch_from_config(recipe_config("ds640"))
     model_c = EncodecMI355X(arch_c, f"cuda:{local}")
     model_c.load_state_dict({k: torch.from_numpy(v) for k, v in make_state_dict(arch_c, 0).items()})
     model_c.engine.micro_batch = 32
     per = 40
     wav_c = torch.from_numpy(synthetic_audio(per, 16000, 1234 + rank)).cuda()
-    parts = [model_c.engine.encode_decode(wav_c[i:i + 32], 32, use_scale=True)["codes"] for i in range(0, per, 32)]
+    parts = [model_c.engine.encode_decode(wav_c[i:i + 16], 32, use_scale=True)["codes"] for i in range(0, per, 16)]
+    both = model_c.engine.encode_decode(wav_c[:32], 32, use_scale=True)["codes"]
+    assert torch.equal(both, torch.cat(parts[:2], 1)), "a 32-utterance call differs from two 16-utterance calls"
     codes_c = gather_codes(torch.cat(parts, 1), dist, shard_sizes=[per] * world)
     torch.cuda.synchronize()
     model_c.engine.check_status()
