@@ -408,20 +408,38 @@ __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
     const float* zm = zq - rowsz;                                               // input row q - 1 (row -1 = the zero halo)
     const int kt = 2 * TR, kf = 2 * p.fr;
     float s1v = 0.f, s2v = 0.f;
+    // wave-uniform: every lane's columns i0 - 1 .. i0 + max(NI, 4) - 2 lie inside the input row (all but the first and the last wave of a row)
+    const bool fast = __all(live && i0 >= 1 && i0 + (NI > 4 ? NI - 2 : 2) < p.Tin);
     if (live) {
         for (int co = 0; co < p.cout; ++co) {
             float x[2][2][NI];                       // [ci][row q / q - 1][columns i0 - 1 .. i0 + NI - 2]
+            if (fast) {
+                // whole wave inside the row: ONE 16-byte load (+ one dword for the fifth column of TR = 1) per (channel, row) instead of
+                // NI dword loads -- the kernel is bound by the address path (PMC: TA busy 89 - 92 %, tools/pmc_ta.sh), not by HBM or latency
+                // (issuing the loads of channel pair co + 1 ahead of the arithmetic of pair co changed nothing: 1.64 vs 1.63 ms)
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
+                for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const float* row = (r ? zm : zq) + (size_t)(2 * co + ci) * p.Tin;
+                    for (int r = 0; r < 2; ++r) {
+                        const float* row = (r ? zm : zq) + (size_t)(2 * co + ci) * p.Tin + (i0 - 1);
+                        const f32x4 v = *(const f32x4u*)row;
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) {
-                        const int t = i0 - 1 + j;
-                        x[ci][r][j] = (t >= 0 && t < p.Tin) ? row[t] : 0.f;
+                        for (int j = 0; j < (NI < 4 ? NI : 4); ++j) x[ci][r][j] = v[j];
+                        if (NI > 4) x[ci][r][NI - 1] = row[4];
                     }
-                }
+            } else {
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const float* row = (r ? zm : zq) + (size_t)(2 * co + ci) * p.Tin;
+#pragma unroll
+                        for (int j = 0; j < NI; ++j) {
+                            const int t = i0 - 1 + j;
+                            x[ci][r][j] = (t >= 0 && t < p.Tin) ? row[t] : 0.f;
+                        }
+                    }
+            }
             float acc[4];
             const float bm = p.bias[co];
 #pragma unroll
