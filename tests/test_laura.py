@@ -340,6 +340,24 @@ def test_decode_is_batch_independent_and_reproducible():
         assert all(v == 8 for v in o) and int(t.max()) < 1024 and int(t.min()) >= 0
 
 
+_fuzz_models = {}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 1, 2, 5, 7, 23])
+def test_random_shapes_against_oracle(seed):
+    """tools/fuzz_laura.py's trial (the one-off sweep over 36 seeds was clean): a random batch size (1 .. 16), ragged text lengths, with /
+    without ragged audio prompts, 1 .. 23 steps, the three tiny configurations in turn (embedding / phoneme inputs, split / uni
+    positions) -- text encoder, greedy KV-cached decoding (tokens identical), per-step log-probabilities, fine predictor."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_laura", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                            "tools", "fuzz_laura.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    name, B, steps, prompt, w = mod.trial(seed, _fuzz_models)
+    assert w["enc"] < 1e-4 and w["fine"] < 1e-4 and w["step_logp"] < LOGP_TOL and w["greedy_mismatch_utts"] == 0, (name, B, steps, prompt, w)
+
+
 @pytest.mark.gpu
 def test_limits_fail_loudly_and_leave_the_engine_usable():
     """What does not fit the engine's position tables / batch limit is an EngineError carrying the reason, never a truncated result,
