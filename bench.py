@@ -8,7 +8,7 @@
 One "step" = one Speech2Token(run_mod="inference") pass (encode -> 32-stage RVQ -> decode) over this rank's utterances of
 synthetic 10 s / 16 kHz audio on the 16k-nq32ds640 architecture:
   N = 1: BASELINE.json configs[1], 16 x 10 s in ONE engine call;
-  N > 1: BASELINE.json configs[2], 128 utterances per GPU (1024 at N = 8) walked in micro-batches of 16 (every op of the path is
+  N > 1: BASELINE.json configs[2], 128 utterances per GPU (1024 at N = 8) walked in micro-batches of 32 (every op of the path is
          per-utterance, results do not depend on the micro-batch), the int64 code indices all-gathered over RCCL inside the step.
 `--workload freqcodec` is a SIDE measurement of the next scope row (BASELINE.json configs[3]: the STFT-domain FreqCodec recipe, 64 x 10 s
 on one GPU); the contract metric stays the default.
@@ -28,10 +28,10 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 # utterances per engine call.  N = 1 is Config B itself (16 utterances, one call).  For N > 1 (Config C, 128 per GPU) the micro-batch
-# is free (every op is per-utterance).  Rounds 1 - 2 used 32 there (two LSTM batch tiles per recurrence step: 1 % better per utterance);
-# with the round-3 LSTM layout one 16-row tile per step is the faster form (measured on one GPU at Config C's per-GPU shape, 128 x 10 s:
-# 126.1 ms in micro-batches of 16 = 10 150 audio-s/s, 131.6 ms in micro-batches of 32; FC_BENCH_MICRO overrides).
-MICRO_BATCH = int(os.environ.get("FC_BENCH_MICRO", "0")) or 16
+# is free (every op is per-utterance): 32 doubles the tile count of the layers at the bottleneck frame rate; the persistent LSTM
+# (H = 1024 fills the chip with one 16-utterance tile) runs its second tile as a second launch.  Measured on one GPU at Config C's
+# per-GPU rate (64 x 10 s): 62.7 ms in micro-batches of 32 = 10 205 audio-s/s, 63.3 ms in micro-batches of 16; FC_BENCH_MICRO overrides.
+MICRO_BATCH = int(os.environ.get("FC_BENCH_MICRO", "0")) or (16 if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 32)
 SAMPLES = 160000
 CONFIG = os.environ.get("FC_BENCH_CONFIG", "ds640")   # the contract metric is ds640; other recipes only for side measurements
 PEAK_F32_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 matrix (= vector) peak
@@ -494,7 +494,7 @@ def main():
     eng = model.engine
     eng.micro_batch = max(eng.micro_batch, MICRO_BATCH)      # one engine call per bench micro-batch
 
-    # N = 1: Config B (16 utterances, one engine call).  N > 1: Config C (128 utterances per GPU, micro-batches of 16).
+    # N = 1: Config B (16 utterances, one engine call).  N > 1: Config C (128 utterances per GPU, micro-batches of 32).
     utts_per_gpu = int(os.environ.get("FC_BENCH_UTTS", MICRO_BATCH if world == 1 else 128))     # freqcodec: 64 (configs[3])
     total_utts = utts_per_gpu * world
     lo, hi = shard_range(total_utts, rank, world)

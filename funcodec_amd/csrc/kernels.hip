@@ -1668,6 +1668,7 @@ struct LstmPersistArgs {
     unsigned* status;    // host-visible engine status words (kernels.h FC_STATUS_*), or null
     int B, H, T;
     int ablate;          // FC_ABLATE_LSTM env: 1 no grid barrier (profiling aid), 64 test hook: behave as if the grid barrier had timed out
+    int tile_base, tiles;   // first 16-row batch tile of this launch / tiles of the whole call (history slot size, barrier word block)
     int groups;          // independent recurrences in one launch: group j = workgroups [j*H/4, (j+1)*H/4) owns batch rows [16j, 16j+16) with
                          // its own barrier words (H = 512 fills only half of the chip: two batch tiles then advance side by side)
 };
@@ -1717,12 +1718,12 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     const int wgs = H >> 2;                          // workgroups of one recurrence
     const int grp = p.groups > 1 ? blockIdx.x / wgs : 0;
     const int blk = blockIdx.x - grp * wgs;
-    const int brow0 = grp * 16;                      // first batch row of this group (groups > 1 run with NBT == 1)
-    unsigned* const sync = p.sync + (size_t)grp * kLstmSyncWords;
+    const int tile0 = p.tile_base + grp;             // first batch tile of this group (groups > 1 run with NBT == 1)
+    const int brow0 = tile0 * 16;                    // its first batch row
+    unsigned* const sync = p.sync + (size_t)tile0 * kLstmSyncWords;
     const unsigned arrivals = (unsigned)wgs >> 4;    // per counter per step
     const int kslice = NS * 16;                      // H / 4 waves
-    const int tile0 = grp;                           // first batch tile of this group (groups > 1 run with NBT == 1)
-    const size_t BH = (size_t)16 * (p.groups > 1 ? p.groups : NBT) * H;   // floats per history slot (batch padded to whole tiles)
+    const size_t BH = (size_t)16 * p.tiles * H;      // floats per history slot (batch padded to whole tiles)
     // ---- weights -> registers (once)
     f32x4 a0[NS], a1i[NS], a1h[NS];
     {
@@ -1880,9 +1881,10 @@ hipError_t launch_zero_fill(float* p, size_t n, hipStream_t st) {
 }
 
 // history slots hold whole 16-row batch tiles (LstmPersistArgs::hist)
-static size_t lstm_persist_slot_floats(int B, int H) { return (size_t)16 * ((B + 15) / 16) * H; }
-size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + (size_t)(2 * T + 1) * lstm_persist_slot_floats(B, H); }
-size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords * lstm_persist_groups(B, H) + lstm_persist_slot_floats(B, H); }
+static int lstm_persist_tiles(int B) { return (B + 15) / 16; }
+static size_t lstm_persist_slot_floats(int B, int H) { return (size_t)16 * lstm_persist_tiles(B) * H; }
+size_t lstm_persist_state_floats(int B, int H, int T) { return (size_t)kLstmSyncWords * lstm_persist_tiles(B) + (size_t)(2 * T + 1) * lstm_persist_slot_floats(B, H); }
+size_t lstm_persist_clear_floats(int B, int H) { return (size_t)kLstmSyncWords * lstm_persist_tiles(B) + lstm_persist_slot_floats(B, H); }
 
 // `state`: lstm_persist_state_floats() floats whose first lstm_persist_clear_floats() are zero (barrier words + the
 // all-zero initial hidden state)
@@ -1890,11 +1892,14 @@ hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bi
                                int B, int H, int T, unsigned* status, hipStream_t st) {
     LstmPersistArgs a;
     const int groups = lstm_persist_groups(B, H);
-    a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.hist = state + (size_t)kLstmSyncWords * groups; a.y = y;
-    a.sync = (unsigned*)state; a.status = status; a.B = B; a.H = H; a.T = T; a.groups = groups;
+    const int tiles = lstm_persist_tiles(B);
+    a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.hist = state + (size_t)kLstmSyncWords * tiles; a.y = y;
+    a.sync = (unsigned*)state; a.status = status; a.B = B; a.H = H; a.T = T; a.groups = groups; a.tile_base = 0; a.tiles = tiles;
     static const int ablate = getenv("FC_ABLATE_LSTM") ? atoi(getenv("FC_ABLATE_LSTM")) : 0;
     a.ablate = ablate;
-    const int nbt = groups > 1 ? 1 : (B + 15) / 16;
+    // H = 1024 fills the chip with ONE batch tile: a second tile (17 .. 32 utterances) is a second launch of the same kernel on its own
+    // history columns and barrier words (round 3: 2 x 1.26 ms; the two-tiles-per-step instantiation needed 3.14 ms with the new history
+    // layout).  H = 512: two tiles side by side as two groups of 128 workgroups in one launch.
     dim3 grid(H / 4 * groups), block(256);
     // FC_LSTM_COOP=1: hipLaunchCooperativeKernel (the runtime validates the grid against the occupancy query at every launch,
     // +15-19 us of host time per launch); default: plain launch, residency validated once per engine by lstm_persist_supported()
@@ -1906,10 +1911,9 @@ hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bi
                     if (ec != hipSuccess) return ec; }                                                            \
         else hipLaunchKernelGGL((lstm_persist_kernel<NS, NBT>), grid, block, 0, st, a);                            \
     } while (0)
-    if (H == 1024 && nbt == 1) FC_LP(16, 1);
-    else if (H == 1024 && nbt == 2) FC_LP(16, 2);
-    else if (H == 512 && nbt == 1) FC_LP(8, 1);
-    else if (H == 512 && nbt == 2) FC_LP(8, 2);
+    if (H == 1024) {
+        for (int tb = 0; tb < tiles; ++tb) { a.tile_base = tb; FC_LP(16, 1); }
+    } else if (H == 512 && groups == tiles) FC_LP(8, 1);
     else return hipErrorInvalidValue;
 #undef FC_LP
     return hipGetLastError();
@@ -1925,13 +1929,10 @@ bool lstm_persist_supported(int B, int H, int L, int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
     const int groups = lstm_persist_groups(B, H);
-    const int nbt = groups > 1 ? 1 : (B + 15) / 16;
     int per_cu = 0;
     hipError_t e = hipErrorInvalidValue;
-    if (H == 1024 && nbt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16, 1>, 256, 0);
-    else if (H == 1024 && nbt == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16, 2>, 256, 0);
-    else if (H == 512 && nbt == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 1>, 256, 0);
-    else if (H == 512 && nbt == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 2>, 256, 0);
+    if (H == 1024) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16, 1>, 256, 0);
+    else if (H == 512) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 1>, 256, 0);
     if (e != hipSuccess || per_cu < 1) return false;
     return (long long)per_cu * prop.multiProcessorCount >= H / 4 * groups && prop.multiProcessorCount >= H / 4 * groups;
 }

@@ -39,8 +39,8 @@ def main():
     model.engine.check_status()                                    # no barrier timeout went unnoticed
     assert codes.shape == (32, total, 100)
     # one step shaped like bench.py's Config C path (BASELINE.json configs[2]): the ds640 net, this rank's utterances walked in
-    # micro-batches of 16 like bench.py, plus one call of 32 (two batch tiles of the persistent LSTM per recurrence step: the other
-    # instantiation), the gather inside the step; scaled down to 40 utterances of 1 s per rank so that the first >= 2-GPU box to run
+    # micro-batches of 32 like bench.py (the persistent LSTM runs the second 16-utterance tile as a second launch), checked against
+    # calls of 16, the gather inside the step; scaled down to 40 utterances of 1 s per rank so that the first >= 2-GPU box to run
     # the suite exercises the exact bench code path
     arch_c = arch_from_config(recipe_config("ds640"))
     model_c = EncodecMI355X(arch_c, f"cuda:{local}")
@@ -48,9 +48,9 @@ def main():
     model_c.engine.micro_batch = 32
     per = 40
     wav_c = torch.from_numpy(synthetic_audio(per, 16000, 1234 + rank)).cuda()
-    parts = [model_c.engine.encode_decode(wav_c[i:i + 16], 32, use_scale=True)["codes"] for i in range(0, per, 16)]
-    both = model_c.engine.encode_decode(wav_c[:32], 32, use_scale=True)["codes"]
-    assert torch.equal(both, torch.cat(parts[:2], 1)), "a 32-utterance call differs from two 16-utterance calls"
+    parts = [model_c.engine.encode_decode(wav_c[i:i + 32], 32, use_scale=True)["codes"] for i in range(0, per, 32)]
+    halves = [model_c.engine.encode_decode(wav_c[i:i + 16], 32, use_scale=True)["codes"] for i in (0, 16)]
+    assert torch.equal(parts[0], torch.cat(halves, 1)), "a 32-utterance call differs from two 16-utterance calls"
     codes_c = gather_codes(torch.cat(parts, 1), dist, shard_sizes=[per] * world)
     torch.cuda.synchronize()
     model_c.engine.check_status()
