@@ -109,7 +109,7 @@ struct Ctx {
 
 int ceil_div_i(int a, int b) { return (a + b - 1) / b; }
 
-const char* kLstmPersistClass = "lstm_persist_kernel<NS, NBT> (whole recurrence of one SLSTM block, one launch)";
+const char* kLstmPersistClass = "lstm_persist_kernel<NS> (whole recurrence of one SLSTM block, one launch)";
 const char* kLstmWaveClass = "lstm_wave_kernel<NS> (whole recurrence of one SLSTM block: T + L - 1 launches incl. gaps)";
 const char* kRvqClass = "rvq_encode_kernel<D, RS> (all stages of the residual quantiser)";
 

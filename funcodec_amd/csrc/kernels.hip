@@ -1708,8 +1708,11 @@ __device__ __forceinline__ void lstm_barrier_wait(unsigned* sync, unsigned targe
 // step later than its data dependence requires so that its input half, P = W_ih1 . h0(s-1), is computed in the SHADOW
 // of the grid barrier of step s (after this workgroup has arrived, before it starts polling) and only the two
 // recurrent products (W_hh0 . h0(s-1), W_hh1 . h1(s-3)) sit on the critical path between two barriers.
-template <int NS, int NBT>
+template <int NS>
 __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistArgs p) {
+    // batch tiles (16 rows) per workgroup and step.  Fixed at one since round 3: a second tile of a call is a second group (H = 512) or a
+    // second launch (H = 1024); the tile loops below are what is left of the two-tiles-per-step form (3.14 vs 2 x 1.26 ms) and fold away.
+    constexpr int NBT = 1;
     static_assert(NS % 2 == 0, "k slices are issued in pairs");
     __shared__ f32x4 red[2][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1905,15 +1908,15 @@ hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bi
     // +15-19 us of host time per launch); default: plain launch, residency validated once per engine by lstm_persist_supported()
     static const int coop = getenv("FC_LSTM_COOP") ? atoi(getenv("FC_LSTM_COOP")) : 0;
     void* kargs[] = {(void*)&a};
-#define FC_LP(NS, NBT)                                                                                           \
+#define FC_LP(NS)                                                                                                \
     do {                                                                                                         \
-        if (coop) { hipError_t ec = hipLaunchCooperativeKernel((const void*)lstm_persist_kernel<NS, NBT>, grid, block, kargs, 0, st); \
+        if (coop) { hipError_t ec = hipLaunchCooperativeKernel((const void*)lstm_persist_kernel<NS>, grid, block, kargs, 0, st); \
                     if (ec != hipSuccess) return ec; }                                                            \
-        else hipLaunchKernelGGL((lstm_persist_kernel<NS, NBT>), grid, block, 0, st, a);                            \
+        else hipLaunchKernelGGL((lstm_persist_kernel<NS>), grid, block, 0, st, a);                                 \
     } while (0)
     if (H == 1024) {
-        for (int tb = 0; tb < tiles; ++tb) { a.tile_base = tb; FC_LP(16, 1); }
-    } else if (H == 512 && groups == tiles) FC_LP(8, 1);
+        for (int tb = 0; tb < tiles; ++tb) { a.tile_base = tb; FC_LP(16); }
+    } else if (H == 512 && groups == tiles) FC_LP(8);
     else return hipErrorInvalidValue;
 #undef FC_LP
     return hipGetLastError();
@@ -1931,8 +1934,8 @@ bool lstm_persist_supported(int B, int H, int L, int device) {
     const int groups = lstm_persist_groups(B, H);
     int per_cu = 0;
     hipError_t e = hipErrorInvalidValue;
-    if (H == 1024) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16, 1>, 256, 0);
-    else if (H == 512) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8, 1>, 256, 0);
+    if (H == 1024) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<16>, 256, 0);
+    else if (H == 512) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_persist_kernel<8>, 256, 0);
     if (e != hipSuccess || per_cu < 1) return false;
     return (long long)per_cu * prop.multiProcessorCount >= H / 4 * groups && prop.multiProcessorCount >= H / 4 * groups;
 }

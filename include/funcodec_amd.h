@@ -200,7 +200,7 @@ int fc_engine_work(const fc_engine* e, int B, int T, int n_q, fc_work* out);
  * last event, returns per-kernel-class totals accumulated since the last read and resets them. */
 typedef struct fc_prof {
     char    kernel[64];      /* named like rocprofv3 prints it, e.g. "conv_mfma_kernel<128, 128, 2, 2, 0, 8, false>",
-                                "lstm_persist_kernel<NS, NBT> (...)" for the persistent recurrence */
+                                "lstm_persist_kernel<NS> (...)" for the persistent recurrence */
     double  total_ms;        /* sum of event-to-event durations */
     double  flops, bytes;    /* algorithmic work of those launches */
     int32_t launches;
