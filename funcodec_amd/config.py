@@ -141,7 +141,7 @@ def _check_seanet_conf(conf: Dict[str, Any], which: str) -> Dict[str, Any]:
 
 def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     """``model: freq_codec`` (FreqCodec, codec_freq.py:123-210) with the 2-D SEANet nets; only the recipe's
-    ``codec_domain: [mag_phase, mag_phase]`` over a GroupNorm, non-causal, un-grouped net is built."""
+    ``codec_domain: [mag_phase, mag_phase]`` is built (GroupNorm or weight_norm nets, the latter optionally causal; grouped convs)."""
     if cfg.get("encoder") != "encodec_seanet_encoder_2d" or cfg.get("decoder") != "encodec_seanet_decoder_2d":
         raise _unsupported("encoder/decoder", (cfg.get("encoder"), cfg.get("decoder")), "freq_codec needs the 2-D SEANet nets")
     if cfg.get("quantizer", "costume_quantizer") != "costume_quantizer":
@@ -149,8 +149,11 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     enc, dec = dict(cfg.get("encoder_conf", {}) or {}), dict(cfg.get("decoder_conf", {}) or {})
     q, m = dict(cfg.get("quantizer_conf", {}) or {}), dict(cfg.get("model_conf", {}) or {})
     for which, conf in (("encoder_conf", enc), ("decoder_conf", dec)):
-        if conf.get("norm", "weight_norm") != "time_group_norm" or conf.get("causal", False):
-            raise _unsupported(f"{which}.norm/causal", (conf.get("norm", "weight_norm"), conf.get("causal", False)), "GroupNorm non-causal only")
+        nrm, cau = conf.get("norm", "weight_norm"), bool(conf.get("causal", False))
+        if nrm not in ("time_group_norm", "weight_norm"):
+            raise _unsupported(f"{which}.norm", nrm, "time_group_norm or weight_norm")
+        if nrm == "time_group_norm" and cau:
+            raise _unsupported(f"{which}.causal", True, "GroupNorm convs cannot be causal (the reference refuses it too, conv.py:46-47)")
         if dict(conf.get("norm_params", {}) or {}).get("num_groups", 1) != 1:
             raise _unsupported(f"{which}.norm_params.num_groups", conf["norm_params"]["num_groups"])
         for key, ok in (("true_skip", False), ("pad_mode", "reflect"),
@@ -229,7 +232,7 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=codec_dim, num_quantizers=int(q.get("num_quantizers", 8)),
         codec_range=None if codec_range is None else float(codec_range),
         encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
-        use_ddp=bool(q.get("use_ddp", True)), norm="time_group_norm", causal=False,
+        use_ddp=bool(q.get("use_ddp", True)), norm=str(shared("norm", "weight_norm")), causal=bool(shared("causal", False)),
         segment_dur=None if seg is None else float(seg), overlap_ratio=0.01 if ov is None else float(ov),
         model_type="freq_codec", n_fft=int(dc.get("n_fft", 512)), stft_hop=int(dc.get("hop_length", 160)),
         enc_conv_group_ratio=int(enc.get("conv_group_ratio", -1)), dec_conv_group_ratio=int(dec.get("conv_group_ratio", -1)),
@@ -403,6 +406,10 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
         return fuzz_freq_recipe_config(int(name[8:]))
     cd = name.endswith("cd")                          # CostumeQuantizer projection to codec_dim = 32 + tanh range (costume_quantizer.py:23-35)
     name = name[:-2] if cd else name
+    wnc = name.endswith("wnc")                        # weight_norm + causal 2-D nets (conv.py:317-447 with causal = True)
+    name = name[:-3] if wnc else name
+    wn = name.endswith("wn")                          # weight_norm (no GroupNorm) 2-D nets
+    name = name[:-2] if wn else name
     seg = name.endswith("seg")                        # FreqCodec._encode / _decode in segmented mode: 0.15 s frames, 10 % overlap
     name = name[:-3] if seg else name
     angle = name.endswith("ang")                      # freqcodec_mag_angle_16k_n32_600k_step.yaml (refused by arch_from_config)
@@ -417,6 +424,8 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     ds640 = name.endswith("640")
     ratios = [[4, 2], [4, 1], [4, 2], [4, 1]] if ds640 else [[4, 1], [4, 1], [4, 2], [4, 1]]
     enc = {"ratios": ratios, "norm": "time_group_norm", "norm_params": {"num_groups": 1}, "causal": False, "dilation_base": 1}
+    if wn or wnc:
+        enc = {"ratios": ratios, "norm": "weight_norm", "causal": bool(wnc), "dilation_base": 1}
     dec = dict(enc, channels=2 if angle else 3)
     if tiny:
         enc.update(n_filters=4, dimension=16)

@@ -246,11 +246,36 @@ ConvLayer mk_conv2d(const std::string& prefix, int cin, int cout, int kf, int kt
 inline int group_count(int n, int ratio) { return ratio > 0 ? n / 2 / ratio : 1; }
 
 void add_conv2d_expect(fc_engine* e, ConvLayer& L) {
-    e->expected.push_back({L.prefix + ".conv.weight", {L.cout, L.c2d / (L.groups > 0 ? L.groups : 1), L.kf, L.k}});   // groups < 1 is refused at create
+    const int cpg = L.c2d / (L.groups > 0 ? L.groups : 1);                         // groups < 1 is refused at create
+    if (L.wnorm) {                                                                 // torch.nn.utils.weight_norm, dim 0 (conv.py:24-25)
+        e->expected.push_back({L.prefix + ".conv.weight_g", {L.cout, 1, 1, 1}});
+        e->expected.push_back({L.prefix + ".conv.weight_v", {L.cout, cpg, L.kf, L.k}});
+    } else {
+        e->expected.push_back({L.prefix + ".conv.weight", {L.cout, cpg, L.kf, L.k}});
+    }
     e->expected.push_back({L.prefix + ".conv.bias", {L.cout}});
-    e->expected.push_back({L.prefix + ".norm.weight", {L.cout}});
-    e->expected.push_back({L.prefix + ".norm.bias", {L.cout}});
+    if (L.has_norm) {
+        e->expected.push_back({L.prefix + ".norm.weight", {L.cout}});
+        e->expected.push_back({L.prefix + ".norm.bias", {L.cout}});
+    }
     e->by_prefix[L.prefix] = &L;
+}
+
+// the weight a weight-normed 2-D layer computes in its forward pre-hook: v * (g / ||v||), the norm over every dim but 0 (`key` = prefix +
+// ".conv" / ".convtr"; d0 = out channels of Conv2d, IN channels of ConvTranspose2d); the plain weight otherwise
+std::vector<float> folded_weight_nd(fc_engine* e, const std::string& key, bool wnorm, size_t d0) {
+    if (!wnorm) return e->host[key + ".weight"].data;
+    const auto& V = e->host[key + ".weight_v"].data;
+    const auto& G = e->host[key + ".weight_g"].data;
+    const size_t inner_n = V.size() / d0;
+    std::vector<float> folded(V.size());
+    for (size_t r = 0; r < d0; ++r) {
+        double ss = 0.0;
+        for (size_t j = 0; j < inner_n; ++j) ss += (double)V[r * inner_n + j] * (double)V[r * inner_n + j];
+        const float sc = G[r] / (float)sqrt(ss);
+        for (size_t j = 0; j < inner_n; ++j) folded[r * inner_n + j] = V[r * inner_n + j] * sc;
+    }
+    return folded;
 }
 
 // CostumeQuantizer (costume_quantizer.py:7-55): the codebooks, and with codec_dim != input_size the two Linears around them
@@ -338,6 +363,17 @@ void build_plan_2d(fc_engine* e) {
     const int F = a.n_fft / 2 + 1, taps = ceil_div_i(a.n_fft, a.stft_hop);
     e->stft = mk_conv("stft", a.stft_hop, 2 * F, taps, 1);
     e->stft.valid = true; e->stft.has_norm = false; e->stft.synthetic = true;
+    {   // norm / causality of every layer of the nets (norm_type 0: GroupNorm(1, C) after each conv; 1: weight_norm, optionally causal in time)
+        auto flag = [&](ConvLayer& L) { L.has_norm = a.norm_type == 0; L.wnorm = a.norm_type == 1; L.causal = a.causal != 0; };
+        flag(e->enc2_first); flag(e->enc_last); flag(e->dec_first); flag(e->dec2_last);
+        for (auto* stages : {&e->enc_stages, &e->dec_stages})
+            for (auto& S : *stages) {
+                flag(S.resample);
+                for (auto& R : S.res) { flag(R.shortcut); flag(R.block1); flag(R.block3); }
+            }
+        for (auto& ph : e->dec_up_phases)
+            for (auto& L : ph) flag(L);
+    }
     e->istft = mk_conv("istft", 2 * F, a.stft_hop, taps, 1);
     e->istft.zpadL = taps - 1; e->istft.zpadR = taps - 1; e->istft.has_norm = false; e->istft.synthetic = true;
     // ---- checkpoint contract, in execution order
@@ -365,10 +401,18 @@ void build_plan_2d(fc_engine* e) {
     add_conv_expect(e, e->dec_first);
     add_lstm(e->dec_lstm);
     for (auto& S : e->dec_stages) {
-        e->expected.push_back({S.resample.prefix + ".convtr.weight", {S.resample.c2d, S.resample.cout / (S.resample.groups > 0 ? S.resample.groups : 1), S.resample.kf, S.resample.k}});
+        const int opg_t = S.resample.cout / (S.resample.groups > 0 ? S.resample.groups : 1);
+        if (S.resample.wnorm) {                                               // dim 0 of a ConvTranspose2d weight = its IN channels
+            e->expected.push_back({S.resample.prefix + ".convtr.weight_g", {S.resample.c2d, 1, 1, 1}});
+            e->expected.push_back({S.resample.prefix + ".convtr.weight_v", {S.resample.c2d, opg_t, S.resample.kf, S.resample.k}});
+        } else {
+            e->expected.push_back({S.resample.prefix + ".convtr.weight", {S.resample.c2d, opg_t, S.resample.kf, S.resample.k}});
+        }
         e->expected.push_back({S.resample.prefix + ".convtr.bias", {S.resample.cout}});
-        e->expected.push_back({S.resample.prefix + ".norm.weight", {S.resample.cout}});
-        e->expected.push_back({S.resample.prefix + ".norm.bias", {S.resample.cout}});
+        if (S.resample.has_norm) {
+            e->expected.push_back({S.resample.prefix + ".norm.weight", {S.resample.cout}});
+            e->expected.push_back({S.resample.prefix + ".norm.bias", {S.resample.cout}});
+        }
         for (auto& R : S.res) { add_conv2d_expect(e, R.block1); add_conv2d_expect(e, R.block3); add_conv2d_expect(e, R.shortcut); }
     }
     add_conv2d_expect(e, e->dec2_last);
@@ -685,7 +729,7 @@ int pack_reshead(fc_engine* e, fc_engine::ResBlock& R) {
 // Conv2d weight [cout][C][kf][kt] -> GEMM weight [cout][a * C + ci][kt] (frequency-major layout: rows fo*sf + a are consecutive
 // [C][T] blocks, so tap a of channel ci is GEMM channel a * C + ci)
 int pack_conv2d(fc_engine* e, ConvLayer& L) {
-    const auto& W = e->host[L.prefix + ".conv.weight"].data;
+    const std::vector<float> W = folded_weight_nd(e, L.prefix + ".conv", L.wnorm, (size_t)L.cout);
     const auto& Bv = e->host[L.prefix + ".conv.bias"].data;
     const int C = L.c2d, kf = L.kf, kt = L.k;
     const int cpg = C / L.groups, opg = L.cout / L.groups;        // grouped: weight [cout][C / groups][kf][kt], block-diagonal when dense
@@ -702,8 +746,10 @@ int pack_conv2d(fc_engine* e, ConvLayer& L) {
     static const int gconv_env = getenv("FC_GCONV") ? atoi(getenv("FC_GCONV")) : 1;
     if (gconv_env && L.groups > 1 && L.dil == 1 && fc::gconv2d_ok(cpg, opg, kf, kt, L.stride) && upload(e, W, &L.w_group)) return 1;
     if (L.cout <= 4 && L.stride == 1 && L.sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && upload(e, wg, &L.w_plain)) return 1;      // [cout][kf * C][kt]: FMA kernel, no MFMA tile
-    if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
-    if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
+    if (L.has_norm) {
+        if (upload(e, e->host[L.prefix + ".norm.weight"].data, &L.gamma)) return 1;
+        if (upload(e, e->host[L.prefix + ".norm.bias"].data, &L.beta)) return 1;
+    }
     return 0;
 }
 
@@ -712,7 +758,7 @@ int pack_conv2d(fc_engine* e, ConvLayer& L) {
 // in the zero-haloed input buffer) with weight W1d[r * C + ci][co][bt] = W[ci][co][p + (1 - r) * sf][bt], packed like every other
 // transposed layer (2-tap GEMM over the time phases).
 int pack_convtr2d(fc_engine* e, const ConvLayer& S, std::vector<ConvLayer>& phases) {
-    const auto& W = e->host[S.prefix + ".convtr.weight"].data;
+    const std::vector<float> W = folded_weight_nd(e, S.prefix + ".convtr", S.wnorm, (size_t)S.c2d);
     const auto& Bv = e->host[S.prefix + ".convtr.bias"].data;
     const int C = S.c2d, cout = S.cout, kf = S.kf, kt = S.k, sf = S.sf, r = S.stride;
     const int cpg = C / S.groups, opg = cout / S.groups;          // grouped: weight [C][cout / groups][kf][kt]
@@ -739,8 +785,10 @@ int pack_convtr2d(fc_engine* e, const ConvLayer& S, std::vector<ConvLayer>& phas
     if (gconv_env && S.groups > 1 && fc::gconvtr2d_ok(cpg, opg, r)) {          // direct kernel: torch-layout weights + plain bias
         if (upload(e, W, &L0.w_group) || upload(e, Bv, &L0.w_plain)) return 1;
     }
-    if (upload(e, e->host[S.prefix + ".norm.weight"].data, &L0.gamma)) return 1;
-    if (upload(e, e->host[S.prefix + ".norm.bias"].data, &L0.beta)) return 1;
+    if (S.has_norm) {
+        if (upload(e, e->host[S.prefix + ".norm.weight"].data, &L0.gamma)) return 1;
+        if (upload(e, e->host[S.prefix + ".norm.bias"].data, &L0.beta)) return 1;
+    }
     return 0;
 }
 
@@ -1136,9 +1184,9 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         c.in_sB = (long long)(x0.F + 2 * x0.halo) * rowsz; c.in_sF = rowsz;
         c.out_sB = (long long)(Fo + 2 * out_halo) * orow; c.out_sF = orow;
         const int nblk = fc::gconv2d_nblk(g.Tout, Fo, L.groups, kf);
-        c.partials = cx.alloc<double>((size_t)B * nblk * 2);
-        o.aff = cx.alloc<float>((size_t)B * L.cout * 2);
-        o.normed = true;
+        c.partials = L.has_norm ? cx.alloc<double>((size_t)B * nblk * 2) : nullptr;       // weight_norm nets: no statistics, no affine
+        o.aff = L.has_norm ? cx.alloc<float>((size_t)B * L.cout * 2) : nullptr;
+        o.normed = L.has_norm;
         const double fl = 2.0 * B * Fo * (double)L.cout * (C / L.groups) * kf * L.k * g.Tout;
         const double by = 4.0 * B * ((double)C * x0.F * x0.T * (dual ? 2 : 1) + (double)L.cout * Fo * g.Tout);
         cx.conv_flops += fl; cx.conv_bytes += by;
@@ -1155,7 +1203,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
             ProfSpan sp(e, cx, cls, fl, by);
             er = fc::launch_gconv2d(c, cx.st);
         }
-        if (er == hipSuccess)
+        if (er == hipSuccess && L.has_norm)
             er = fc::launch_gn_finalize(c.partials, nblk, (double)L.cout * Fo * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps, B, o.aff, cx.st);
         if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fo, out_halo, L.cout, g.Tout, 0, cx.st);
         if (er != hipSuccess) { cx.err = 1; g_err = "grouped 2-D conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); }
@@ -1200,9 +1248,9 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
     c.out = cx.dry ? nullptr : o.buf + (long long)out_halo * orow;
     c.out_sB = (long long)(Fo + 2 * out_halo) * orow; c.out_sF = orow; c.out_sM = g.Tout; c.out_sT = 1;
     const int nblk = fc::conv_nblk(c);
-    c.partials = cx.alloc<double>((size_t)B * Fo * nblk * 2);
-    o.aff = cx.alloc<float>((size_t)B * L.cout * 2);
-    o.normed = true;
+    c.partials = L.has_norm ? cx.alloc<double>((size_t)B * Fo * nblk * 2) : nullptr;
+    o.aff = L.has_norm ? cx.alloc<float>((size_t)B * L.cout * 2) : nullptr;
+    o.normed = L.has_norm;
     const double fl = 2.0 * B * Fo * (double)L.M * L.cin * L.gk * g.Tout;
     const double by = 4.0 * B * ((double)C * x0.F * x0.T * (dual_eff ? 2 : 1) + (double)L.cout * Fo * g.Tout);
     cx.conv_flops += fl; cx.conv_bytes += by;
@@ -1224,7 +1272,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         ProfSpan sp(e, cx, cls, fl, by);
         er = fc::launch_conv(c, cx.st);
     }
-    if (er == hipSuccess)
+    if (er == hipSuccess && L.has_norm)
         er = fc::launch_gn_finalize(c.partials, nblk * Fo, (double)L.cout * Fo * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps, B, o.aff, cx.st);
     if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fo, out_halo, L.cout, g.Tout, 0, cx.st);
     if (er != hipSuccess) { cx.err = 1; g_err = "2-D conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); }
@@ -1264,9 +1312,11 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
     const int nblk = fc::conv_nblk(c0);
     const long long part_row = (long long)(Fin + 1) * nblk;
     const int gnblk = fc::gconvtr2d_nblk(T, st, Fin, sf);     // partial slots of the grouped direct kernel (same buffer)
-    double* partials = cx.alloc<double>((size_t)B * std::max<long long>(sf * part_row, gnblk) * 2);
-    o.aff = cx.alloc<float>((size_t)B * cout * 2);
-    o.normed = true;
+    const bool has_norm = S.has_norm;
+    const int t_trimL = S.causal ? 0 : st - st / 2;           // unpad2d: causal (trim_right_ratio 1) trims the time axis on the right only (conv.py:427-431)
+    double* partials = has_norm ? cx.alloc<double>((size_t)B * std::max<long long>(sf * part_row, gnblk) * 2) : nullptr;
+    o.aff = has_norm ? cx.alloc<float>((size_t)B * cout * 2) : nullptr;
+    o.normed = has_norm;
     const double fl = 2.0 * B * (Fin + 1) * (double)phases[0].M * 2 * C * 2 * (T + 1) * sf;
     const double by = 4.0 * B * ((double)C * Fin * T * (x1 ? 2 : 1) + (double)cout * Fout * g.Tout);
     cx.conv_flops += fl; cx.conv_bytes += by;
@@ -1286,9 +1336,9 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
             }
             ProfSpan sp(e, cx, cls, 2.0 * B * (double)cout * 8 * (Fin + 1) * sf * (T + 1) * st, by);
             er = fc::launch_gconvtr2d(z.buf, phases[0].w_group, phases[0].w_plain, o.buf + (long long)out_halo * orow, gpart, B, C, cout, Fin, T, sf, st,
-                                      f_l, Fout, st - st / 2, g.Tout, (long long)(Fout + 2 * out_halo) * orow, cx.st);
+                                      f_l, Fout, t_trimL, g.Tout, (long long)(Fout + 2 * out_halo) * orow, cx.st);
         }
-        if (er == hipSuccess)
+        if (er == hipSuccess && has_norm)
             er = fc::launch_gn_finalize(gpart, gnblk, (double)cout * (Fin + 1) * sf * g.count_T, phases[0].gamma, phases[0].beta, cout, e->arch.gn_eps,
                                         B, o.aff, cx.st);
         if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fout, out_halo, cout, g.Tout, 0, cx.st);
@@ -1303,7 +1353,7 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
         c.B = B * (Fin + 1); c.Cin = L.cin; c.Tin = T; c.M = L.M;
         c.k = L.gk; c.stride = L.gstride; c.dil = 1; c.padL = g.padL; c.padR = g.padR; c.pad_zero = 1;
         c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
-        c.Tout = T + 1; c.up_r = st; c.trimL = st - st / 2; c.Tfinal = g.Tout;
+        c.Tout = T + 1; c.up_r = st; c.trimL = t_trimL; c.Tfinal = g.Tout;
         c.Fo = Fin + 1; c.affC = C;
         c.in_sB0 = (long long)(Fin + 2) * C * T; c.in_sB1 = (long long)C * T;
         c.out = o.buf + ((long long)out_halo + p - f_l) * orow;      // rows outside [0, Fout) are never stored (store range below)
@@ -1313,7 +1363,7 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
         int hi = (Fout - 1 + f_l - p) >= 0 ? (Fout - 1 + f_l - p) / sf + 1 : 0;   // q * sf + p - f_l <= Fout - 1
         if (hi > Fin + 1) hi = Fin + 1;
         c.store_lo = lo; c.store_hi = hi;
-        c.partials = partials + (long long)p * part_row * 2;
+        c.partials = has_norm ? partials + (long long)p * part_row * 2 : nullptr;
         c.part_sB0 = (long long)sf * part_row;
         int cls = 0;
         if (e->profiling) {
@@ -1330,7 +1380,7 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
         er = fc::launch_conv(c, cx.st);
     }
     const ConvLayer& L0 = phases[0];
-    if (er == hipSuccess)
+    if (er == hipSuccess && has_norm)
         er = fc::launch_gn_finalize(partials, (int)(sf * part_row), (double)cout * (Fin + 1) * sf * g.count_T, L0.gamma, L0.beta, cout, e->arch.gn_eps,
                                     B, o.aff, cx.st);
     if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fout, out_halo, cout, g.Tout, 0, cx.st);
@@ -1577,7 +1627,7 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
         if (arch->ratios[i] < 1) return fail("ratios must be >= 1");
     if (arch->model_type != 0 && arch->model_type != 1) return fail("fc_arch.model_type must be 0 (encodec) or 1 (freq_codec, mag_phase)");
     if (arch->model_type == 1) {
-        if (arch->norm_type != 0 || arch->causal) return fail("freq_codec: only the GroupNorm, non-causal recipe is built");
+        if (arch->norm_type != 0 && arch->norm_type != 1) return fail("freq_codec: norm must be time_group_norm or weight_norm");
         if (arch->input_channels != 3) return fail("freq_codec: input_channels must be 3 (log-magnitude, phase re, phase im)");
         if (arch->n_fft < 64 || (arch->n_fft & (arch->n_fft - 1)) || arch->stft_hop < 1 || arch->stft_hop > arch->n_fft)
             return fail("freq_codec: n_fft must be a power of two >= 64 and 1 <= stft_hop <= n_fft");

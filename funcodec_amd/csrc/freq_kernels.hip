@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
     }
     if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && p.partials) {                        // weight_norm nets: no GroupNorm statistics
         const size_t slot = (((size_t)b * gridDim.y + fu) * gridDim.x + tile) * 2;
         p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
         p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];

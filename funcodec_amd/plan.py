@@ -166,7 +166,7 @@ def expected_tensors(a: ArchSpec) -> Dict[str, Tuple[int, ...]]:
             # torch layouts: Conv [out, in / groups, ...], ConvTranspose [in, out / groups, ...]
             wshape = (op.cout, op.cin // op.groups) + kk if op.kind == "conv" else (op.cin, op.cout // op.groups) + kk
             if wn:
-                out[f"{op.key}.{inner}.weight_g"] = (wshape[0], 1, 1)
+                out[f"{op.key}.{inner}.weight_g"] = (wshape[0],) + (1,) * (len(wshape) - 1)
                 out[f"{op.key}.{inner}.weight_v"] = wshape
             else:
                 out[f"{op.key}.{inner}.weight"] = wshape

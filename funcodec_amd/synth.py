@@ -181,6 +181,15 @@ def make_freq_state_dict(cfg: Dict[str, Any], seed: int = 0) -> Dict[str, np.nda
         cout = shape[0] if kind == "conv" else shape[0] // 2        # every ConvTranspose2d of the net halves the channels
         fan_in = int(np.prod(shape[1:])) if kind == "conv" else int(shape[1] * np.prod(shape[2:]))
         b = 1.0 / np.sqrt(fan_in)
+        if cfg["encoder_conf"].get("norm", "weight_norm") == "weight_norm":
+            # torch.nn.utils.weight_norm (dim 0; conv.py:24-25): g has one entry per slice of dim 0 -- out channels of Conv, IN channels of
+            # ConvTranspose; a trained checkpoint has g != ||v||, so g is randomised around the norm
+            v = uni(shape, b)
+            nrm = np.sqrt((v.astype(np.float64) ** 2).reshape(shape[0], -1).sum(axis=1)).reshape((shape[0],) + (1,) * (len(shape) - 1))
+            sd[f"{key}.{inner}.weight_v"] = v
+            sd[f"{key}.{inner}.weight_g"] = (nrm * (1.0 + 0.2 * rng.standard_normal(nrm.shape))).astype(np.float32)
+            sd[f"{key}.{inner}.bias"] = uni((cout,), b)
+            continue
         sd[f"{key}.{inner}.weight"] = uni(shape, b)
         sd[f"{key}.{inner}.bias"] = uni((cout,), b)
         sd[f"{key}.norm.weight"] = (1.0 + 0.1 * rng.standard_normal(cout)).astype(np.float32)

@@ -49,8 +49,9 @@ def pad2d_reflect(x: torch.Tensor, pad_time: Tuple[int, int], pad_freq: Tuple[in
     return padded[..., :padded.shape[-2] - extra_f, :padded.shape[-1] - extra_t]
 
 
-def sconv2d(x, w, b, gamma, beta, stride: Tuple[int, int], eps: float, dilation: Tuple[int, int] = (1, 1)):
-    """SConv2d.forward conv.py:342-381 (non-causal) -> NormConv2d -> GroupNorm(1, C) over (C, F, T)."""
+def sconv2d(x, w, b, gamma, beta, stride: Tuple[int, int], eps: float, dilation: Tuple[int, int] = (1, 1), causal: bool = False):
+    """SConv2d.forward conv.py:342-381 -> NormConv2d -> GroupNorm(1, C) over (C, F, T) (or none: weight_norm).  `causal` concerns the
+    time axis only (:361-367): all of the fixed padding before, the extra padding after; the frequency axis is padded as always."""
     kf, kt = w.shape[-2:]
     tot_f = (kf - 1) * dilation[0] - (stride[0] - 1)
     tot_t = (kt - 1) * dilation[1] - (stride[1] - 1)
@@ -59,20 +60,25 @@ def sconv2d(x, w, b, gamma, beta, stride: Tuple[int, int], eps: float, dilation:
     f_before = tot_f - f_after
     t_after = tot_t // 2
     t_before = tot_t - t_after + extra_t          # NB: the reference adds the extra padding on the LEFT of the time axis here (:377)
+    if causal:
+        t_before, t_after = tot_t, extra_t
     x = pad2d_reflect(x, (t_before, t_after), (f_before, f_after))
     y = F.conv2d(x, w, b, stride=stride, dilation=dilation, groups=x.shape[1] // w.shape[1])     # conv_group_ratio > 0: grouped
     return y if gamma is None else F.group_norm(y, 1, gamma, beta, eps)
 
 
-def sconvtr2d(x, w, b, gamma, beta, stride: Tuple[int, int], eps: float, out_padding=((0, 0), (0, 0))):
-    """SConvTranspose2d.forward conv.py:408-447 (non-causal): ConvTranspose2d -> GroupNorm on the untrimmed output -> unpad2d,
-    the trims reduced by `out_padding` ([(freq_left, freq_right), (time_left, time_right)])."""
+def sconvtr2d(x, w, b, gamma, beta, stride: Tuple[int, int], eps: float, out_padding=((0, 0), (0, 0)), causal: bool = False):
+    """SConvTranspose2d.forward conv.py:408-447: ConvTranspose2d -> GroupNorm on the untrimmed output (or none) -> unpad2d,
+    the trims reduced by `out_padding` ([(freq_left, freq_right), (time_left, time_right)]).  `causal` (trim_right_ratio = 1, :427-431):
+    the whole time trim on the right."""
     kf, kt = w.shape[-2:]
     y = F.conv_transpose2d(x, w, b, stride=stride, groups=b.shape[0] // w.shape[1])             # tr_conv_group_ratio > 0
     if gamma is not None:
         y = F.group_norm(y, 1, gamma, beta, eps)
     pf, pt = kf - stride[0], kt - stride[1]
     f_r, t_r = pf // 2, pt // 2
+    if causal:
+        t_r = pt
     f_l, t_l = pf - f_r, pt - t_r
     (fo_l, fo_r), (to_l, to_r) = out_padding
     f_l, f_r, t_l, t_r = max(f_l - fo_l, 0), max(f_r - fo_r, 0), max(t_l - to_l, 0), max(t_r - to_r, 0)
@@ -97,7 +103,7 @@ class FreqOracle(Oracle):
 
     def _conv2(self, x, prefix, stride=(1, 1), dilation=(1, 1)):
         w, b, g, be = self._p(prefix)
-        return sconv2d(x, w, b, g, be, stride, self.eps, dilation)
+        return sconv2d(x, w, b, g, be, stride, self.eps, dilation, self.causal)
 
     def _resblock2(self, x, prefix, dil_t=1):
         """SEANetResnetBlock2d.forward seanet_encoder.py:239-240: shortcut(x) + block(x); block = ELU, 3x3 (dilation (1, d)), ELU, 1x1."""
@@ -144,7 +150,7 @@ class FreqOracle(Oracle):
         for i, (fr, tr) in enumerate(self.ratios2d):
             idx += 1                                                   # ELU
             w, b, g, be = self._p(f"decoder.model.{idx}.convtr")
-            x = sconvtr2d(self._elu(x), w, b, g, be, (fr, tr), self.eps, self.last_out_padding if i == n - 1 else ((0, 0), (0, 0)))
+            x = sconvtr2d(self._elu(x), w, b, g, be, (fr, tr), self.eps, self.last_out_padding if i == n - 1 else ((0, 0), (0, 0)), self.causal)
             idx += 1
             for j in range(self.n_res):
                 x = self._resblock2(x, f"decoder.model.{idx}", self.dil_base ** j)

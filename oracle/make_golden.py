@@ -108,6 +108,9 @@ FREQ_CASES = [
     ("tinyfreqseg_b2_t6000", "tinyfreqseg", 8, "tones", 85, 2, 6000),
     # CostumeQuantizer's input / output projection (codec_dim = 32 != dimension = 16) and tanh range behind the 2-D encoder
     ("tinyfreqcd_b2_t2000", "tinyfreqcd", 9, "tones", 86, 2, 2000),
+    # 2-D nets with weight_norm instead of GroupNorm, non-causal and causal (conv.py:317-447: causal time padding / right-only time trim)
+    ("tinyfreqwn_b2_t2200", "tinyfreqwn", 10, "tones", 87, 2, 2200),
+    ("tinyfreqwnc_b2_t2600", "tinyfreqwnc", 11, "tones", 88, 2, 2600),
     # the reference's own demo recordings (real speech / music) through the FreqCodec recipe
     ("freqmp_wav_libritts_5105", "freqmp", 0, "wav:libritts_5105", 0, 1, 18186),
     ("freqmp_wav_libritts_8230", "freqmp", 0, "wav:libritts_8230", 0, 1, 29440),

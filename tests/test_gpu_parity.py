@@ -728,6 +728,10 @@ def test_freq_codec_segmented_mode_against_reference_golden(name):
     ("tinyfreq640", 12, 2, 5000, "noise", None, True),     # time ratios 2,1,2,1
     ("freqmp", 2, 2, 8000, "tones", 4000, True),           # the recipe shape
     ("freqmpgr8", 6, 1, 6000, "noise", None, True),        # grouped Conv2d / ConvTranspose2d (conv_group_ratio 8)
+    ("tinyfreqwn", 14, 3, 1500, "noise", None, True),      # weight_norm 2-D nets (no GroupNorm)
+    ("tinyfreqwnc", 15, 2, 3333, "tones", 2000, False),    # weight_norm + causal (time padding on the left, time trim on the right)
+    ("tinyfreq640wnc", 16, 2, 4100, "noise", None, True),  # the same with time ratios 2,1,2,1
+    ("tinyfreqgr1wnc", 17, 1, 2500, "tones", None, True),  # and with grouped convs (direct kernels without statistics)
 ])
 def test_freq_codec_against_oracle_fresh_inputs(cfg_name, seed, B, T, kind, bw, use_scale):
     from helpers import freq_engine_for, freq_oracle_for

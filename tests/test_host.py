@@ -61,6 +61,24 @@ def test_freq_codec_checkpoint_contract_matches_reference_keys():
     assert {k for k in ref if k not in want} == {"quantizer.rq.model.inited", "quantizer.rq.model.cluster_size", "quantizer.rq.model.embed_avg"}
 
 
+@pytest.mark.parametrize("name", ["tinyfreqwn", "tinyfreqwnc"])
+def test_freq_codec_weight_norm_contract(name):
+    """2-D nets with weight_norm (no GroupNorm modules), non-causal and causal: weight_g [d0, 1, 1, 1] / weight_v keys, no norm.* keys;
+    the engine, the host plan and the seeded checkpoint (which the real reference loaded for the goldens) agree."""
+    from funcodec_amd.synth import make_freq_state_dict
+    cfg = recipe_config(name)
+    arch = arch_from_config(cfg)
+    assert arch.norm == "weight_norm" and arch.causal == name.endswith("c")
+    want = expected_tensors(arch)
+    assert CodecEngine(arch).expected_tensors() == want
+    assert want["encoder.model.0.conv.conv.weight_g"] == (4, 1, 1, 1) and not any(".norm." in k for k in want)
+    assert want["decoder.model.4.convtr.convtr.weight_g"][1:] == (1, 1, 1)
+    sd = make_freq_state_dict(cfg, 0)
+    for k, shape in want.items():
+        assert sd[k].shape == shape, (k, sd[k].shape, shape)
+    assert set(sd) - set(want) == {"quantizer.rq.model.inited", "quantizer.rq.model.cluster_size", "quantizer.rq.model.embed_avg"}
+
+
 @pytest.mark.parametrize("name", ["tinyfreqgr1", "freqmpgr8", "freqmp640gr1"])
 def test_freq_codec_grouped_conv_contract(name):
     """conv_group_ratio / tr_conv_group_ratio > 0 (the "gr" of the released FreqCodec models): the engine, the host plan and the
