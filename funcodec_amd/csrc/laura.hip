@@ -578,7 +578,7 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     };
     int s = 1;
     if (s < max_length && !cx.err) { run_step(cx.st); ++s; }          // first step eagerly (also sets the kernels' LDS attributes)
-    // the remaining steps replay ONE captured HIP graph of the step (~64 small launches): the loop is launch-bound otherwise
+    // the remaining steps replay ONE captured HIP graph of the step (62 small launches): the loop is launch-bound otherwise
     static const bool graph_env = !(getenv("FC_LAURA_GRAPH") && atoi(getenv("FC_LAURA_GRAPH")) == 0);
     hipGraphExec_t gexec = nullptr;
     if (graph_env && cx.st != nullptr && max_length - s >= 4 && !cx.err) {
