@@ -1,0 +1,42 @@
+"""`python bench.py --gpus N` must launch its own N ranks (the reference's multi-GPU story is N self-launched
+processes, egs/LibriTTS/codec/encoding_decoding.sh:59-101).  Runs the launcher's dry-run mode on CPU: world 2 over gloo, the same
+shard_range / gather_codes the GPU ranks use, no engine."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=300)
+
+
+def _json_lines(stdout):
+    return [json.loads(ln) for ln in stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_self_launches_its_ranks_and_prints_one_line():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "0", "--dry-run-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["gather_ok"] is True
+    assert out["config"]["shard_sizes"] == [4, 3] and out["config"]["global_utterances"] == 7
+
+
+def test_bench_single_rank_dry_run_needs_no_launcher():
+    r = _run(["--gpus", "1", "--steps", "1", "--dry-run-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_lines(r.stdout)[0]
+    assert out["n_gpus"] == 1 and out["config"]["ranks_seen"] == 1 and out["gather_ok"] is True
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _run(["--gpus", "4", "--dry-run-launcher"], env_extra={"WORLD_SIZE": "1", "RANK": "0"}, drop=())
+    # under an existing WORLD_SIZE the script must not re-launch, and a rank count that contradicts --gpus is an error, not a silent N = 1 run
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not _json_lines(r.stdout)
