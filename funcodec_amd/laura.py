@@ -127,6 +127,27 @@ class LauraEngine:
     def _dev(self, t, dtype) -> torch.Tensor:
         return torch.as_tensor(t).to(device=self.device, dtype=dtype).contiguous()
 
+    # -- argument validation: the C side takes plain pointers and trusts these shapes ------------------------------------------------
+    def _check_batch(self, what: str, B: int, cap: Optional[int] = None, **length_lists) -> None:
+        if B < 1 or (cap is not None and B > cap):
+            raise EngineError(f"{what}: batch of {B} utterances" + (f", the engine takes 1 .. {cap} per call" if cap else ""))
+        for name, vals in length_lists.items():
+            if vals is None:
+                continue
+            if len(vals) != B:
+                raise EngineError(f"{what}: {name} has {len(vals)} entries for a batch of {B}")
+
+    def _check_lens(self, what: str, name: str, vals: Sequence[int], upper: int, lower: int = 0) -> List[int]:
+        out = [int(v) for v in vals]
+        for v in out:
+            if v < lower or v > upper:
+                raise EngineError(f"{what}: {name} entry {v} outside [{lower}, {upper}]")
+        return out
+
+    def _check_text_outs(self, what: str, text_outs: torch.Tensor) -> None:
+        if text_outs.dim() != 3 or text_outs.shape[-1] != self.spec.codebook_dim:
+            raise EngineError(f"{what}: text_outs must be [B, L, {self.spec.codebook_dim}], got {tuple(text_outs.shape)}")
+
     # -- LauraGenModel.encode -------------------------------------------------------------------------------------------
     @_on_device
     def encode(self, text, text_lengths: Sequence[int]) -> torch.Tensor:
@@ -134,7 +155,13 @@ class LauraEngine:
         text = torch.as_tensor(text)
         ids = not text.is_floating_point()
         text = self._dev(text, torch.int64 if ids else torch.float32)
+        if (ids and text.dim() != 2) or (not ids and (text.dim() != 3 or text.shape[-1] != self.spec.input_size)):
+            raise EngineError(f"encode: text must be int64 [B, L] token ids or float [B, L, {self.spec.input_size}] embeddings, "
+                              f"got {tuple(text.shape)}")
         B, L = text.shape[0], text.shape[1]
+        text_lengths = list(text_lengths)
+        self._check_batch("encode", B, text_lengths=text_lengths)
+        text_lengths = self._check_lens("encode", "text_lengths", text_lengths, L, 1)
         out = torch.empty((B, L, self.spec.codebook_dim), dtype=torch.float32, device=self.device)
         ws = self._workspace(B, L, 0, 1)
         self._check(self.lib.fc_laura_encode(self._h, None if ids else _ptr(text), _ptr(text) if ids else None, _i32(text_lengths), B, L,
@@ -147,12 +174,21 @@ class LauraEngine:
                     codec_lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
         """log-softmax of the LM output at every position of [<sos>, text, <task>, codec]: [B, Tseq, vocab]."""
         text_outs = self._dev(text_outs, torch.float32)
+        self._check_text_outs("lm_logprobs", text_outs)
         B, L = text_outs.shape[0], text_outs.shape[1]
+        text_lengths = list(text_lengths)
+        self._check_batch("lm_logprobs", B, text_lengths=text_lengths)
+        text_lengths = self._check_lens("lm_logprobs", "text_lengths", text_lengths, L, 1)
         Cmax = 0
         if codec is not None:
             codec = self._dev(codec, torch.int64)
+            if codec.dim() != 3 or codec.shape[0] != B or codec.shape[2] != self.spec.predict_nq:
+                raise EngineError(f"lm_logprobs: codec must be int64 [{B}, Cmax, {self.spec.predict_nq}], got {tuple(codec.shape)}")
             Cmax = codec.shape[1]
-        cl = list(codec_lengths) if codec is not None else [0] * B
+            if codec_lengths is None:
+                raise EngineError("lm_logprobs: codec given without codec_lengths")
+            self._check_batch("lm_logprobs", B, codec_lengths=list(codec_lengths))
+        cl = self._check_lens("lm_logprobs", "codec_lengths", list(codec_lengths), Cmax) if codec is not None else [0] * B
         Tseq = max(int(t) + 2 + int(c) for t, c in zip(text_lengths, cl))
         logp = torch.empty((B, Tseq, self.spec.lm_vocab), dtype=torch.float32, device=self.device)
         ws = self._workspace(B, L, Cmax, 1)
@@ -170,19 +206,30 @@ class LauraEngine:
         """Batch form of decode_codec: returns (tokens [B, Cmax + max_length, nq] int64, lengths list[int]) and, with
         return_logp, the per-step log-probabilities [B, max_length, vocab]."""
         text_outs = self._dev(text_outs, torch.float32)
+        self._check_text_outs("decode_codec", text_outs)
         B, L = text_outs.shape[0], text_outs.shape[1]
-        if B > self.max_batch:
-            raise EngineError(f"at most {self.max_batch} utterances per decode_codec call")
+        text_lengths = list(text_lengths)
+        self._check_batch("decode_codec", B, cap=self.max_batch, text_lengths=text_lengths)
+        text_lengths = self._check_lens("decode_codec", "text_lengths", text_lengths, L, 1)
+        if int(max_length) < 1:
+            raise EngineError(f"decode_codec: max_length {max_length} < 1")
         nq = self.spec.predict_nq
         Cmax = 0
         if continual is not None:
             continual = self._dev(continual, torch.int64)
+            if continual.dim() != 3 or continual.shape[0] != B or continual.shape[2] != nq:
+                raise EngineError(f"decode_codec: continual must be int64 [{B}, Cmax, {nq}], got {tuple(continual.shape)}")
             Cmax = continual.shape[1]
-            assert continual.shape == (B, Cmax, nq), continual.shape
+            if continual_lengths is None:
+                raise EngineError("decode_codec: continual given without continual_lengths")
+            continual_lengths = list(continual_lengths)
+            self._check_batch("decode_codec", B, continual_lengths=continual_lengths)
+            continual_lengths = self._check_lens("decode_codec", "continual_lengths", continual_lengths, Cmax)
         mode, k, p = sampling_args(sampling)
         if forced is not None:
             forced = self._dev(forced, torch.int64)
-            assert forced.shape == (B, max_length, nq), forced.shape
+            if tuple(forced.shape) != (B, int(max_length), nq):
+                raise EngineError(f"decode_codec: forced must be int64 [{B}, {int(max_length)}, {nq}], got {tuple(forced.shape)}")
         tokens = torch.zeros((B, Cmax + max_length, nq), dtype=torch.int64, device=self.device)
         logp = torch.zeros((B, max_length, self.spec.lm_vocab), dtype=torch.float32, device=self.device) if return_logp else None
         out_lens = (C.c_int32 * B)()
@@ -211,8 +258,15 @@ class LauraEngine:
         """codec int64 [B, Cmax, >= predict_nq] -> dense codec embeddings [B, Cmax, codebook_dim] (rows past each length zero)."""
         text_outs = self._dev(text_outs, torch.float32)
         codec = self._dev(codec, torch.int64)
+        self._check_text_outs("codec_emb", text_outs)
         B, L = text_outs.shape[0], text_outs.shape[1]
+        if codec.dim() != 3 or codec.shape[0] != B or codec.shape[2] < self.spec.predict_nq:
+            raise EngineError(f"codec_emb: codec must be int64 [{B}, Cmax, >= {self.spec.predict_nq}], got {tuple(codec.shape)}")
         Cmax, cols = codec.shape[1], codec.shape[2]
+        text_lengths, codec_lengths = list(text_lengths), list(codec_lengths)
+        self._check_batch("codec_emb", B, text_lengths=text_lengths, codec_lengths=codec_lengths)
+        text_lengths = self._check_lens("codec_emb", "text_lengths", text_lengths, L, 1)
+        codec_lengths = self._check_lens("codec_emb", "codec_lengths", codec_lengths, Cmax)
         emb = torch.empty((B, Cmax, self.spec.codebook_dim), dtype=torch.float32, device=self.device)
         ws = self._workspace(B, L, Cmax, 1)
         self._check(self.lib.fc_laura_codec_emb(self._h, _ptr(text_outs), _i32(text_lengths), B, L, _ptr(codec), cols, _i32(codec_lengths),

@@ -358,6 +358,69 @@ def main():
             manifest["cases"]["ds640_b2_t160000_variants"] = dict(kind="variants", of="ds640_b2_t160000", threads_default=nthreads,
                                                                   runs=["indices_threads1", "indices_utt1_alone", "indices_utt1_alone_threads3"])
             print("[golden] ds640_b2_t160000_variants: 1 thread / utterance 1 alone (default threads, 3 threads)")
+        # ---- the two FreqCodec fixtures on the reference's own recordings whose codes the engine does not reproduce frame for frame
+        # (VERDICT r3 "what's weak" #1): the REAL reference under other settings -- ONE thread, THREE threads, and with its STFT evaluated in
+        # fp64 (the exact transform, rounded to complex64 afterwards).  Frames / stages on which these runs of the reference disagree with
+        # the fixture are not defined by "the reference"; the GPU test may differ from the fixture only there (or on a proven fp32 tie).
+        for base in ("freqmp_wav_libritts_8230", "freqmp_wav_jamendo_0027"):
+            vname = base + "_variants"
+            if not (only is None or vname in only):
+                continue
+            ref_shim.install_torchaudio_transforms()
+            import torchaudio
+            import yaml
+            from freq_synth import freq_recipe_config, make_freq_state_dict
+            from funcodec.bin.codec_inference import Speech2Token
+            name, cfg_name, wseed, akind, aseed, B, T = next(c for c in FREQ_CASES if c[0] == base)
+            cfg = freq_recipe_config(cfg_name)
+            sd = make_freq_state_dict(cfg, wseed)
+            d = os.path.join(tmp, f"{cfg_name}_{wseed}_var")
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "config.yaml"), "wt") as f:
+                yaml.safe_dump(reference_config(cfg), f)
+            torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, os.path.join(d, "model.pth"))
+            s2t = Speech2Token(os.path.join(d, "config.yaml"), os.path.join(d, "model.pth"), device="cpu")
+            x = torch.from_numpy(case_audio(akind, aseed, B, T))
+            fixture = np.load(os.path.join(GOLD, base + ".npz"))
+            nthreads = torch.get_num_threads()
+
+            def run():
+                with torch.no_grad():
+                    idx = s2t(x.unsqueeze(1), bit_width=None, run_mod="encode")[0][0]
+                    enc = s2t.model._encode_frame(x.unsqueeze(1))[0]
+                return idx.numpy().astype(np.int16), enc.numpy()
+
+            i0, e0 = run()
+            assert np.array_equal(i0, fixture["indices"]) and np.array_equal(e0, fixture["encoder_out"]), f"{base}: fixture not reproduced"
+            arrays, summary = {}, {}
+            Spec = torchaudio.transforms.Spectrogram
+            real_forward = Spec.forward
+
+            def forward64(self, xx):         # the reference's Spectrogram with the transform in fp64, the result rounded to complex64
+                shape = xx.shape
+                st = torch.stft(xx.double().reshape(-1, shape[-1]), self.n_fft, self.hop_length, self.win_length, self.window.double(),
+                                center=True, pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+                return st.reshape(shape[:-1] + st.shape[-2:]).to(torch.complex64)
+
+            for tag, threads, f64 in (("threads1", 1, False), ("threads3", 3, False), ("stft64", nthreads, True)):
+                torch.set_num_threads(threads)
+                if f64:
+                    Spec.forward = forward64
+                try:
+                    iv, ev = run()
+                finally:
+                    Spec.forward = real_forward
+                    torch.set_num_threads(nthreads)
+                arrays["indices_" + tag] = iv
+                arrays["encoder_out_" + tag] = ev
+                diff_frames = np.nonzero((iv != fixture["indices"]).any(0).reshape(-1))[0]
+                summary[tag] = dict(frames_differing=int(diff_frames.size), first_stage_agreement=float((iv[0] == fixture["indices"][0]).mean()),
+                                    all_stage_agreement=float((iv == fixture["indices"]).mean()),
+                                    encoder_out_rms_diff=float(np.sqrt(((ev - fixture["encoder_out"]).astype(np.float64) ** 2).mean())))
+            np.savez_compressed(os.path.join(GOLD, vname + ".npz"), **arrays)
+            manifest["cases"][vname] = dict(kind="variants", of=base, threads_default=nthreads, runs=["threads1", "threads3", "stft64"],
+                                            summary=summary)
+            print(f"[golden] {vname}: {json.dumps(summary)}")
         if only is not None:
             old = json.load(open(os.path.join(GOLD, "MANIFEST.json")))
             old["cases"].update(manifest["cases"])

@@ -8,6 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import record_report, record_waivers
 from helpers import (audio, engine_for, golden, index_report, manifest, oracle_for, rms, state_for)
 
 pytestmark = pytest.mark.gpu
@@ -626,6 +627,8 @@ def _assert_flips_are_near_ties(embed, ref_enc, ref_idx, got_idx, got_enc=None, 
         resid = resid - e[r2[i]]
     if max_frames is not None:
         assert len(bad_frames) <= max_frames, (len(bad_frames), proofs)
+    # every accepted tie goes on record (conftest.py: summary line + gpurun_out/tie_waivers.json)
+    record_waivers(os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::")[-1], proofs)
     return proofs
 
 
@@ -657,39 +660,81 @@ def test_freq_codec_against_reference_golden(name):
     noise = float(c.get("stft_self_noise", 0.0))
     assert rms(r["enc_out"], g["encoder_out"]) < max(1e-4, 2.0 * noise)
     ill = noise > 1e-4
-    if ill:
-        # the codes of such a recording are functions of the FFT's rounding (32 residual stages amplify 6e-4 into other codes): what
-        # remains checkable is the encoder output bound above and the decode path from the REFERENCE's codes below
-        first = float((r["codes"][0].cpu() == torch.from_numpy(g["indices"][0].astype(np.int64))).float().mean())
-        print(f"{name}: ill-conditioned STFT fixture (self-noise {noise:.1e}); first-stage codes identical on {100 * first:.1f} % of the frames")
-        assert first > 0.8
-        rep = dict(mismatched_indices=0)
-        r = dict(r, codes=torch.from_numpy(g["indices"].astype(np.int64)).to(r["codes"].device), quantized=torch.from_numpy(g["quantized"]))
+    ref = g["indices"].astype(np.int64)                                  # [nq, B, Tf]
+    ours = r["codes"].cpu().numpy()
+    # COMMITTED FACTS about the fixture (oracle/make_golden.py, `<name>_variants.npz`): the REAL reference with one thread, three threads and
+    # with its STFT evaluated exactly (fp64).  Frames on which those runs disagree with the fixture are not defined by "the reference".
+    variants = {}
+    if name + "_variants" in MAN["cases"]:
+        v = golden(name + "_variants")
+        variants = {k[len("indices_"):]: v[k].astype(np.int64) for k in v if k.startswith("indices_")}
+    ref_disagrees = np.zeros(ref.shape[1:], dtype=bool)                   # [B, Tf]
+    for iv in variants.values():
+        ref_disagrees |= (iv != ref).any(0)
+    ours_differs = (ours != ref).any(0)
     if "scale" in g:
         assert float(((r["scale"].cpu() - torch.from_numpy(g["scale"])).abs() / torch.from_numpy(g["scale"])).max()) < 1e-5
     else:
         assert r.get("scale") is None and not m.arch.audio_normalize
-    rep = rep if ill else index_report(r["codes"], g["indices"].astype(np.int64))
-    if rep["mismatched_indices"]:
-        _assert_flips_are_near_ties(freq_state_for(c["config"], c["weight_seed"])[2]["quantizer.rq.model.embed"], g["encoder_out"],
-                                    g["indices"].astype(np.int64), r["codes"], got_enc=r["enc_out"], max_frames=1)
+    embed = freq_state_for(c["config"], c["weight_seed"])[2]["quantizer.rq.model.embed"]
+    if ill:
+        # band-limited music: 10 % of the STFT bins sit at the fp32 FFT's rounding floor, their phase features are rounding noise and the
+        # encoder output of ANY second transform moves by `stft_self_noise`.  How far the codes move under such a perturbation is a fact of
+        # the fixture: the reference itself with the exact STFT (variant "stft64").  The engine is held to that: per stage, its codes are
+        # compared with the SET of reference runs, the numbers go on record, and it may not scatter more than a few times what the
+        # reference's own variant does.
+        runs = dict(fixture=ref, **variants)
+        in_set = np.zeros_like(ours, dtype=bool)
+        for iv in runs.values():
+            in_set |= ours == iv
+        per_stage_set = in_set.reshape(ours.shape[0], -1).mean(1)
+        frames_equal_some_run = max(int((ours == iv).all(0).sum()) for iv in runs.values())
+        frames_total = int(ours_differs.size)
+        ref_self = int(ref_disagrees.sum())
+        facts = dict(frames=frames_total, reference_self_disagreement_frames=ref_self,
+                     engine_frames_differing_from_fixture=int(ours_differs.sum()),
+                     engine_frames_identical_to_best_single_run=frames_equal_some_run,
+                     first_stage_agreement_with_fixture=float((ours[0] == ref[0]).mean()),
+                     first_stage_agreement_with_set=float(per_stage_set[0]),
+                     per_stage_agreement_with_set=[round(float(x), 4) for x in per_stage_set],
+                     all_stage_agreement_with_fixture=float((ours == ref).mean()),
+                     reference_variants_all_stage_agreement={k: float((iv == ref).mean()) for k, iv in variants.items()},
+                     encoder_out_rms_vs_fixture=rms(r["enc_out"], g["encoder_out"]), stft_self_noise=noise)
+        record_report(name, **facts)
+        print(f"{name}: ill-conditioned STFT fixture: {facts}")
+        assert variants, "the ill-conditioned fixture needs its committed reference variants"
+        assert facts["first_stage_agreement_with_set"] >= 0.99, facts
+        assert frames_total - frames_equal_some_run <= max(8, 4 * ref_self), facts
+        # what follows (decode path) runs from the REFERENCE's codes
+        r = dict(r, codes=torch.from_numpy(ref).to(r["codes"].device), quantized=torch.from_numpy(g["quantized"]))
     else:
-        assert rms(r["quantized"], g["quantized"]) <= qtol
+        unexplained = ours_differs & ~ref_disagrees
+        if unexplained.any():
+            # not a frame the reference disagrees with itself on: it must be a PROVEN fp32 tie of the reference's own distances
+            keep = torch.from_numpy(np.where(unexplained[None], ours, ref))        # ours on the unexplained frames, the fixture elsewhere
+            _assert_flips_are_near_ties(embed, g["encoder_out"], ref, keep, got_enc=r["enc_out"], max_frames=1)
+        if ours_differs.any():
+            record_report(name, engine_frames_differing_from_fixture=np.argwhere(ours_differs).tolist(),
+                          reference_self_disagreement_frames=np.argwhere(ref_disagrees).tolist(),
+                          explained_by_reference_variants=int((ours_differs & ref_disagrees).sum()))
+        else:
+            assert rms(r["quantized"], g["quantized"]) <= qtol
     r2 = m.engine.encode_decode(wav, c["n_q"], use_scale=True)
     m.engine.check_status()
     assert ill or torch.equal(r2["codes"], r["codes"])
     assert tuple(r2["recon"].shape) == g["recon"].shape                 # (B, 1, min(T, decoded samples))
-    # the waveform is checked whether or not a frame flipped: whole utterances without a tie, up to the tie otherwise
-    flips = (r["codes"].cpu() != torch.from_numpy(g["indices"].astype(np.int64))).any(0).reshape(-1).nonzero().flatten().tolist()
+    # the waveform is checked whether or not a frame flipped, against the SIGNAL's level (the recordings are quiet: 1e-4 absolute would be
+    # 3 % of libritts_8230's RMS): 1e-3 of the reference reconstruction's RMS without a flip; with a flipped frame elsewhere the
+    # GroupNorm(1, C) statistics of every decoder layer span the whole utterance, so the samples before the flip move by ~1 / frames of
+    # its effect: 1e-2 of the RMS there
+    flips = np.nonzero(ours_differs.reshape(-1))[0].tolist()
     Tf = g["indices"].shape[2]
-    tol = WAV_RMS_TOL * float(np.sqrt((g["recon"] ** 2).mean())) * 10
+    sig_rms = float(np.sqrt((g["recon"].astype(np.float64) ** 2).mean()))
     for b in range(c["batch"]):
         cut = _prefix_before(flips, Tf, m.engine.hop_length, b)
         n = g["recon"].shape[-1] if cut is None else min(cut, g["recon"].shape[-1])
         if n > 0 and not ill:
-            # no flip: the tight bar (1e-3 of the signal's RMS).  With a flipped frame elsewhere the GroupNorm(1, C) statistics of every
-            # decoder layer span the whole utterance, so the prefix moves by ~1 / frames of the flip's effect: north_star's absolute bar
-            assert rms(r2["recon"][b, :, :n], g["recon"][b, :, :n]) < (tol if cut is None else WAV_RMS_TOL), (b, n)
+            assert rms(r2["recon"][b, :, :n], g["recon"][b, :, :n]) < (1e-3 if cut is None else 1e-2) * sig_rms, (b, n, cut)
     tok = torch.from_numpy(g["indices"].astype(np.int64)).permute(1, 2, 0).contiguous()
     w2, emb = m.engine.decode_codes(tok)
     assert rms(emb, g["quantized"]) <= qtol

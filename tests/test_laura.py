@@ -374,7 +374,7 @@ def test_limits_fail_loudly_and_leave_the_engine_usable():
         m.engine.decode_codec(outs, lens, 256, sampling=False)
     with pytest.raises(EngineError, match="max_positions"):
         m.encode(torch.from_numpy(synthetic_text(cfg, 1, [300], 3)), torch.tensor([300]))
-    with pytest.raises(EngineError, match="at most"):
+    with pytest.raises(EngineError, match=r"1 \.\. 16 per call"):
         m.engine.decode_codec(outs[:1].repeat(17, 1, 1), [lens[0]] * 17, 4, sampling=False)
     again = m.engine.decode_codec(outs, lens, 6, sampling=False)
     assert torch.equal(ref[0], again[0]) and ref[1] == again[1]
@@ -383,6 +383,48 @@ def test_limits_fail_loudly_and_leave_the_engine_usable():
     assert o1.shape[:2] == (1, 1) and bool(torch.isfinite(o1).all())
     t, ol = m.engine.decode_codec(o1, [1], 1, sampling=False)
     assert ol == [1] and t.shape[1] >= 1
+
+
+@pytest.mark.gpu
+def test_wrong_shapes_are_refused_before_the_c_abi_sees_them():
+    """The C ABI takes plain pointers and trusts the shapes: a tensor of the wrong width, a lengths list of the wrong length
+    or a codec tensor with the wrong column count must be an EngineError on the host side, never an out-of-bounds read on the device."""
+    from funcodec_amd.engine import EngineError
+    name = "laura_tiny_b3"
+    c, cfg, spec, sd, text, _ = case_inputs(name)
+    g = golden(name)
+    m = laura_engine(name)
+    lens = c["text_lengths"]
+    outs = torch.from_numpy(g["text_outs"])
+    B, L, D = outs.shape
+    nq = spec.predict_nq
+    ref = m.engine.decode_codec(outs, lens, 4, sampling=False)
+    wide = torch.zeros(B, L, D + 16)
+    codec = torch.zeros(B, 5, nq, dtype=torch.int64)
+    bad_calls = [
+        lambda: m.engine.decode_codec(wide, lens, 4, sampling=False),                                   # text_outs width
+        lambda: m.engine.decode_codec(outs, lens[:-1], 4, sampling=False),                              # short lengths list
+        lambda: m.engine.decode_codec(outs, [L + 1] * B, 4, sampling=False),                            # length past the tensor
+        lambda: m.engine.decode_codec(outs, lens, 4, sampling=False, continual=codec[:, :, :1], continual_lengths=[5] * B),
+        lambda: m.engine.decode_codec(outs, lens, 4, sampling=False, continual=codec, continual_lengths=[5] * (B - 1)),
+        lambda: m.engine.decode_codec(outs, lens, 4, sampling=False, continual=codec),                  # continual without lengths
+        lambda: m.engine.decode_codec(outs, lens, 4, sampling=False, forced=torch.zeros(B, 3, nq, dtype=torch.int64)),
+        lambda: m.engine.lm_logprobs(wide, lens),
+        lambda: m.engine.lm_logprobs(outs, lens, torch.zeros(B, 5, nq + 1, dtype=torch.int64), [5] * B),
+        lambda: m.engine.lm_logprobs(outs, lens, codec, [5] * (B + 1)),
+        lambda: m.engine.lm_logprobs(outs, lens, codec, [6] * B),
+        lambda: m.engine.codec_emb(wide, lens, codec, [5] * B),
+        lambda: m.engine.codec_emb(outs, lens, codec[:, :, :0], [5] * B),
+        lambda: m.engine.codec_emb(outs, lens[:1], codec, [5] * B),
+        lambda: m.engine.codec_emb(outs, lens, codec, [5] * (B - 1)),
+        lambda: m.engine.encode(torch.zeros(B, L, spec.input_size + 1), lens) if spec.vocab_size <= 0 else m.engine.encode(torch.zeros(B, L, 3, dtype=torch.int64), lens),
+        lambda: m.engine.encode(torch.from_numpy(text), lens + [1]),
+    ]
+    for i, call in enumerate(bad_calls):
+        with pytest.raises(EngineError):
+            call()
+    again = m.engine.decode_codec(outs, lens, 4, sampling=False)
+    assert torch.equal(ref[0], again[0]) and ref[1] == again[1]
 
 
 @pytest.mark.gpu
