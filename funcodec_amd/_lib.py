@@ -101,6 +101,7 @@ SYMBOLS = {
     "fc_laura_codec_emb": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int, _P, _P, C.c_size_t, _P]),
     "fc_laura_linear": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "fc_laura_debug_probe": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "fc_laura_set_persistent_step": (C.c_int, [_P, C.c_int]),
 }
 
 _lib = None

@@ -103,6 +103,9 @@ struct fc_laura {
     Lin text_out, lm_decoder, codec_out;
     float *lm_emb = nullptr, *cb = nullptr, *tok_emb = nullptr, *pe_abs = nullptr;
     float* lm_embed_wt = nullptr;      // codec_lm.encoder.embed.0.weight transposed [D][d] (the sampler's fused input layer)
+    lk::StepLayer* step_layers = nullptr;   // device table of the LM's blocks for the persistent decoding step (laura_persist.hip)
+    int persist_grid = 0;              // workgroups of the persistent step launch, 0 = not available on this device / for this model
+    bool persist_on = !(getenv("FC_LAURA_PERSIST") && atoi(getenv("FC_LAURA_PERSIST")) == 0);   // fc_laura_set_persistent_step
     std::map<std::string, Lin*> lin_by_name;
     std::vector<void*> dev_allocs;
     int vocab() const { return arch.predict_nq * (arch.codebook_size + 1); }
@@ -532,9 +535,20 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     float* hb = cx.alloc<float>((size_t)16 * ff);
     float* lg = cx.alloc<float>((size_t)16 * V);
     float* nemb = cx.alloc<float>((size_t)16 * D);
+    // the decoding step as ONE persistent launch (laura_persist.hip): per-block edge buffers, arrival counters, the launch counter
+    const int KS2 = lk::step_persist_ksplit(d, ff);
+    auto pad32 = [](size_t n) { return (n + 31) & ~(size_t)31; };
+    const size_t o_q = 0, o_ap = o_q + pad32((size_t)16 * d), o_xm = o_ap + pad32((size_t)16 * heads * 8 * (dkh + 2)),
+                 o_hb = o_xm + pad32((size_t)16 * d), o_xo = o_hb + pad32((size_t)16 * ff), edge_stride = o_xo + pad32((size_t)KS2 * 16 * d);
+    float* edge = cx.alloc<float>(edge_stride * NL);
+    const size_t sync_words = lk::step_persist_sync_words(NL);
+    unsigned* psync = cx.alloc<unsigned>(sync_words + 32);
+    unsigned* pseq = psync ? psync + sync_words : nullptr;          // one word behind the counters
+    const bool persist = e->persist_on && e->persist_grid > 0 && lk::step_persist_supported(B, d, ff, heads, dkh, V, NS);
     if (cx.live()) {
         cx.check(lk::launch_lm_assemble(tfm, Tt, tl, e->lm_emb, e->cb, K, nq, continual, cl, Cmax, B, D, T, seq, pos, bidir, cx.st), "LM input");
         cx.check(lk::launch_fill_i32(ctr, 0, 3 * B + 4, cx.st), "counters");
+        cx.check(lk::launch_fill_i32((int*)psync, 0, (int)sync_words + 32, cx.st), "arrival counters");
         if (continual) hipLaunchKernelGGL(copy_prompt_kernel, dim3(B), dim3(256), 0, cx.st, continual, cl, Cmax, nq, tokens, Cmax + max_length);
     }
     float* h = run_stack_full(e, cx, S, seq, T, pos, e->arch.bidirectional_inputs ? bidir : nullptr, 1, &kv);
@@ -549,11 +563,23 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     // the sampler also runs the LM's input layer on the new token (Linear + LayerNorm + ReLU + x * sqrt(d)): xs is ready for block 0
     sm.emb_wt = e->lm_embed_wt; sm.emb_bias = S.embed.bias; sm.emb_g = S.eg; sm.emb_b = S.eb; sm.dm = d; sm.emb_relu = S.s.embed_relu;
     sm.xscale = sqrtf((float)d); sm.xs = xs;
+    sm.launch_seq = pseq;                  // every sampler launch numbers the persistent step launch that follows it (1, 2, ...)
     cx.check(lk::launch_sample(sm, cx.st), "sampling");
     int host_done = 0;
+    lk::StepPersistArgs pa{};
+    pa.layers = e->step_layers; pa.wdec = e->lm_decoder.wf; pa.bdec = e->lm_decoder.bias; pa.ag = S.ag; pa.ab = S.ab;
+    pa.xs = xs; pa.logits = lg; pa.edge = edge; pa.kc = kv.kc; pa.vc = kv.vc; pa.pos = pos; pa.sync = psync; pa.seq = pseq;
+    pa.edge_stride = edge_stride; pa.o_q = (int)o_q; pa.o_ap = (int)o_ap; pa.o_xm = (int)o_xm; pa.o_hb = (int)o_hb; pa.o_xo = (int)o_xo;
+    pa.B = B; pa.d = d; pa.ff = ff; pa.H = heads; pa.DK = dkh; pa.NL = NL; pa.V = V; pa.Tcap = Tcap; pa.R = e->R; pa.PR = e->PR; pa.NS = NS;
+    pa.act = S.s.act; pa.G = e->persist_grid; pa.KS2 = KS2;
     // one decoding step: the newest token of every utterance through the LM against its KV cache.  Every kernel reads its
     // positions from device memory, so the launch sequence is identical from step to step.
     auto run_step = [&](hipStream_t st) {
+        if (persist) {
+            cx.check(lk::launch_step_persist(pa, st), "persistent decoding step");
+            cx.check(lk::launch_sample(sm, st), "sampling");
+            return;
+        }
         for (int i = 0; i < NL; ++i) {
             const Block& b = S.blocks[i];
             float* kc = kv.kc + (size_t)i * B * d * Tcap;
@@ -574,6 +600,14 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     auto all_done = [&]() -> bool {       // all utterances finished? (one small read-back)
         if (hipMemcpyAsync(&host_done, n_done, sizeof(int), hipMemcpyDeviceToHost, cx.st) != hipSuccess ||
             hipStreamSynchronize(cx.st) != hipSuccess) { cx.err = 1; fail("decode_codec: status read-back failed"); return true; }
+        if (persist) {      // stop replaying steps once a hand-off has timed out
+            unsigned perr = 0;
+            if (hipMemcpy(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess || perr) {
+                cx.err = 1;
+                fail("decode_codec: the persistent decoding step timed out at a hand-off (set FC_LAURA_PERSIST=0 to use the kernel chain)");
+                return true;
+            }
+        }
         return host_done >= B;
     };
     int s = 1;
@@ -599,6 +633,12 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (cx.err) return 1;
+    if (persist) {      // a hand-off of the persistent step timed out (a workgroup not resident, a lost store): never a silent result
+        unsigned perr = 0;
+        HIP_TRY(hipMemcpyAsync(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost, cx.st));
+        HIP_TRY(hipStreamSynchronize(cx.st));
+        if (perr) return fail("decode_codec: the persistent decoding step timed out at a hand-off (set FC_LAURA_PERSIST=0 to use the kernel chain)");
+    }
     std::vector<int> gen(B);
     HIP_TRY(hipMemcpyAsync(gen.data(), n_gen, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, cx.st));
     HIP_TRY(hipStreamSynchronize(cx.st));
@@ -741,6 +781,17 @@ int fc_laura_finalize(fc_laura* e) {
         }
         if (upload(e, pe, &e->pe_abs)) return 1;
     }
+    {   // the persistent decoding step's view of the LM blocks
+        const Stack& S = e->codec_lm;
+        std::vector<lk::StepLayer> tab(S.blocks.size());
+        for (size_t i = 0; i < S.blocks.size(); ++i) {
+            const Block& b = S.blocks[i];
+            tab[i] = lk::StepLayer{b.qkv.wf, b.qkv.bias, b.out.wf, b.out.bias, b.ff1.wf, b.ff1.bias, b.ff2.wf, b.ff2.bias,
+                                   b.n1g, b.n1b, b.n2g, b.n2b, b.bu, b.bv, b.ptab};
+        }
+        if (upload(e, tab, &e->step_layers)) return 1;
+        e->persist_grid = lk::step_persist_grid(e->device, S.s.d_model, S.s.ff);
+    }
     e->host.clear();
     e->finalized = true;
     return 0;
@@ -832,6 +883,12 @@ int fc_laura_codec_emb(fc_laura* e, const float* text_outs, const int32_t* text_
     if (Tmax > e->R) return fail("sequence longer than max_positions");
     Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
     return do_codec_emb(e, cx, text_outs, text_lens, L, codec, nq_cols, codec_lens, Cmax, emb, Tmax);
+}
+
+int fc_laura_set_persistent_step(fc_laura* e, int on) {
+    if (!e) return -1;
+    e->persist_on = on != 0;
+    return e->persist_on && e->persist_grid > 0 ? 1 : 0;
 }
 
 int fc_laura_debug_probe(void* dev_dst, size_t cap_bytes, int stack, int layer, int what) {

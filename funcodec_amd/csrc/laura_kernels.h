@@ -124,10 +124,40 @@ struct Sample {
     int dm = 0, emb_relu = 0;
     float xscale = 1.f;
     float* xs = nullptr;            // [B][dm]
+    unsigned* launch_seq = nullptr; // device word incremented once per launch (the persistent step kernel's launch number), or null
 };
 hipError_t launch_sample(const Sample& s, hipStream_t st);
 
 hipError_t launch_fill_i32(int* p, int v, int n, hipStream_t st);
+
+// ---- step form as ONE persistent launch (laura_persist.hip) ------------------------------------------------------------------------
+struct StepLayer {          // constant device pointers of one block (fragment-order weights of the step form, biases padded to row tiles)
+    const float *wqkv, *bqkv, *wout, *bout, *wff1, *bff1, *wff2, *bff2;
+    const float *n1g, *n1b, *n2g, *n2b, *bu, *bv, *ptab;
+};
+struct StepPersistArgs {
+    const StepLayer* layers;        // device [NL]
+    const float *wdec, *bdec;       // output layer (fragment order), bias
+    const float *ag, *ab;           // after_norm
+    const float* xs;                // [16][d]: LM input of this step (written by the sampler of the previous step)
+    float* logits;                  // [16][V]
+    float* edge;                    // NL x edge_stride floats: per block q [16][d] | partials [B][H][NS][DK + 2] | xm [16][d] | h [16][ff] | x_out [KS2][16][d]
+    float *kc, *vc;                 // KV caches [NL][B][d][Tcap] / [NL][B][Tcap][d]
+    const int* pos;                 // device [B]
+    unsigned* sync;                 // arrival counters (step_persist_sync_words), zeroed once per decode call
+    const unsigned* seq;            // device word: number of this launch within the call (1, 2, ...), incremented by the sampler
+    size_t edge_stride;
+    int o_q, o_ap, o_xm, o_hb, o_xo;
+    int B, d, ff, H, DK, NL, V, Tcap, R, PR, NS, act, G;
+    int KS2;                        // k slices of w_2 (step_persist_ksplit)
+    int wtile;                      // floats of one LDS weight tile (set by launch_step_persist)
+};
+int step_persist_ksplit(int d, int ff);
+size_t step_persist_sync_words(int NL);
+size_t step_persist_lds_bytes(int B, int d, int ff, int H, int DK);
+bool step_persist_supported(int B, int d, int ff, int H, int DK, int V, int NS);
+int step_persist_grid(int device, int d, int ff);          // workgroups of the persistent launch (0: not launchable here)
+hipError_t launch_step_persist(const StepPersistArgs& a, hipStream_t st);
 
 }  // namespace laura
 }  // namespace fc

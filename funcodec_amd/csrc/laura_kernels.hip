@@ -933,6 +933,7 @@ struct SampleArgs {
     int dm, emb_relu;
     float xscale;
     float* xs;
+    unsigned* launch_seq;
 };
 
 #define FC_SAMPLE_MAXV 2048      // candidates per group, padded to a power of two for the bitonic sort (K + 1 <= 2048)
@@ -1272,6 +1273,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             }
         }
         a.step[b] = step + 1;
+        if (b == 0 && a.launch_seq) *a.launch_seq += 1u;
     }
 }
 
@@ -1280,7 +1282,7 @@ hipError_t launch_sample(const Sample& s, hipStream_t st) {
     if (s.emb_wt && (s.dm > 1024 || s.dm % 4 || s.D > FC_SAMPLE_MAXV)) return hipErrorInvalidValue;
     SampleArgs a{s.logits, s.K, s.nq, s.mode, s.ki, s.pf, s.seed, s.forced, s.max_steps, s.tokens, s.tok_stride, s.tok_off, s.n_gen,
                  s.done, s.n_done, s.pos, s.step, s.logp_out, s.cb, s.D, s.next_emb, s.B,
-                 s.emb_wt, s.emb_bias, s.emb_g, s.emb_b, s.dm, s.emb_relu, s.xscale, s.xs};
+                 s.emb_wt, s.emb_bias, s.emb_g, s.emb_b, s.dm, s.emb_relu, s.xscale, s.xs, s.launch_seq};
     hipLaunchKernelGGL(sample_kernel, dim3(s.B), dim3(256), 0, st, a);
     return hipGetLastError();
 }

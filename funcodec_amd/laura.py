@@ -111,6 +111,11 @@ class LauraEngine:
             logging.info("funcodec_amd: skipped %d LauraTTS checkpoint tensors outside the generation path (e.g. %s)", len(skipped), skipped[0])
         self._check(self.lib.fc_laura_finalize(self._h))
 
+    def set_persistent_step(self, on: bool) -> bool:
+        """Decoding step as one persistent launch (default) or as the chain of one kernel per Linear / attention; returns whether the
+        persistent form is in effect (False also when this model / device cannot run it)."""
+        return self.lib.fc_laura_set_persistent_step(self._h, int(bool(on))) == 1
+
     def _workspace(self, B: int, L: int, Cmax: int, max_length: int) -> torch.Tensor:
         key = (B, L, Cmax, max_length)
         need = self._ws_need.get(key)

@@ -319,6 +319,13 @@ int fc_laura_linear(fc_laura* e, const char* name, const float* x, int B, int T,
  * block `layer` (layer = number of blocks: before after_norm).  dev_dst NULL switches it off. */
 int fc_laura_debug_probe(void* dev_dst, size_t cap_bytes, int stack, int layer, int what);
 
+/* How fc_laura_decode_codec runs a decoding step (no reference counterpart: the reference re-scores the whole prefix per token,
+ * funcodec/models/audio_generation/laura_model.py:501-548).  on = 1 (default; FC_LAURA_PERSIST=0 in the environment changes the default):
+ * ONE persistent launch per step whose workgroups hand the token vectors to each other through arrival counters (csrc/laura_persist.hip);
+ * on = 0: the chain of one kernel per Linear / attention (csrc/laura_kernels.hip).  Same arithmetic, results agree to fp32 rounding.
+ * Returns 1 if the persistent form is in effect afterwards, 0 if the chain is (switched off, or the model / device cannot run it), -1 on a null handle. */
+int fc_laura_set_persistent_step(fc_laura* e, int on);
+
 #ifdef __cplusplus
 }
 #endif

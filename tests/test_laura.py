@@ -463,6 +463,44 @@ def test_step_form_long_sequences_against_full_sequence_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,B,steps", [("lauraphn", 8, 120), ("lauraphn", 16, 40), ("lauraphn", 3, 40), ("tinylaura", 5, 30)])
+def test_persistent_step_equals_the_kernel_chain(cfg_name, B, steps):
+    """The decoding step as ONE persistent launch (csrc/laura_persist.hip: workgroups hand the token vectors over through arrival
+    counters, weights prefetched by LDS DMA) against the chain of one kernel per Linear / attention it replaces: same arithmetic up to the
+    split of the contraction / key ranges, so teacher-forced log-probabilities agree to fp32 rounding at EVERY step and greedy generations
+    are identical; repeated runs of the persistent form are bit-identical (fixed summation orders, no atomics on data)."""
+    from funcodec_amd.laura import LauraGenMI355X
+    cfg = laura_recipe_config(cfg_name)
+    spec = laura_spec_from_config(cfg)
+    sd = make_laura_state_dict(cfg, 3)
+    m = LauraGenMI355X(spec, "cuda:0", max_positions=512)
+    m.load_state_dict(sd)
+    lens = [12 + (5 * i) % 23 for i in range(B)]
+    text = synthetic_text(cfg, B, lens, 17)
+    rng = np.random.Generator(np.random.PCG64(4))
+    forced = torch.from_numpy(rng.integers(0, spec.codebook_size, size=(B, steps, spec.predict_nq)).astype(np.int64))
+    cont = torch.from_numpy(rng.integers(0, spec.codebook_size, size=(B, 9, spec.predict_nq)).astype(np.int64))
+    cl = [9 - (i % 4) for i in range(B)]
+    with torch.no_grad():
+        outs, _ = m.encode(torch.from_numpy(text), torch.tensor(lens))
+        assert m.engine.set_persistent_step(True), "the persistent step must be available for this model on MI355X"
+        tp, lp, sp = m.engine.decode_codec(outs, lens, steps, sampling=False, forced=forced, return_logp=True, continual=cont, continual_lengths=cl)
+        tp2, lp2, sp2 = m.engine.decode_codec(outs, lens, steps, sampling=False, forced=forced, return_logp=True, continual=cont, continual_lengths=cl)
+        gp = m.engine.decode_codec(outs, lens, steps, sampling=False)
+        kp = m.engine.decode_codec(outs, lens, steps, sampling=25, seed=11)
+        assert not m.engine.set_persistent_step(False)
+        tc, lc, sc = m.engine.decode_codec(outs, lens, steps, sampling=False, forced=forced, return_logp=True, continual=cont, continual_lengths=cl)
+        gc = m.engine.decode_codec(outs, lens, steps, sampling=False)
+        m.engine.set_persistent_step(True)
+    assert lp == lc == [c + steps for c in cl] and torch.equal(tp, tc)
+    assert torch.equal(sp, sp2) and torch.equal(tp, tp2)                      # run-to-run bit-identical
+    err = float((sp - sc).abs().max())
+    assert err < 2e-5, err
+    assert gp[1] == gc[1] and torch.equal(gp[0], gc[0])                       # greedy generations identical
+    assert all(v == steps for v in kp[1]) and int(kp[0].max()) < spec.codebook_size
+
+
+@pytest.mark.gpu
 def test_device_sampler_follows_the_step_distribution():
     """Device-side sampling against the oracle's restatement of LauraGenModel.sampling_ids on the SAME scores: for top-k the drawn
     ids must lie in the reference's candidate set, and over many seeds the empirical distribution of the first sampled token
