@@ -538,12 +538,14 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     // the decoding step as ONE persistent launch (laura_persist.hip): per-block edge buffers, arrival counters, the launch counter
     const int KS2 = lk::step_persist_ksplit(d, ff);
     auto pad32 = [](size_t n) { return (n + 31) & ~(size_t)31; };
-    const size_t o_q = 0, o_ap = o_q + pad32((size_t)16 * d), o_xm = o_ap + pad32((size_t)16 * heads * 8 * (dkh + 2)),
+    const size_t o_q = 0, o_ap = o_q + pad32((size_t)16 * d), o_xm = o_ap + pad32((size_t)16 * heads * 8 * (dkh + 4)),
                  o_hb = o_xm + pad32((size_t)16 * d), o_xo = o_hb + pad32((size_t)16 * ff), edge_stride = o_xo + pad32((size_t)KS2 * 16 * d);
     float* edge = cx.alloc<float>(edge_stride * NL);
     const size_t sync_words = lk::step_persist_sync_words(NL);
     unsigned* psync = cx.alloc<unsigned>(sync_words + 32);
     unsigned* pseq = psync ? psync + sync_words : nullptr;          // one word behind the counters
+    static const char* trace_path = getenv("FC_LAURA_TRACE");        // tuning aid: s_memtime stamps of the LAST persistent step -> file
+    unsigned long long* ptrace = trace_path ? cx.alloc<unsigned long long>((size_t)256 * 64 * 8) : nullptr;
     const bool persist = e->persist_on && e->persist_grid > 0 && lk::step_persist_supported(B, d, ff, heads, dkh, V, NS);
     if (cx.live()) {
         cx.check(lk::launch_lm_assemble(tfm, Tt, tl, e->lm_emb, e->cb, K, nq, continual, cl, Cmax, B, D, T, seq, pos, bidir, cx.st), "LM input");
@@ -571,7 +573,8 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     pa.xs = xs; pa.logits = lg; pa.edge = edge; pa.kc = kv.kc; pa.vc = kv.vc; pa.pos = pos; pa.sync = psync; pa.seq = pseq;
     pa.edge_stride = edge_stride; pa.o_q = (int)o_q; pa.o_ap = (int)o_ap; pa.o_xm = (int)o_xm; pa.o_hb = (int)o_hb; pa.o_xo = (int)o_xo;
     pa.B = B; pa.d = d; pa.ff = ff; pa.H = heads; pa.DK = dkh; pa.NL = NL; pa.V = V; pa.Tcap = Tcap; pa.R = e->R; pa.PR = e->PR; pa.NS = NS;
-    pa.act = S.s.act; pa.G = e->persist_grid; pa.KS2 = KS2;
+    pa.act = S.s.act; pa.G = e->persist_grid; pa.KS2 = KS2; pa.trace = ptrace;
+    if (ptrace && cx.live()) cx.check(hipMemsetAsync(ptrace, 0, (size_t)256 * 64 * 8 * sizeof(unsigned long long), cx.st), "trace");
     // one decoding step: the newest token of every utterance through the LM against its KV cache.  Every kernel reads its
     // positions from device memory, so the launch sequence is identical from step to step.
     auto run_step = [&](hipStream_t st) {
@@ -633,6 +636,12 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (cx.err) return 1;
+    if (persist && ptrace) {
+        std::vector<unsigned long long> tr((size_t)256 * 64 * 8);
+        HIP_TRY(hipMemcpyAsync(tr.data(), ptrace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, cx.st));
+        HIP_TRY(hipStreamSynchronize(cx.st));
+        if (FILE* f = fopen(trace_path, "wb")) { fwrite(tr.data(), sizeof(unsigned long long), tr.size(), f); fclose(f); }
+    }
     if (persist) {      // a hand-off of the persistent step timed out (a workgroup not resident, a lost store): never a silent result
         unsigned perr = 0;
         HIP_TRY(hipMemcpyAsync(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost, cx.st));

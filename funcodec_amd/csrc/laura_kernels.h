@@ -141,7 +141,7 @@ struct StepPersistArgs {
     const float *ag, *ab;           // after_norm
     const float* xs;                // [16][d]: LM input of this step (written by the sampler of the previous step)
     float* logits;                  // [16][V]
-    float* edge;                    // NL x edge_stride floats: per block q [16][d] | partials [B][H][NS][DK + 2] | xm [16][d] | h [16][ff] | x_out [KS2][16][d]
+    float* edge;                    // NL x edge_stride floats: per block q [16][d] | partials [B][H][NS][DK + 4] | xm [16][d] | h [16][ff] | x_out [KS2][16][d]
     float *kc, *vc;                 // KV caches [NL][B][d][Tcap] / [NL][B][Tcap][d]
     const int* pos;                 // device [B]
     unsigned* sync;                 // arrival counters (step_persist_sync_words), zeroed once per decode call
@@ -151,6 +151,7 @@ struct StepPersistArgs {
     int B, d, ff, H, DK, NL, V, Tcap, R, PR, NS, act, G;
     int KS2;                        // k slices of w_2 (step_persist_ksplit)
     int wtile;                      // floats of one LDS weight tile (set by launch_step_persist)
+    unsigned long long* trace;      // tuning aid (FC_LAURA_TRACE): [G][64 units][8] s_memtime stamps of the last launch, or null
 };
 int step_persist_ksplit(int d, int ff);
 size_t step_persist_sync_words(int NL);

@@ -54,15 +54,23 @@ constexpr int kThreads = 512, kWaves = 8;
 constexpr int kCntStride = 32;            // words between two arrival counters (128 bytes)
 constexpr int kCntPerPhase = 16;
 
+// sum / max over the 64 lanes of a wave: 16-lane rows by DPP butterflies (quad swaps, half-row and row mirrors), then the four row
+// results through readlane -- ~20 VALU instructions; a __shfl_xor tree is 6 ds_bpermute round trips through the LDS crossbar
+#define FC_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
+#define FC_LANE(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l))
 __device__ __forceinline__ float wave_sum_p(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += FC_DPP(v, 0xB1);
+    v += FC_DPP(v, 0x4E);
+    v += FC_DPP(v, 0x141);
+    v += FC_DPP(v, 0x140);
+    return ((FC_LANE(v, 0) + FC_LANE(v, 16)) + FC_LANE(v, 32)) + FC_LANE(v, 48);
 }
 __device__ __forceinline__ float wave_max_p(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, FC_DPP(v, 0xB1));
+    v = fmaxf(v, FC_DPP(v, 0x4E));
+    v = fmaxf(v, FC_DPP(v, 0x141));
+    v = fmaxf(v, FC_DPP(v, 0x140));
+    return fmaxf(fmaxf(FC_LANE(v, 0), FC_LANE(v, 16)), fmaxf(FC_LANE(v, 32), FC_LANE(v, 48)));
 }
 __device__ __forceinline__ float act_p(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.f;
@@ -72,8 +80,23 @@ __device__ __forceinline__ float act_p(float v, int act) {
 __device__ __forceinline__ void store_wt(float* p, float v) {       // write-through store (global_store_dword ... sc1)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void store_wt4(float* p, f32x4 v) {      // 16-byte write-through store: one fabric write instead of four
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// Workgroup barrier for LDS hand-offs that leaves global memory operations in flight.  __syncthreads() is a workgroup-scope fence +
+// s_barrier: hipcc drains vmcnt(0) in front of it, i.e. every barrier would wait for the weight tile this wave has just requested (the
+// first two builds: +1.1 us per unit).  LDS traffic is ordered by lgkmcnt; global hand-offs have their own explicit drains (arrive).
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct Item { int ph, u; };
+
+// tuning aid: thread 0 of a workgroup stamps s_memtime (shader clock) at the edges of a unit's life; slot = (workgroup, n-th unit)
+struct Trace {
+    unsigned long long* p;
+    __device__ __forceinline__ void stamp(int j) const { if (p && threadIdx.x == 0) p[j] = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void id(int ph, int u) const { if (p && threadIdx.x == 0) p[7] = ((unsigned long long)(unsigned)ph << 32) | (unsigned)u; }
+};
 
 // kinds: 0 QKV, 1 ATT, 2 OUT, 3 FF1, 4 FF2, 5 DEC
 __device__ __forceinline__ int phase_kind(const StepPersistArgs& a, int ph) { return ph == 5 * a.NL ? 5 : ph % 5; }
@@ -138,7 +161,7 @@ __device__ __forceinline__ void wait_phase(const StepPersistArgs& a, int ph, uns
             }
         }
     }
-    __syncthreads();
+    wg_barrier();
 }
 
 // ---- weight tiles ------------------------------------------------------------------------------------------------------------------
@@ -214,82 +237,148 @@ __device__ __forceinline__ const float* layer_in(const StepPersistArgs& a, int l
 __device__ __forceinline__ int layer_in_parts(const StepPersistArgs& a, int l) { return l == 0 ? 1 : a.KS2; }
 
 // ---- staging of a GEMV unit's input into LDS: Xs [B + 1][XS] (row B = zeros), optional LayerNorm over K ------------------------------
-// src: `parts` buffers of [16][ld] floats (part stride 16 * ld) that are added up; columns [col0, col0 + K) of every row
+// src: `parts` buffers of [16][ld] floats (part stride 16 * ld) that are added up; columns [col0, col0 + K) of every row.
+// Every load of a thread is issued before the first use (batches of 4 elements x PM parts, clamped addresses): a load -> LDS store loop
+// pays one memory round trip per trip, and a fresh line of another XCD's write-through store is ~1 us away (measured: 7.6 us per QKV
+// unit in the first version of this kernel, of which 3.6 us were a LayerNorm that walked LDS three times per row).
+template <int PM>
 __device__ __forceinline__ void stage_rows(const float* src, int ld, int col0, int parts, int K, int B, int XS, float* Xs, const float* gamma,
-                                           const float* beta, float eps, float* gb) {
+                                           const float* beta, float eps, float* gb, Trace tr) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int e = tid * 4; e < (B + 1) * K; e += kThreads * 4) {
-        const int b = e / K, k = e - b * K;
-        gfp sp = FC_G(src) + (size_t)(b < B ? b : B - 1) * ld + col0 + k;
-        f32x4 v = *FC_G4(sp);
-        for (int q = 1; q < parts; ++q) v += *FC_G4(sp + (size_t)q * 16 * ld);
-        if (b >= B) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *(f32x4*)(Xs + b * XS + k) = v;
+    const int K4 = K >> 2, NE = B * K4;
+    for (int k = tid; k < K4; k += kThreads) *(f32x4*)(Xs + B * XS + 4 * k) = (f32x4){0.f, 0.f, 0.f, 0.f};        // the zero row
+    if (gamma) {       // K <= 1024: one 16-byte piece of gamma or beta per thread
+        const int i = tid < 2 * K4 ? tid : 0;
+        const f32x4 gv = *FC_G4(FC_G(i < K4 ? gamma : beta) + 4 * (i < K4 ? i : i - K4));
+        if (tid < 2 * K4) *(f32x4*)(gb + 4 * i) = gv;
     }
-    if (gamma) {
-        for (int k = tid * 4; k < K; k += kThreads * 4) {
-            *(f32x4*)(gb + k) = *FC_G4(FC_G(gamma) + k);
-            *(f32x4*)(gb + K + k) = *FC_G4(FC_G(beta) + k);
+    for (int base = 0; base < NE; base += 4 * kThreads) {
+        f32x4 v[4][PM];
+        int dst[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = base + i * kThreads + tid, ec = e < NE ? e : NE - 1;
+            const int b = ec / K4, k4 = ec - b * K4;
+            dst[i] = e < NE ? b * XS + 4 * k4 : -1;
+            gfp sp = FC_G(src) + (size_t)b * ld + col0 + 4 * k4;
+#pragma unroll
+            for (int q = 0; q < PM; ++q) v[i][q] = *FC_G4(sp + (size_t)(q < parts ? q : 0) * 16 * ld);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 sum = v[i][0];
+#pragma unroll
+            for (int q = 1; q < PM; ++q) if (q < parts) sum += v[i][q];
+            if (dst[i] >= 0) *(f32x4*)(Xs + dst[i]) = sum;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the weight tile (LDS DMA) has landed too
-    __syncthreads();
-    if (gamma) {       // two-pass LayerNorm of every row (one wave per row at a time), like gemv_kernel
-        for (int b = w; b < B; b += kWaves) {
+    tr.stamp(5);
+    wg_barrier();
+    tr.stamp(6);
+#ifndef FC_PERSIST_ABL
+#define FC_PERSIST_ABL 0       // profiling builds only (results are garbage): 1 no LayerNorm arithmetic, 2 no precise division / square root in it
+#endif
+    if (gamma) {       // two-pass LayerNorm, one wave per row, the row in registers (<= 4 pieces of 16 bytes per lane)
+        for (int b = w; b < B && !(FC_PERSIST_ABL & 1); b += kWaves) {
             float* xr = Xs + b * XS;
+            f32x4 x[4];
             float s = 0.f;
-            for (int k = lane; k < K; k += 64) s += xr[k];
-            const float mean = wave_sum_p(s) / (float)K;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = lane + 64 * i;
+                x[i] = j < K4 ? *(const f32x4*)(xr + 4 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                s += (x[i][0] + x[i][1]) + (x[i][2] + x[i][3]);
+            }
+            f32x4 gm[4], bt[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = lane + 64 * i < K4 ? lane + 64 * i : 0;
+                gm[i] = *(const f32x4*)(gb + 4 * j);
+                bt[i] = *(const f32x4*)(gb + K + 4 * j);
+            }
+            const float mean = (FC_PERSIST_ABL & 2) ? wave_sum_p(s) * __builtin_amdgcn_rcpf((float)K) : wave_sum_p(s) / (float)K;
             float q = 0.f;
-            for (int k = lane; k < K; k += 64) { const float dv = xr[k] - mean; q += dv * dv; }
-            const float rstd = 1.f / sqrtf(wave_sum_p(q) / (float)K + eps);
-            for (int k = lane; k < K; k += 64) xr[k] = (xr[k] - mean) * rstd * gb[k] + gb[K + k];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lane + 64 * i < K4) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float dv = x[i][c] - mean; q += dv * dv; }
+                }
+            const float rstd = (FC_PERSIST_ABL & 2) ? __builtin_amdgcn_rsqf(wave_sum_p(q) * __builtin_amdgcn_rcpf((float)K) + eps)
+                                                    : 1.f / sqrtf(wave_sum_p(q) / (float)K + eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = lane + 64 * i;
+                if (j < K4) *(f32x4*)(xr + 4 * j) = (x[i] - mean) * rstd * gm[i] + bt[i];
+            }
         }
-        __syncthreads();
+        wg_barrier();
     }
 }
 
-// x[b][h * DK + dd] = combination of the NS key-range partials of head h (flash-decoding), as gemv_kernel's `apart` prologue
-__device__ __forceinline__ void stage_partials(const float* __restrict__ apart, int B, int H, int DK, int NS, int XS, float* Xs, float* wn) {
-    const int tid = threadIdx.x, K = H * DK, PS = DK + 2;
-    for (int e = tid; e < B * H; e += kThreads) {
-        gfp pp = FC_G(apart) + (size_t)e * NS * PS;
-        float mv[8], lv[8];
+// x[b][h * DK + dd] = combination of the NS key-range partials of head h (flash-decoding): o_s (unnormalised), running max m_s, sum l_s;
+// partial row = [o[DK] | m | l | pad pad] (16-byte aligned).  Everything a thread needs is requested at once: its (b, h) pair's m / l
+// values and the o pieces of its <= 2 output quads per batch.
+__device__ __forceinline__ void stage_partials(const float* apart, int B, int H, int DK, int NS, int XS, float* Xs, float* wn, Trace tr) {
+    const int tid = threadIdx.x, K = H * DK, PS = DK + 4, DK4 = DK >> 2;
+    const int NE = B * H * DK4;                       // output quads
+    for (int k = tid * 4; k < K; k += kThreads * 4) *(f32x4*)(Xs + B * XS + k) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mv[8], lv[8];
+    {
+        const int e = tid < B * H ? tid : 0;
+        gfp pp = FC_G(apart) + (size_t)e * NS * PS + DK;
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp) {
             const int sc = sp < NS ? sp : NS - 1;
-            mv[sp] = pp[sc * PS + DK];
-            lv[sp] = pp[sc * PS + DK + 1];
+            mv[sp] = pp[sc * PS];
+            lv[sp] = pp[sc * PS + 1];
         }
-        float M = -INFINITY;
+    }
+    bool first = true;
+    for (int base = 0; base < NE; base += 2 * kThreads) {
+        f32x4 ov[2][8];
+        int bh[2], dst[2];
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) M = fmaxf(M, sp < NS ? mv[sp] : -INFINITY);
-        float L = 0.f, wg[8];
+        for (int i = 0; i < 2; ++i) {
+            const int e = base + i * kThreads + tid, ec = e < NE ? e : NE - 1;
+            bh[i] = ec / DK4;
+            const int q4 = ec - bh[i] * DK4, b = bh[i] / H, h = bh[i] - b * H;
+            dst[i] = e < NE ? b * XS + h * DK + 4 * q4 : -1;
+            gfp pp = FC_G(apart) + (size_t)bh[i] * NS * PS + 4 * q4;
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {
-            wg[sp] = sp < NS ? expf(mv[sp] - M) : 0.f;
-            L = fmaf(lv[sp], wg[sp], L);
+            for (int sp = 0; sp < 8; ++sp) ov[i][sp] = *FC_G4(pp + (size_t)(sp < NS ? sp : NS - 1) * PS);
         }
-        const float inv = 1.f / L;
+        if (first) {       // normalised weights exp(m_s - M) / L of every (b, h), once
+            first = false;
+            if (tid < B * H) {
+                float M = -INFINITY;
 #pragma unroll
-        for (int sp = 0; sp < 8; ++sp) wn[e * 8 + sp] = wg[sp] * inv;
+                for (int sp = 0; sp < 8; ++sp) M = fmaxf(M, sp < NS ? mv[sp] : -INFINITY);
+                float L = 0.f, wg[8];
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    wg[sp] = sp < NS ? expf(mv[sp] - M) : 0.f;
+                    L = fmaf(lv[sp], wg[sp], L);
+                }
+                const float inv = 1.f / L;
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) wn[tid * 8 + sp] = wg[sp] * inv;
+            }
+            wg_barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* wq = wn + bh[i] * 8;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) o += ov[i][sp] * wq[sp];          // weights of ranges >= NS are 0
+            if (dst[i] >= 0) *(f32x4*)(Xs + dst[i]) = o;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the weight tile (LDS DMA) has landed too
-    __syncthreads();
-    for (int e = tid; e < B * K; e += kThreads) {
-        const int b = e / K, k = e - b * K, h = k / DK, dd = k - h * DK;
-        gfp pp = FC_G(apart) + ((size_t)(b * H + h) * NS) * PS + dd;
-        const float* wq = wn + (b * H + h) * 8;
-        float ov[8];
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp) ov[sp] = pp[(sp < NS ? sp : NS - 1) * PS];
-        float o = 0.f;
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp) o = fmaf(ov[sp], wq[sp], o);
-        Xs[b * XS + k] = o;
-    }
-    for (int k = tid; k < K; k += kThreads) Xs[B * XS + k] = 0.f;
-    __syncthreads();
+    tr.stamp(5);
+    wg_barrier();
 }
 
 // ---- attention unit: one (utterance, head) against ONE key range of the KV cache; the two halves of the workgroup take half of the
@@ -320,7 +409,7 @@ __device__ __forceinline__ void att_unit(const StepPersistArgs& a, int l, int u,
     const int h0 = k0 + hf * hc;
     const int h1 = h0 + hc < k1 ? h0 + hc : k1;
     const int npass = (hc + CH - 1) / CH;             // the same for both halves (workgroup barriers inside the pass loop)
-    float* out = edge_ap(a, l) + ((size_t)(b * a.H + h) * a.NS + sp) * (DK + 2);
+    float* out = edge_ap(a, l) + ((size_t)(b * a.H + h) * a.NS + sp) * (DK + 4);
     if (tid < DK) {
         const float q = edge_q(a, l)[(size_t)b * d + h * DK + tid];
         qu[tid] = q + FC_G(L.bu)[h * DK + tid];
@@ -355,7 +444,7 @@ __device__ __forceinline__ void att_unit(const StepPersistArgs& a, int l, int u,
             const int jj = jg + i * NG;
             vv[i] = *FC_G4(vb + (size_t)(jj < cn ? c0 + jj : cs) * d);
         }
-        __syncthreads();                              // qu / qv visible (first pass); LDS of the previous pass free
+        wg_barrier();                              // qu / qv visible (first pass); LDS of the previous pass free
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dd = 0; dd < DPG; ++dd) {
@@ -366,7 +455,7 @@ __device__ __forceinline__ void att_unit(const StepPersistArgs& a, int l, int u,
             acc[3] = fmaf(uu, kv[dd][3], fmaf(vq, pv[dd][0], acc[3]));
         }
         *(f32x4*)&partH[dg * CH + 4 * ql] = acc;
-        __syncthreads();
+        wg_barrier();
         const float scale = 1.f / sqrtf((float)DK);
         float s = -INFINITY;
         if (t < cn) {
@@ -377,15 +466,15 @@ __device__ __forceinline__ void att_unit(const StepPersistArgs& a, int l, int u,
         }
         float m = wave_max_p(s);
         if (lane == 0) wred[hf * 4 + wl] = m;
-        __syncthreads();
+        wg_barrier();
         m = fmaxf(fmaxf(wred[hf * 4], wred[hf * 4 + 1]), fmaxf(wred[hf * 4 + 2], wred[hf * 4 + 3]));
         const float m_new = fmaxf(m_run, m);
         const float e = t < cn ? expf(s - m_new) : 0.f;
         if (t < CH) scH[t] = e;
         float ls = wave_sum_p(e);
-        __syncthreads();
+        wg_barrier();
         if (lane == 0) wred[hf * 4 + wl] = ls;
-        __syncthreads();
+        wg_barrier();
         if (cn > 0) {                                 // an empty pass of this half leaves its running state alone (m_new may be -inf)
             const float corr = expf(m_run - m_new);
             l_run = l_run * corr + (wred[hf * 4] + wred[hf * 4 + 1] + wred[hf * 4 + 2] + wred[hf * 4 + 3]);
@@ -400,7 +489,7 @@ __device__ __forceinline__ void att_unit(const StepPersistArgs& a, int l, int u,
     }
     *(f32x4*)&cred[(hf * NG + jg) * DK + 4 * dq] = o_acc;
     if (t == 0) { ml[hf * 2] = m_run; ml[hf * 2 + 1] = l_run; }
-    __syncthreads();
+    wg_barrier();
     if (tid < 64) {                                   // wave 0 stores (and arrives afterwards)
         const float m0 = ml[0], l0 = ml[1], m1 = ml[2], l1 = ml[3];
         const float M = fmaxf(m0, m1);
@@ -423,7 +512,7 @@ __device__ __forceinline__ float* lds_bias(float* lds, const StepPersistArgs& a,
 __device__ __forceinline__ float* lds_work(float* lds, const StepPersistArgs& a) { return lds + 2 * a.wtile + 128; }
 
 // `par`: which LDS tile holds THIS unit's weights (requested while the previous GEMV unit computed); the next unit's go to the other one
-__device__ __forceinline__ void gemv_item(const StepPersistArgs& a, Item it, int par, Item nxt, unsigned seq, float* lds) {
+__device__ __forceinline__ void gemv_item(const StepPersistArgs& a, Item it, int par, Item nxt, unsigned seq, float* lds, Trace tr) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = lane >> 4, r16 = lane & 15;
     const int k = phase_kind(a, it.ph), l = it.ph / 5;
     const TileDesc t = tile_desc(a, it);
@@ -433,65 +522,80 @@ __device__ __forceinline__ void gemv_item(const StepPersistArgs& a, Item it, int
     float* gb = Xs + (size_t)(B + 1) * XS;            // gamma | beta (2 * d floats), then the partial weights of the OUT prologue
     float* red = gb + 2 * a.d + 8 * B * a.H;          // [kWaves][64][4]
     const int eb = r16 < B ? r16 : 0, n0 = t.tile * 16 + 4 * g;
-    // Epilogue operands.  An edge buffer may only be read once its phase is complete (a line read earlier could be served stale later), so
-    // the ADDRESS is selected, never the load: OUT's residual (the block's input = the sum of the previous w_2's k slices) is final before
-    // this unit's wait, FF2's (xm) behind it; every other kind reads the step's input vector (written by the previous launch) and ignores
-    // the value.
-    const int nn = n0 < a.d ? n0 : 0;
-    const bool res_in = k == 2;
-    gfp pre = FC_G(res_in ? layer_in(a, l) : a.xs) + (size_t)eb * a.d + nn;
-    const int pre_parts = res_in ? layer_in_parts(a, l) : 1;
-    f32x4 eold_in = *FC_G4(pre);
-    for (int q = 1; q < pre_parts; ++q) eold_in += *FC_G4(pre + (size_t)q * 16 * a.d);
     const int epos = a.pos[eb];
+    tr.id(it.ph, it.u);
+    tr.stamp(0);
     wait_phase(a, it.ph - 1, seq);
-    const f32x4 eold_xm = *FC_G4(FC_G(k == 4 ? edge_xm(a, l) : a.xs) + (size_t)eb * a.d + nn);
+    tr.stamp(1);
+    // Epilogue operands, requested together with the staging loads.  An edge buffer may only be read once its phase is complete (a line
+    // read earlier could be served stale later: a workgroup without an attention unit reaches OUT(l) straight from its own FF2(l - 1) tile,
+    // before the other tiles of x_l exist), so these loads sit BEHIND the wait, and the ADDRESS is selected, never the load: OUT adds the
+    // block's input (= the sum of the previous w_2's k slices), FF2 adds xm; every other kind reads the step's input vector and ignores it.
+    const int nn = n0 < a.d ? n0 : 0;
+    gfp rsrc = FC_G(k == 2 ? layer_in(a, l) : (k == 4 ? edge_xm(a, l) : a.xs)) + (size_t)eb * a.d + nn;
+    const int rparts = k == 2 ? layer_in_parts(a, l) : 1;
+    f32x4 eold = *FC_G4(rsrc);
+    for (int q = 1; q < rparts; ++q) eold += *FC_G4(rsrc + (size_t)q * 16 * a.d);
     const StepLayer& L = a.layers[k == 5 ? 0 : l];
     switch (k) {
-        case 0: stage_rows(layer_in(a, l), a.d, 0, layer_in_parts(a, l), K, B, XS, Xs, L.n1g, L.n1b, 1e-12f, gb); break;
-        case 2: stage_partials(edge_ap(a, l), B, a.H, a.DK, a.NS, XS, Xs, gb + 2 * a.d); break;
-        case 3: stage_rows(edge_xm(a, l), a.d, 0, 1, K, B, XS, Xs, L.n2g, L.n2b, 1e-12f, gb); break;
-        case 4: stage_rows(edge_hb(a, l), a.ff, t.ks * K, 1, K, B, XS, Xs, nullptr, nullptr, 0.f, gb); break;
-        default: stage_rows(layer_in(a, a.NL), a.d, 0, layer_in_parts(a, a.NL), K, B, XS, Xs, a.ag, a.ab, 1e-12f, gb); break;
+        case 0: stage_rows<4>(layer_in(a, l), a.d, 0, layer_in_parts(a, l), K, B, XS, Xs, L.n1g, L.n1b, 1e-12f, gb, tr); break;
+        case 2: stage_partials(edge_ap(a, l), B, a.H, a.DK, a.NS, XS, Xs, gb + 2 * a.d, tr); break;
+        case 3: stage_rows<1>(edge_xm(a, l), a.d, 0, 1, K, B, XS, Xs, L.n2g, L.n2b, 1e-12f, gb, tr); break;
+        case 4: stage_rows<1>(edge_hb(a, l), a.ff, t.ks * K, 1, K, B, XS, Xs, nullptr, nullptr, 0.f, gb, tr); break;
+        default: stage_rows<4>(layer_in(a, a.NL), a.d, 0, layer_in_parts(a, a.NL), K, B, XS, Xs, a.ag, a.ab, 1e-12f, gb, tr); break;
     }
-    // the next GEMV unit's tile streams into the other LDS tile under this unit's MFMAs, its hand-off and the next wait
-    request_tile(tn, lds_tile(lds, a, par ^ 1), lds_bias(lds, a, par ^ 1), wv, lane);
+    tr.stamp(2);
     const f32x4 acc = mfma_tile(lds_tile(lds, a, par), t, Xs, XS, B, wv, lane);
     *(f32x4*)(red + (wv * 64 + lane) * 4) = acc;
-    __syncthreads();
+    // The next GEMV unit's tile streams into the other LDS tile under this unit's hand-off and the next wait.  Requested BEHIND this
+    // wave's last LDS access of the unit: hipcc drains vmcnt before the first LDS access that follows an LDS DMA (it cannot tell the
+    // tiles apart) -- ahead of the MFMA loop that put the tile's HBM round trip (1.1 us) into every unit.
+    request_tile(tn, lds_tile(lds, a, par ^ 1), lds_bias(lds, a, par ^ 1), wv, lane);
+    wg_barrier();
+    tr.stamp(3);
     if (wv == 0) {
         f32x4 s = *(const f32x4*)(red + lane * 4);
 #pragma unroll
         for (int x = 1; x < kWaves; ++x) s += *(const f32x4*)(red + (x * 64 + lane) * 4);
         const f32x4 pb = *(const f32x4*)(lds_bias(lds, a, par) + 4 * g);
         const int b = r16;
+        if (t.ks == 0) s += pb;                       // bias (and FF2's residual) with the first k slice only
         if (b < B) {
+            if (k == 0) {
+                const int d = a.d;                    // a row tile lies inside q, k or v (d % 16 == 0)
+                if (n0 < d) store_wt4(edge_q(a, l) + (size_t)b * d + n0, s);
+                else if (n0 < 2 * d) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + r;
-                if (n >= t.N) continue;
-                float v = s[r];
-                if (t.ks == 0) v += pb[r];            // bias (and FF2's residual) with the first k slice only
-                if (k == 0) {
-                    const int d = a.d;
-                    if (n < d) store_wt(edge_q(a, l) + (size_t)b * d + n, v);
-                    else if (n < 2 * d) store_wt(a.kc + (size_t)l * B * d * a.Tcap + ((size_t)b * d + (n - d)) * a.Tcap + epos, v);
-                    else store_wt(a.vc + (size_t)l * B * d * a.Tcap + ((size_t)b * a.Tcap + epos) * d + (n - 2 * d), v);
-                } else if (k == 2) store_wt(edge_xm(a, l) + (size_t)b * a.d + n, eold_in[r] + v);
-                else if (k == 3) store_wt(edge_hb(a, l) + (size_t)b * a.ff + n, act_p(v, a.act));
-                else if (k == 4) store_wt(edge_xo(a, l) + ((size_t)t.ks * 16 + b) * a.d + n, t.ks == 0 ? eold_xm[r] + v : v);
-                else store_wt(a.logits + (size_t)b * a.V + n, v);
+                    for (int r = 0; r < 4; ++r) store_wt(a.kc + (size_t)l * B * d * a.Tcap + ((size_t)b * d + (n0 + r - d)) * a.Tcap + epos, s[r]);
+                } else store_wt4(a.vc + (size_t)l * B * d * a.Tcap + ((size_t)b * a.Tcap + epos) * d + (n0 - 2 * d), s);
+            } else if (k == 2) store_wt4(edge_xm(a, l) + (size_t)b * a.d + n0, eold + s);
+            else if (k == 3) {
+                f32x4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = act_p(s[r], a.act);
+                store_wt4(edge_hb(a, l) + (size_t)b * a.ff + n0, hv);
+            } else if (k == 4) store_wt4(edge_xo(a, l) + ((size_t)t.ks * 16 + b) * a.d + n0, t.ks == 0 ? eold + s : s);
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + r < t.N) a.logits[(size_t)b * a.V + n0 + r] = s[r];       // read by the next kernel (the sampler)
             }
         }
         arrive(a, it.ph, it.u);
+        tr.stamp(4);
     }
 }
 
-__device__ __forceinline__ void att_item(const StepPersistArgs& a, Item it, unsigned seq, float* work) {
+__device__ __forceinline__ void att_item(const StepPersistArgs& a, Item it, unsigned seq, float* work, Trace tr) {
+    tr.id(it.ph, it.u);
+    tr.stamp(0);
     wait_phase(a, it.ph - 1, seq);
+    tr.stamp(1);
     if (a.DK == 64) att_unit<64>(a, it.ph / 5, it.u, work);
     else att_unit<32>(a, it.ph / 5, it.u, work);
+    tr.stamp(3);
     if (threadIdx.x < 64) arrive(a, it.ph, it.u);
+    tr.stamp(4);
 }
 
 __device__ __forceinline__ bool same_item(Item x, Item y) { return x.ph == y.ph && x.u == y.u; }
@@ -511,14 +615,15 @@ __global__ __launch_bounds__(kThreads, 2) void step_persist_kernel(StepPersistAr
     next_item(a, wg, it);                 // first unit of this workgroup (phase order)
     if (it.ph < 0) return;
     Item g = gemv_from(a, wg, it);
-    int par = 0;
+    int par = 0, nth = 0;
     request_tile(tile_desc(a, g), lds_tile(lds, a, 0), lds_bias(lds, a, 0), wv, lane);
+    auto slot = [&]() { Trace t{a.trace ? a.trace + ((size_t)wg * 64 + (nth < 63 ? nth : 63)) * 8 : nullptr}; ++nth; return t; };
     for (;;) {
-        while (it.ph >= 0 && !same_item(it, g)) { att_item(a, it, seq, lds_work(lds, a)); next_item(a, wg, it); }     // attention units ahead of g
+        while (it.ph >= 0 && !same_item(it, g)) { att_item(a, it, seq, lds_work(lds, a), slot()); next_item(a, wg, it); }     // attention units ahead of g
         if (g.ph < 0) break;
         next_item(a, wg, it);
         const Item g2 = gemv_from(a, wg, it);
-        gemv_item(a, g, par, g2, seq, lds);
+        gemv_item(a, g, par, g2, seq, lds, slot());
         g = g2;
         par ^= 1;
     }
