@@ -393,11 +393,25 @@ float* run_stack_full(fc_laura* e, Ctx& cx, const Stack& S, const float* in, int
     return xn;
 }
 
+struct LenPack { int v[64]; };
+__global__ void set_lens_kernel(LenPack p, int* dst, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = p.v[threadIdx.x];
+}
+
+// Lengths travel BY VALUE in kernel arguments (64 per launch): the caller's arrays are temporaries of the binding, and an asynchronous
+// copy from pageable host memory is allowed to read them after the call has returned.
 int* upload_lens(Ctx& cx, const int32_t* host, int B, int fill = 0) {
     int* d = cx.alloc<int>(B);
     if (!cx.live()) return d;
-    if (host) cx.check(hipMemcpyAsync(d, host, (size_t)B * sizeof(int), hipMemcpyHostToDevice, cx.st), "lengths upload");
-    else cx.check(lk::launch_fill_i32(d, fill, B, cx.st), "fill");
+    if (host) {
+        for (int b0 = 0; b0 < B; b0 += 64) {
+            LenPack p;
+            const int n = B - b0 < 64 ? B - b0 : 64;
+            for (int i = 0; i < 64; ++i) p.v[i] = i < n ? host[b0 + i] : 0;
+            hipLaunchKernelGGL(set_lens_kernel, dim3(1), dim3(64), 0, cx.st, p, d + b0, n);
+        }
+        cx.check(hipGetLastError(), "lengths upload");
+    } else cx.check(lk::launch_fill_i32(d, fill, B, cx.st), "fill");
     return d;
 }
 
@@ -662,13 +676,19 @@ int check_ready(fc_laura* e) {
     return 0;
 }
 
-int check_stack(const fc_laura_stack& s, const char* name) {
+int check_stack(const fc_laura_stack& s, const char* name, bool step = false) {
     if (s.idim < 1 || s.d_model < 64 || s.heads < 1 || s.ff < 16 || s.layers < 1) return fail(std::string(name) + ": bad sizes");
     if (s.d_model % s.heads) return fail(std::string(name) + ": d_model must be a multiple of heads");
     const int dk = s.d_model / s.heads;
     if (dk != 32 && dk != 64) return fail(std::string(name) + ": head dimension must be 32 or 64");
     if (s.d_model % 16 || s.ff % 16) return fail(std::string(name) + ": d_model and ff must be multiples of 16");
     if (s.act != 1 && s.act != 2) return fail(std::string(name) + ": activation must be 1 (relu) or 2 (swish)");
+    // limits of the kernels, refused HERE with a reason instead of a hipErrorInvalidValue at the first call: the LayerNorm kernels
+    // and the sampler's fused input layer hold a row of <= 1024 channels; the step form's GEMV stages (16 + 1) x (K + 4) floats of input
+    // plus 16 KiB of partial tiles in the 160 KiB of LDS, K = ff for w_2
+    if (s.d_model > 1024) return fail(std::string(name) + ": d_model above 1024 is not supported (LayerNorm / sampler kernels)");
+    if (step && ((size_t)17 * ((size_t)s.ff + 4) * 4 + 16 * 1024 > 160 * 1024))
+        return fail(std::string(name) + ": feed-forward width too large for the decoding step's GEMV (LDS): ff <= 2112");
     return 0;
 }
 
@@ -683,7 +703,8 @@ int fc_laura_create(const fc_laura_arch* arch, int device, fc_laura** out) {
     if (arch->predict_nq < 1 || arch->predict_nq > 8 || arch->predict_nq > arch->num_quantizers) return fail("bad predict_nq");
     if (arch->codebook_dim % 16 || arch->codebook_dim < 16) return fail("codebook_dim must be a multiple of 16");
     if (arch->max_positions < 16 || arch->max_positions > 2048) return fail("max_positions must be in [16, 2048]");
-    if (check_stack(arch->text_encoder, "text_encoder") || check_stack(arch->codec_lm, "codec_lm") ||
+    if (arch->max_positions % 4) return fail("max_positions must be a multiple of 4 (time axes are padded to whole quads)");
+    if (check_stack(arch->text_encoder, "text_encoder") || check_stack(arch->codec_lm, "codec_lm", true) ||
         check_stack(arch->codec_encoder, "codec_encoder")) return 1;
     if (arch->codec_lm.idim != arch->codebook_dim || arch->codec_encoder.idim != arch->codebook_dim)
         return fail("codec_lm / codec_encoder input width must equal codebook_dim");

@@ -1022,6 +1022,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             __syncthreads();
             const float total = wred[0] + wred[1] + wred[2] + wred[3];
             int ncand = G;
+            bool selected = false;                   // top-k candidates already in val[] / idx[] order
             if (a.mode == 2 && a.ki <= 64) {
                 // top-k with a small k (the recipe samples with --sampling 25): radix-select the k-th largest logit (4 passes over
                 // 8-bit digits of the order-preserving integer image of the float), collect everything >= it, order those few by
@@ -1082,22 +1083,29 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                     }
                 }
                 __syncthreads();
-                const int nc = ccount < 256 ? ccount : 256;
-                float myv = 0.f;
-                int myi = 0, rank = 0;
-                if (tid < nc) {
-                    myv = cval[tid]; myi = cidx[tid];
-                    for (int c = 0; c < nc; ++c) {
-                        const float ov = cval[c];
-                        const int oi = cidx[c];
-                        rank += (ov > myv || (ov == myv && oi < myi)) ? 1 : 0;
+                // more than 256 logits at or above the k-th key (hundreds of ties at the threshold: saturated or constant logits): which of
+                // them the 256 slots hold depends on the order of the atomics -- take the full sort below instead, whose tie-break
+                // (probability descending, index ascending) is the documented one.  ccount is uniform here.
+                if (ccount <= 256) {
+                    const int nc = ccount;
+                    float myv = 0.f;
+                    int myi = 0, rank = 0;
+                    if (tid < nc) {
+                        myv = cval[tid]; myi = cidx[tid];
+                        for (int c = 0; c < nc; ++c) {
+                            const float ov = cval[c];
+                            const int oi = cidx[c];
+                            rank += (ov > myv || (ov == myv && oi < myi)) ? 1 : 0;
+                        }
                     }
+                    __syncthreads();
+                    if (tid < nc) { val[rank] = myv; idx[rank] = myi; }
+                    __syncthreads();
+                    ncand = kk < nc ? kk : nc;
+                    selected = true;
                 }
-                __syncthreads();
-                if (tid < nc) { val[rank] = myv; idx[rank] = myi; }
-                __syncthreads();
-                ncand = kk < nc ? kk : nc;
-            } else if (a.mode >= 2) {
+            }
+            if (!selected && a.mode >= 2) {
                 // descending by probability, ties by index (topk / a stable descending sort): bitonic sort of 2048 pairs
                 for (int kk = 2; kk <= FC_SAMPLE_MAXV; kk <<= 1)
                     for (int j = kk >> 1; j > 0; j >>= 1) {

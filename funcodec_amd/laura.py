@@ -48,6 +48,8 @@ class LauraEngine:
             raise EngineError(f"funcodec_amd runs on MI355X (gfx950) only; device={device!r} has no implementation "
                               "(there is deliberately no CPU fallback)")
         self.device = torch.device("cuda", dev.index if dev.index is not None else 0)
+        if int(max_positions) % 4 or not 16 <= int(max_positions) <= 2048:
+            raise EngineError(f"max_positions must be a multiple of 4 in [16, 2048], got {max_positions}")
         a = _lib.FcLauraArch()
         a.abi_version = _lib.FC_ABI_VERSION
         a.input_size, a.vocab_size = spec.input_size, spec.vocab_size

@@ -146,6 +146,10 @@ def laura_spec_from_config(cfg: Dict[str, Any]) -> LauraSpec:
             raise _unsupported(f"{n}: head dimension", dk, "the attention kernels are built for 32 and 64")
         if s.d_model % 64 or s.ff % 64 or s.idim % 8:
             raise _unsupported(f"{n}: sizes", (s.idim, s.d_model, s.ff), "d_model and linear_units must be multiples of 64, the input size of 8")
+        if s.d_model > 1024:
+            raise _unsupported(f"{n}: d_model", s.d_model, "the LayerNorm kernels and the sampler's input layer hold rows of at most 1024 channels")
+    if lm_spec.ff > 2112:
+        raise _unsupported("codec_lm: unit", lm_spec.ff, "the decoding step's GEMV stages 17 rows of ff floats in LDS: at most 2112")
     return LauraSpec(input_size=input_size, vocab_size=vocab, codebook_size=K, codebook_dim=D, num_quantizers=nqs,
                      predict_nq=predict_nq, pos_emb_type=pos_emb_type, bidirectional_inputs=bool(lm.get("bidirectional_inputs", False)),
                      text_encoder=te, codec_lm=lm_spec, codec_encoder=ce, token_list=list(token_list) if token_list else None)

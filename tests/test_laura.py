@@ -112,7 +112,9 @@ def test_config_validation_refuses_what_the_engine_cannot_reproduce():
     for path, val in [(("text_encoder_conf", "use_cnn_module"), True), (("text_encoder_conf", "macaron_style"), True),
                       (("codec_encoder_conf", "rel_pos_type"), "legacy"), (("model_conf", "codec_lm_conf", "pe_type"), "split"),
                       (("model_conf", "codec_lm_conf", "pos_enc"), "abs_pos"), (("model_conf", "codec_conf", "codebook_size"), 512),
-                      (("text_encoder_conf", "input_layer"), "conv2d"), (("model_conf", "pos_emb_type"), "other")]:
+                      (("text_encoder_conf", "input_layer"), "conv2d"), (("model_conf", "pos_emb_type"), "other"),
+                      # limits of the kernels, refused with a reason at config time instead of a hipErrorInvalidValue at the first call
+                      (("text_encoder_conf", "output_size"), 2048), (("model_conf", "codec_lm_conf", "unit"), 4096)]:
         bad = laura_recipe_config("laura")
         d = bad
         for k in path[:-1]:
@@ -498,6 +500,33 @@ def test_persistent_step_equals_the_kernel_chain(cfg_name, B, steps):
     assert err < 2e-5, err
     assert gp[1] == gc[1] and torch.equal(gp[0], gc[0])                       # greedy generations identical
     assert all(0 <= v - c <= steps for v, c in zip(kp[1], [0] * B)) and int(kp[0].max()) < spec.codebook_size   # top-k sampling may draw <eos>
+
+
+@pytest.mark.gpu
+def test_top_k_with_hundreds_of_tied_logits_is_deterministic():
+    """A constant output layer makes all 1025 logits of a group equal: more than the 256 slots of the radix-select path tie at the k-th
+    key.  The sampler must then order the candidates by (probability descending, index ascending) -- i.e. the top-k set is ids 0 .. k-1 --
+    instead of whatever 256 entries its atomics happened to collect, and a generation stays a function of its seed."""
+    from funcodec_amd.laura import LauraGenMI355X
+    cfg = laura_recipe_config("tinylaura")
+    spec = laura_spec_from_config(cfg)
+    sd = make_laura_state_dict(cfg, 5)
+    sd["codec_lm.decoder.weight"] = np.zeros_like(sd["codec_lm.decoder.weight"])
+    sd["codec_lm.decoder.bias"] = np.zeros_like(sd["codec_lm.decoder.bias"])
+    m = LauraGenMI355X(spec, "cuda:0", max_positions=256)
+    m.load_state_dict(sd)
+    lens = [9, 7, 11]
+    text = synthetic_text(cfg, 3, lens, 2)
+    with torch.no_grad():
+        outs, _ = m.encode(torch.from_numpy(text), torch.tensor(lens))
+        for persist in (True, False):
+            m.engine.set_persistent_step(persist)
+            a = m.engine.decode_codec(outs, lens, 20, sampling=5, seed=77)
+            b = m.engine.decode_codec(outs, lens, 20, sampling=5, seed=77)
+            assert torch.equal(a[0], b[0]) and a[1] == b[1] == [20, 20, 20]
+            assert int(a[0].max()) < 5 and int(a[0].min()) >= 0, a[0].unique()
+            assert len(a[0].unique()) > 1                     # it does sample among the five
+        m.engine.set_persistent_step(True)
 
 
 @pytest.mark.gpu

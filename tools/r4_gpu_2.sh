@@ -5,8 +5,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd $R
 export FC_WAIVER_JSON=$OUT/tie_waivers_laura.json
-true
-true
+timeout 600 python -m pytest tests/test_laura.py -m gpu -q -x > $OUT/laura_pytest.log 2>&1; tail -4 $OUT/laura_pytest.log
 FC_LAURA_TRACE=$OUT/laura_trace.bin timeout 300 python bench.py --workload laura --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_laura_persist.json 2> $OUT/bench_laura_persist.err
 python tools/laura_trace.py $OUT/laura_trace.bin 2.1
 python - <<'PY'
