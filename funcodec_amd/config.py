@@ -140,8 +140,9 @@ def _check_seanet_conf(conf: Dict[str, Any], which: str) -> Dict[str, Any]:
 
 
 def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
-    """``model: freq_codec`` (FreqCodec, codec_freq.py:123-210) with the 2-D SEANet nets; only the recipe's
-    ``codec_domain: [mag_phase, mag_phase]`` is built (GroupNorm or weight_norm nets, the latter optionally causal; grouped convs)."""
+    """``model: freq_codec`` (FreqCodec, codec_freq.py:123-210) with the 2-D SEANet nets; the recipes'
+    ``codec_domain: [mag_phase, mag_phase]`` and ``[mag_angle, mag_angle]`` are built (GroupNorm or weight_norm nets, the latter optionally
+    causal; grouped convs)."""
     if cfg.get("encoder") != "encodec_seanet_encoder_2d" or cfg.get("decoder") != "encodec_seanet_decoder_2d":
         raise _unsupported("encoder/decoder", (cfg.get("encoder"), cfg.get("decoder")), "freq_codec needs the 2-D SEANet nets")
     if cfg.get("quantizer", "costume_quantizer") != "costume_quantizer":
@@ -176,12 +177,17 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     if dec.get("final_activation_params", None) not in (None, {}):
         raise _unsupported("decoder_conf.final_activation_params", dec.get("final_activation_params"))
     domain = list(m.get("codec_domain", ["time", "time"]))
-    if domain != ["mag_phase", "mag_phase"]:
-        # mag_angle was built and measured in round 2, then removed: torch.angle of the first STFT frame (reflect padding makes it
-        # exactly symmetric: every bin's imaginary part is rounding noise) and of the DC / Nyquist rows flips between 0 / +pi / -pi
-        # with the FFT implementation, so no golden of the reference can be reproduced by ANY other float implementation
-        raise _unsupported("model_conf.codec_domain", m.get("codec_domain"), "only [mag_phase, mag_phase] is built")
-    n_in = 3
+    if domain not in (["mag_phase", "mag_phase"], ["mag_angle", "mag_angle"]):
+        # `stft`: the reference's own decode branch keeps a channel axis the [:, :, :T] trim cannot take (codec_freq.py:413-415), no recipe
+        # uses it; `mag` has no decode branch at all; mixed pairs have no recipe either
+        raise _unsupported("model_conf.codec_domain", m.get("codec_domain"), "[mag_phase, mag_phase] and [mag_angle, mag_angle] are built")
+    # mag_angle (conf/freqcodec_mag_angle_16k_n32_600k_step.yaml): the encoder sees torch.angle of the STFT.  Where a bin's imaginary part
+    # is rounding noise around a negative real part (the first STFT frame, whose reflect padding makes it symmetric; DC / Nyquist rows) the
+    # angle is +pi or -pi by the FFT's rounding, so the ENCODER INPUT of this domain is reproducible only modulo 2 pi -- by any second STFT,
+    # the reference's own included (tests/golden/*ang*_variants: its fp64 STFT moves its own encoder output by the fixture's
+    # `stft_self_noise`).  The engine runs the recipe; what its parity tests pin is said in tests/test_gpu_parity.py (features modulo 2 pi,
+    # the whole path from the reference's features, the decode path from the reference's codes).
+    n_in = 3 if domain[0] == "mag_phase" else 2
     if m.get("bypass_quantizer", False):
         raise _unsupported("model_conf.bypass_quantizer", True)
     if cfg.get("input_size", 1) != n_in or dec.get("channels", 1) != n_in:
@@ -418,7 +424,7 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     name = name[:-2] if wn else name
     seg = name.endswith("seg")                        # FreqCodec._encode / _decode in segmented mode: 0.15 s frames, 10 % overlap
     name = name[:-3] if seg else name
-    angle = name.endswith("ang")                      # freqcodec_mag_angle_16k_n32_600k_step.yaml (refused by arch_from_config)
+    angle = name.endswith("ang")                      # freqcodec_mag_angle_16k_n32_600k_step.yaml: codec_domain [mag_angle, mag_angle], 2 channels
     name = name[:-3] if angle else name
     gr = -1
     if "gr" in name:                                  # e.g. "freqmpgr1", "tinyfreqgr2": conv_group_ratio = tr_conv_group_ratio = N

@@ -1390,6 +1390,10 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
 
 int stft_frames(const fc_engine* e, int T) { return 1 + T / e->arch.stft_hop; }
 
+// fc_debug_freq_features: one-shot capture (mode 1) or override (mode 2) of the STFT-domain feature tensor of the next encode
+struct FeatHook { float* buf = nullptr; size_t cap = 0; int mode = 0; };
+thread_local FeatHook g_feat_hook;
+
 // FreqCodec._encode_frame (codec_freq.py:330-392, mag_phase) + SEANetEncoder2d.forward: wav -> last conv (raw + affine) at Tf frames
 Act run_encoder_2d(fc_engine* e, Ctx& cx, const float* wav, int T, const float* scale) {
     const fc_arch& a = e->arch;
@@ -1408,7 +1412,14 @@ Act run_encoder_2d(fc_engine* e, Ctx& cx, const float* wav, int T, const float* 
     feats.C = a.input_channels; feats.F = F; feats.T = Tp; feats.halo = e->halo2;
     feats.buf = cx.alloc<float>((size_t)B * (F + 2 * e->halo2) * feats.C * Tp);
     if (!cx.dry && !cx.err) {
-        hipError_t er = fc::launch_stft_feats(spec.raw, B, F, Tp, (long long)2 * F * Tp, e->halo2, feats.buf, cx.st);
+        hipError_t er = fc::launch_stft_feats(spec.raw, B, F, Tp, (long long)2 * F * Tp, e->halo2, feats.C, feats.buf, cx.st);
+        // test hooks (fc_debug_freq_features): hand the features out / take them from the caller, in the reference's [B][C][F][Tp]
+        if (er == hipSuccess && g_feat_hook.buf && g_feat_hook.mode != 0) {
+            const size_t need = (size_t)B * feats.C * F * Tp * sizeof(float);
+            if (need > g_feat_hook.cap) { cx.err = 1; g_err = "fc_debug_freq_features: buffer too small"; }
+            else er = fc::launch_feats_relayout(feats.buf, g_feat_hook.buf, B, feats.C, F, Tp, e->halo2, g_feat_hook.mode == 1, cx.st);
+            g_feat_hook.mode = 0;            // one shot
+        }
         if (er == hipSuccess) er = fc::launch_halo_rows(feats.buf, B, F, e->halo2, feats.C, Tp, 0, cx.st);
         if (er != hipSuccess) { cx.err = 1; g_err = std::string("stft feature launch failed: ") + hipGetErrorString(er); }
     }
@@ -1459,7 +1470,7 @@ void run_decoder_2d(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf, const flo
     if (!cx.dry && !cx.err) {
         if (last.F != F) { cx.err = 1; g_err = "internal: decoder frequency rows != n_fft / 2 + 1"; }
         else if (out_len > hop * (Tp2 - 1)) { cx.err = 1; g_err = "out_len exceeds the inverse STFT's length stft_hop * (frames - 1)"; }
-        else if (fc::launch_spec_from_dec(last.buf, last.aff, B, F, Tp2, 0, spec, cx.st) != hipSuccess) { cx.err = 1; g_err = "spectrum launch failed"; }
+        else if (fc::launch_spec_from_dec(last.buf, last.aff, B, F, Tp2, 0, a.input_channels, spec, cx.st) != hipSuccess) { cx.err = 1; g_err = "spectrum launch failed"; }
     }
     fc::Src ss; ss.ptr = spec; ss.used = 1;
     Act yp = run_conv(e, cx, e->istft, ss, fc::Src(), 0, Tp2);                      // [B][hop][Mp2]
@@ -1628,7 +1639,8 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     if (arch->model_type != 0 && arch->model_type != 1) return fail("fc_arch.model_type must be 0 (encodec) or 1 (freq_codec, mag_phase)");
     if (arch->model_type == 1) {
         if (arch->norm_type != 0 && arch->norm_type != 1) return fail("freq_codec: norm must be time_group_norm or weight_norm");
-        if (arch->input_channels != 3) return fail("freq_codec: input_channels must be 3 (log-magnitude, phase re, phase im)");
+        if (arch->input_channels != 3 && arch->input_channels != 2)
+            return fail("freq_codec: input_channels must be 3 (codec_domain mag_phase: log-magnitude, phase re, phase im) or 2 (mag_angle: log-magnitude, angle)");
         if (arch->n_fft < 64 || (arch->n_fft & (arch->n_fft - 1)) || arch->stft_hop < 1 || arch->stft_hop > arch->n_fft)
             return fail("freq_codec: n_fft must be a power of two >= 64 and 1 <= stft_hop <= n_fft");
         if (arch->stft_hop % 2) return fail("freq_codec: stft_hop must be even");
@@ -2055,6 +2067,12 @@ int fc_write_wav_pcm16(const char* path, const float* wav, int n, int sample_rat
               (n == 0 || fwrite(pcm.data(), 2, (size_t)n, f) == (size_t)n);
     ok = (fclose(f) == 0) && ok;
     return ok ? 0 : fail(std::string("short write to ") + path);
+}
+
+int fc_debug_freq_features(void* dev_buf, size_t cap_bytes, int mode) {
+    if (mode < 0 || mode > 2 || (mode != 0 && !dev_buf)) return fail("fc_debug_freq_features: mode 0 (off), 1 (capture) or 2 (override) with a device buffer");
+    g_feat_hook.buf = (float*)dev_buf; g_feat_hook.cap = cap_bytes; g_feat_hook.mode = mode;
+    return 0;
 }
 
 int fc_debug_timeline(unsigned long long* dst) {

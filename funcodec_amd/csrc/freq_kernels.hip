@@ -36,26 +36,49 @@ hipError_t launch_polyphase_in(const float* wav, const float* div, int B, int T,
     return hipGetLastError();
 }
 
-// STFT rows (re: 0..F-1, im: F..2F-1) [B][2F][Tp] -> features [B][halo + f][3][Tp] = (log(max(|X|, 1e-6)), X / max(|X|, 1e-6))
-// (codec_freq.py:371-379)
+// STFT rows (re: 0..F-1, im: F..2F-1) [B][2F][Tp] -> features, frequency-major [B][halo + f][C][Tp]:
+//   C = 3 (codec_domain mag_phase, codec_freq.py:371-379): log(max(|X|, 1e-6)), X / max(|X|, 1e-6)
+//   C = 2 (codec_domain mag_angle, codec_freq.py:356-364): log(max(|X|, 1e-6)), torch.angle(X) = atan2(im, re)
+template <int C>
 __global__ __launch_bounds__(256) void stft_feats_kernel(const float* __restrict__ spec, int F, int Tp, long long spec_sB, int halo,
                                                          float* __restrict__ feats) {
     const int b = blockIdx.z, f = blockIdx.y;
     const float* re = spec + (size_t)b * spec_sB + (size_t)f * Tp;
     const float* im = re + (size_t)F * Tp;
-    float* o = feats + (((size_t)b * (F + 2 * halo) + halo + f) * 3) * Tp;
+    float* o = feats + (((size_t)b * (F + 2 * halo) + halo + f) * C) * Tp;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < Tp; t += gridDim.x * 256) {
         const float a = re[t], c = im[t];
         const float mag = sqrtf(a * a + c * c);
         const float cl = fmaxf(mag, 1e-6f);
         o[t] = logf(cl);
-        o[Tp + t] = a / cl;
-        o[2 * (size_t)Tp + t] = c / cl;
+        if (C == 3) {
+            o[Tp + t] = a / cl;
+            o[2 * (size_t)Tp + t] = c / cl;
+        } else {
+            o[Tp + t] = atan2f(c, a);
+        }
     }
 }
 
-hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, float* feats, hipStream_t st) {
-    hipLaunchKernelGGL(stft_feats_kernel, dim3(cdiv(Tp, 256), F, B), dim3(256), 0, st, spec, F, Tp, spec_sB, halo, feats);
+hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, int C, float* feats, hipStream_t st) {
+    if (C == 3) hipLaunchKernelGGL(stft_feats_kernel<3>, dim3(cdiv(Tp, 256), F, B), dim3(256), 0, st, spec, F, Tp, spec_sB, halo, feats);
+    else if (C == 2) hipLaunchKernelGGL(stft_feats_kernel<2>, dim3(cdiv(Tp, 256), F, B), dim3(256), 0, st, spec, F, Tp, spec_sB, halo, feats);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// test hooks (fc_debug_freq_features): the feature tensor in the reference's layout [B][C][F][Tp] <-> the engine's [B][halo + f][C][Tp]
+__global__ __launch_bounds__(256) void feats_relayout_kernel(float* __restrict__ eng, float* __restrict__ ref, int C, int F, int Tp, int halo, int to_ref) {
+    const int b = blockIdx.z, fc = blockIdx.y, f = fc / C, c = fc - f * C;
+    float* e = eng + (((size_t)b * (F + 2 * halo) + halo + f) * C + c) * Tp;
+    float* r = ref + (((size_t)b * C + c) * F + f) * Tp;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < Tp; t += gridDim.x * 256) {
+        if (to_ref) r[t] = e[t];
+        else e[t] = r[t];
+    }
+}
+hipError_t launch_feats_relayout(float* eng, float* ref, int B, int C, int F, int Tp, int halo, int to_ref, hipStream_t st) {
+    hipLaunchKernelGGL(feats_relayout_kernel, dim3(cdiv(Tp, 256), F * C, B), dim3(256), 0, st, eng, ref, C, F, Tp, halo, to_ref);
     return hipGetLastError();
 }
 
@@ -109,26 +132,39 @@ hipError_t launch_combine2d(const float* s0, const float* aff0, int h0, const fl
     return hipGetLastError();
 }
 
-// decoder output (raw, frequency-major [B][F + 2*halo][3][Tp], GroupNorm(1, 3) pending as aff[b][3]) -> spectrum rows for the
-// inverse-STFT GEMM [B][2F][Tp]: softplus(mag) * (re, im)  (codec_freq.py:419-428; F.softplus: log1p(exp(x)), x for x > 20)
+// decoder output (raw, frequency-major [B][F + 2*halo][C][Tp], GroupNorm(1, C) pending as aff[b][C]) -> spectrum rows for the
+// inverse-STFT GEMM [B][2F][Tp]  (F.softplus: log1p(exp(x)), x for x > 20):
+//   C = 3 (mag_phase, codec_freq.py:419-428): softplus(mag) * (re, im)
+//   C = 2 (mag_angle, codec_freq.py:426-434): mag = softplus(o0), angle = sin(o1) * pi, spectrum = (cos(angle) mag, sin(angle) mag)
+template <int C>
 __global__ __launch_bounds__(256) void spec_from_dec_kernel(const float* __restrict__ dec, const float* __restrict__ aff, int F, int Tp,
                                                             int halo, float* __restrict__ spec) {
     const int b = blockIdx.z, f = blockIdx.y;
-    const float2* A = (const float2*)aff + (size_t)b * 3;
-    const float2 Am = aff ? A[0] : make_float2(1.f, 0.f), Ar = aff ? A[1] : make_float2(1.f, 0.f), Ai = aff ? A[2] : make_float2(1.f, 0.f);
-    const float* r = dec + (((size_t)b * (F + 2 * halo) + halo + f) * 3) * Tp;
+    const float2* A = (const float2*)aff + (size_t)b * C;
+    const float2 one = make_float2(1.f, 0.f);
+    const float2 Am = aff ? A[0] : one, Ar = aff ? A[1] : one, Ai = (aff && C == 3) ? A[C - 1] : one;
+    const float* r = dec + (((size_t)b * (F + 2 * halo) + halo + f) * C) * Tp;
     float* ore = spec + ((size_t)b * 2 * F + f) * Tp;
     float* oim = ore + (size_t)F * Tp;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < Tp; t += gridDim.x * 256) {
         const float m = fmaf(r[t], Am.x, Am.y);
         const float sp = m > 20.f ? m : log1pf(expf(m));
-        ore[t] = sp * fmaf(r[Tp + t], Ar.x, Ar.y);
-        oim[t] = sp * fmaf(r[2 * (size_t)Tp + t], Ai.x, Ai.y);
+        const float o1 = fmaf(r[Tp + t], Ar.x, Ar.y);
+        if (C == 3) {
+            ore[t] = sp * o1;
+            oim[t] = sp * fmaf(r[2 * (size_t)Tp + t], Ai.x, Ai.y);
+        } else {
+            const float ang = sinf(o1) * 3.14159265358979323846f;      // torch.pi rounded to fp32 by the multiplication's operand
+            ore[t] = cosf(ang) * sp;
+            oim[t] = sinf(ang) * sp;
+        }
     }
 }
 
-hipError_t launch_spec_from_dec(const float* dec, const float* aff, int B, int F, int Tp, int halo, float* spec, hipStream_t st) {
-    hipLaunchKernelGGL(spec_from_dec_kernel, dim3(cdiv(Tp, 256), F, B), dim3(256), 0, st, dec, aff, F, Tp, halo, spec);
+hipError_t launch_spec_from_dec(const float* dec, const float* aff, int B, int F, int Tp, int halo, int C, float* spec, hipStream_t st) {
+    if (C == 3) hipLaunchKernelGGL(spec_from_dec_kernel<3>, dim3(cdiv(Tp, 256), F, B), dim3(256), 0, st, dec, aff, F, Tp, halo, spec);
+    else if (C == 2) hipLaunchKernelGGL(spec_from_dec_kernel<2>, dim3(cdiv(Tp, 256), F, B), dim3(256), 0, st, dec, aff, F, Tp, halo, spec);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -92,11 +92,12 @@ int gconvtr2d_nblk(int Tin, int tr, int Fin, int fr);
 hipError_t launch_gconvtr2d(const float* z, const float* w, const float* bias, float* out, double* partials, int B, int C, int cout, int Fin,
                             int Tin, int fr, int tr, int f_l, int Fout, int trimL, int Tout, long long out_sB, hipStream_t st);
 hipError_t launch_polyphase_in(const float* wav, const float* div, int B, int T, int hop, int n_fft, int Mp, float* xp, hipStream_t st);
-hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, float* feats, hipStream_t st);
+hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, int C, float* feats, hipStream_t st);
+hipError_t launch_feats_relayout(float* eng, float* ref, int B, int C, int F, int Tp, int halo, int to_ref, hipStream_t st);
 hipError_t launch_halo_rows(float* buf, int B, int F, int halo, int C, int T, int zero, hipStream_t st);
 hipError_t launch_combine2d(const float* s0, const float* aff0, int h0, const float* s1, const float* aff1, int h1, int elu, float alpha,
                             int B, int F, int C, int T, float* dst, int hd, hipStream_t st);
-hipError_t launch_spec_from_dec(const float* dec, const float* aff, int B, int F, int Tp, int halo, float* spec, hipStream_t st);
+hipError_t launch_spec_from_dec(const float* dec, const float* aff, int B, int F, int Tp, int halo, int C, float* spec, hipStream_t st);
 hipError_t launch_istft_finish(const float* ypoly, const float* win2, int B, int hop, int n_fft, int Mp, int Tp, const float* mul, int out_len,
                                float* wav, hipStream_t st);
 

@@ -306,6 +306,13 @@ class CodecEngine:
                                             self._stream()))
         return out
 
+    def debug_freq_features(self, buf: Optional[torch.Tensor], mode: int) -> None:
+        """Test hook (fc_debug_freq_features): the next encode / encode_decode call of this thread hands its STFT-domain feature tensor
+        [B, input_channels, n_fft / 2 + 1, frames] to `buf` (mode 1) or takes it from there (mode 2); mode 0 disarms."""
+        if buf is not None and (buf.device != self.device or buf.dtype != torch.float32 or not buf.is_contiguous()):
+            raise EngineError("debug_freq_features: a contiguous float32 tensor on the engine's device")
+        self._check(self.lib.fc_debug_freq_features(_ptr(buf), 0 if buf is None else buf.numel() * 4, int(mode)))
+
     def check_status(self, sync: bool = True) -> None:
         """Raise if a kernel of an earlier call recorded a failure (persistent-LSTM barrier timeout, out-of-range code
         index).  With sync=True the engine's stream is synchronised first, so every call enqueued so far is covered."""

@@ -61,8 +61,10 @@ typedef struct fc_arch {
     int32_t dilation_base;          /* block j of a stage dilates its k=3 conv by dilation_base**j (seanet_encoder.py:127-133) */
     /* ABI version 4: the STFT-domain codec (FreqCodec, funcodec/models/codec_freq.py:123-210; SEANetEncoder2d / SEANetDecoder2d,
      * funcodec/models/encoder/seanet_encoder.py:252-363, decoder/seanet_decoder.py:244-360).  model_type 0 ignores the rest. */
-    int32_t model_type;             /* 0 = encodec (time domain), 1 = freq_codec with codec_domain [mag_phase, mag_phase] */
-    int32_t input_channels;         /* encoder input / decoder output channels of the 2-D nets (3: log-magnitude, phase re, im) */
+    int32_t model_type;             /* 0 = encodec (time domain), 1 = freq_codec (codec_domain [mag_phase, mag_phase] or [mag_angle, mag_angle]) */
+    int32_t input_channels;         /* encoder input / decoder output channels of the 2-D nets, which also names the codec_domain like the
+                                     * reference's input_size does (codec_freq.py:356-379): 3 = mag_phase (log-magnitude, phase re, phase im),
+                                     * 2 = mag_angle (log-magnitude, torch.angle) */
     int32_t n_fft;                  /* 512  (model_conf.domain_conf.n_fft) */
     int32_t stft_hop;               /* 160  (model_conf.domain_conf.hop_length) */
     int32_t ratios_f[FC_MAX_RATIOS];/* frequency ratios of the 2-D stages, decoder order (ratios[] holds the time ratios) */
@@ -214,6 +216,14 @@ int fc_engine_profile_read(fc_engine* e, fc_prof* out /* [FC_PROF_CLASSES] */);
 /* Kernel-phase timeline of the last conv launch, [2 roles][24 work items][8 stamps] of shader-clock ticks.
  * Only builds made with FC_TIMELINE=1 record anything (all zeros otherwise); a tuning aid, not part of the path. */
 int fc_debug_timeline(unsigned long long* dst /* [2*24*8] */);
+
+/* Test hook for the STFT-domain codec (model_type 1): the NEXT fc_encode / fc_encode_decode call of this thread hands its feature tensor
+ * (the 2-D encoder's input, codec_freq.py:356-379) to `dev_buf` (mode 1) or takes it from there (mode 2), in the reference's layout
+ * [B][input_channels][n_fft / 2 + 1][1 + T / stft_hop] fp32; mode 0 disarms.  One shot.  Why it exists: torch.angle of a bin whose
+ * imaginary part is rounding noise around a negative real part is +pi or -pi by the FFT's rounding, so for codec_domain mag_angle no
+ * second STFT implementation reproduces the reference's feature tensor bin for bin; the parity tests compare the features modulo 2 pi
+ * and pin the rest of the path from the reference's own features. */
+int fc_debug_freq_features(void* dev_buf, size_t cap_bytes, int mode);
 
 /* ---- host-side wire formats of the CLI (no GPU work) -------------------------------------------
  * The text form of one utterance's codes, byte for byte what funcodec/bin/codec_inference.py:295-299 writes with

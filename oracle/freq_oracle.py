@@ -94,7 +94,7 @@ class FreqOracle(Oracle):
         m = dict(config.get("model_conf", {}))
         self.ratios2d: List[Tuple[int, int]] = [tuple(r) for r in enc.get("ratios", [[4, 1], [4, 1], [4, 2], [4, 1]])]
         self.domain = tuple(m.get("codec_domain", ("time", "time")))
-        assert self.domain == ("mag_phase", "mag_phase"), "only the mag_phase recipe is restated"
+        assert self.domain in (("mag_phase", "mag_phase"), ("mag_angle", "mag_angle")), "the mag_phase and mag_angle recipes are restated"
         dc = dict(m.get("domain_conf", {}) or {})
         self.n_fft, self.stft_hop = dc.get("n_fft", 512), dc.get("hop_length", 160)
         self.audio_normalize = m.get("audio_normalize", False)          # FreqCodec.__init__ default is False (codec_freq.py:141)
@@ -160,7 +160,7 @@ class FreqOracle(Oracle):
 
     @torch.no_grad()
     def encode_frame(self, speech: torch.Tensor):
-        """FreqCodec._encode_frame codec_freq.py:330-392 (mag_phase): speech [B,1,T] -> emb [B,Tf,D], scale [B,1]|None, features."""
+        """FreqCodec._encode_frame codec_freq.py:330-392 (mag_phase / mag_angle): speech [B,1,T] -> emb [B,Tf,D], scale [B,1]|None, features."""
         x = speech
         scale = None
         if self.audio_normalize:
@@ -170,11 +170,17 @@ class FreqOracle(Oracle):
             x = x / scale
             scale = scale.view(-1, 1)
         xc = spectrogram(x.squeeze(1), self.n_fft, self.stft_hop)
+        feats = self.features(xc)
+        return self.encoder2d(feats), scale, feats
+
+    def features(self, xc: torch.Tensor) -> torch.Tensor:
+        """codec_freq.py:356-379: the 2-D encoder's input from the complex STFT (encoder.input_size 2 / 3: the stacked form)."""
         mag = torch.abs(xc)
         log_mag = torch.log(torch.clamp(mag, min=1e-6))
-        phase = xc / torch.clamp(mag, min=1e-6)
-        feats = torch.stack([log_mag, phase.real, phase.imag], dim=1)   # encoder.input_size == 3
-        return self.encoder2d(feats), scale, feats
+        if self.domain[0] == "mag_angle":                               # :356-364
+            return torch.stack([log_mag, torch.angle(xc)], dim=1)
+        phase = xc / torch.clamp(mag, min=1e-6)                         # :371-379
+        return torch.stack([log_mag, phase.real, phase.imag], dim=1)
 
     @torch.no_grad()
     def decode_frame(self, emb: torch.Tensor, scale):
@@ -182,7 +188,11 @@ class FreqOracle(Oracle):
         out = self.decoder2d(emb)
         parts = [p.squeeze(1) for p in torch.split(out, 1, dim=1)]
         mag = F.softplus(parts[0])
-        spec = mag * torch.complex(parts[1], parts[2])
+        if self.domain[1] == "mag_angle":                               # codec_freq.py:426-434
+            ang = torch.sin(parts[1]) * torch.pi
+            spec = torch.complex(torch.cos(ang) * mag, torch.sin(ang) * mag)
+        else:
+            spec = mag * torch.complex(parts[1], parts[2])
         wav = inverse_spectrogram(spec, self.n_fft, self.stft_hop).unsqueeze(1)
         if scale is not None:
             wav = wav * scale.view(-1, 1, 1)

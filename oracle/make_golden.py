@@ -120,6 +120,11 @@ FREQ_CASES = [
     ("freqfuzz3_b2_t3000", "freqfuzz3", 3, "tones", 96, 2, 3000),
     ("freqfuzz5_b2_t2500", "freqfuzz5", 5, "noise", 97, 2, 2500),
     ("freqfuzz10_b3_t700", "freqfuzz10", 10, "tones", 98, 3, 700),
+    # codec_domain [mag_angle, mag_angle] (conf/freqcodec_mag_angle_16k_n32_600k_step.yaml): log-magnitude + torch.angle, 2 channels.  These
+    # fixtures also carry the reference's FEATURE tensor (the 2-D encoder's input): the angle of a bin whose imaginary part is rounding
+    # noise around a negative real part is +-pi by the FFT's rounding, so the path behind the STFT is pinned from the reference's features
+    ("tinyfreqang_b2_t2000", "tinyfreqang", 4, "tones", 89, 2, 2000),
+    ("freqmpang_b1_t16000", "freqmpang", 0, "noise", 90, 1, 16000),
 ]
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [
@@ -309,13 +314,20 @@ def main():
                                                frames=[int(i.shape[2]) for i in idx])
                 print(f"[golden] {name}: FreqCodec segmented, {len(idx)} frames {[tuple(i.shape) for i in idx]} oracle==reference OK")
                 continue
+            grabbed = {}
+            hook = s2t.model.encoder.register_forward_pre_hook(lambda mod, args: grabbed.__setitem__("features", args[0].detach().clone()))
             with torch.no_grad():
                 emb_ref, scale_ref = s2t.model._encode_frame(x.unsqueeze(1))
+            hook.remove()
             assert torch.equal(o["encoder_out"], emb_ref), f"{name}: oracle encoder != reference"
+            assert torch.equal(o["features"], grabbed["features"]), f"{name}: oracle features != the reference encoder's input"
             assert torch.equal(o["code_indices"][0], idx[0]), f"{name}: oracle indices != reference"
             assert torch.equal(o["code_embeddings"][0][0], embs[0][0]), f"{name}: oracle quantized != reference"
             assert torch.equal(o["recon_speech"], recon), f"{name}: oracle recon != reference"
             arrays = dict(indices=idx[0].numpy().astype(np.int16), encoder_out=emb_ref.numpy(), quantized=embs[0][0].numpy(), recon=recon.numpy())
+            angle = cfg["model_conf"]["codec_domain"][0] == "mag_angle"
+            if angle:
+                arrays.update(features=grabbed["features"].numpy())
             if scale_ref is not None:                  # model_conf.audio_normalize: false -> no scale
                 arrays.update(scale=scale_ref.numpy())
             np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
@@ -329,9 +341,19 @@ def main():
                 e64 = orc.encode_frame(x.unsqueeze(1))[0]
             _fo.spectrogram = _real
             self_noise = float((e64 - emb_ref).pow(2).mean().sqrt())
+            extra = {}
+            if angle:      # how many feature bins the reference's own exact STFT wraps by 2 pi, and what that does to its own codes
+                with torch.no_grad():
+                    _fo.spectrogram = lambda xx, n_fft, hop: _real(xx.double(), n_fft, hop).to(torch.complex64)
+                    o64 = orc.inference(x, None, True)
+                    _fo.spectrogram = _real
+                dang = (o64["features"][:, 1] - grabbed["features"][:, 1]).abs()
+                extra = dict(angle_bins=int(dang.numel()), angle_bins_wrapped_by_fp64_stft=int((dang > 3.0).sum()),
+                             frames_with_other_codes_under_fp64_stft=int((o64["code_indices"][0] != idx[0]).any(0).sum()),
+                             frames=int(idx[0].shape[1] * idx[0].shape[2]))
             manifest["cases"][name] = dict(kind="freq", config=cfg_name, weight_seed=wseed, codebook_decay=1.0, audio_kind=akind,
                                            audio_seed=aseed, batch=B, samples=T, bit_width=None, n_q=int(idx[0].shape[0]),
-                                           frames=int(idx[0].shape[2]), stft_self_noise=self_noise,
+                                           frames=int(idx[0].shape[2]), stft_self_noise=self_noise, **({"angle_conditioning": extra} if extra else {}),
                                            note="torchaudio Spectrogram / InverseSpectrogram restated over torch.stft / istft (oracle/ref_shim.py)")
             print(f"[golden] {name}: FreqCodec idx{tuple(idx[0].shape)} recon{tuple(recon.shape)} oracle==reference OK")
             if cfg_name == "freqmp":              # checkpoint key list of the real FreqCodec model (format pin)
