@@ -186,7 +186,7 @@ def laura_step_pmc_traffic():
             launches, fetch_mb, write_mb = int(f[-7]), float(f[-2]), float(f[-1])
         except ValueError:
             continue
-        if any(k in ln for k in ("gemv_kernel", "attn_step_kernel", "sample_kernel", "layernorm_rows_kernel")):
+        if any(k in ln for k in ("step_persist_kernel", "gemv_kernel", "attn_step_kernel", "sample_kernel", "layernorm_rows_kernel")):
             tot += launches * (fetch_mb + write_mb) * 1e6
         if "sample_kernel" in ln:
             steps = launches
@@ -444,7 +444,8 @@ def laura_side(batch: int = 8, text_len: int = 100, prompt_frames: int = 75, new
            "phases_ms": {"text_encoder": round(phases[0] / steps, 3), "decode_codec": round(ar_ms, 3),
                          "codec_emb": round(phases[2] / steps, 3), "codec_decoder": round(phases[3] / steps, 3)},
            "decode_step_us": round(ar_step_us, 2),
-           "roofline": {"bound": "hbm", "kernel": "decoding step (62 launches: weight-streaming MFMA GEMVs + KV-cache attention)",
+           "roofline": {"bound": "hbm", "kernel": "decoding step (one persistent launch: 61 phases of weight-streaming MFMA GEMV tiles + KV-cache "
+                                                  "attention units handed over through arrival counters, + the sampler launch)",
                         "achieved": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e9, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
                         "frac": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4),
                         "traffic": (laura_step_pmc_traffic() or {}).get("bytes_per_step"), "traffic_detail": laura_step_pmc_traffic(),

@@ -169,7 +169,8 @@ def inference_modelscope(
     torch.manual_seed(seed)
     my_model = Speech2Token.from_pretrained(model_tag=model_tag, config_file=config_file, model_file=model_file,
                                             device="cuda", dtype=dtype, streaming=streaming,
-                                            sampling_rate=sampling_rate, bit_width=bit_width)
+                                            sampling_rate=sampling_rate, bit_width=bit_width,
+                                            check_status=False)      # ONE status check per batch, below (not one per call + one per batch)
 
     def _forward(data_path_and_name_and_type=None, raw_inputs=None, output_dir_v2: Optional[str] = None,
                  param_dict: Optional[dict] = None):
