@@ -588,6 +588,7 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
     pa.edge_stride = edge_stride; pa.o_q = (int)o_q; pa.o_ap = (int)o_ap; pa.o_xm = (int)o_xm; pa.o_hb = (int)o_hb; pa.o_xo = (int)o_xo;
     pa.B = B; pa.d = d; pa.ff = ff; pa.H = heads; pa.DK = dkh; pa.NL = NL; pa.V = V; pa.Tcap = Tcap; pa.R = e->R; pa.PR = e->PR; pa.NS = NS;
     pa.act = S.s.act; pa.G = e->persist_grid; pa.KS2 = KS2; pa.trace = ptrace;
+    { const char* t = getenv("FC_LAURA_PERSIST_TEST"); pa.test_timeout = t && std::string(t) == "timeout"; }
     if (ptrace && cx.live()) cx.check(hipMemsetAsync(ptrace, 0, (size_t)256 * 64 * 8 * sizeof(unsigned long long), cx.st), "trace");
     // one decoding step: the newest token of every utterance through the LM against its KV cache.  Every kernel reads its
     // positions from device memory, so the launch sequence is identical from step to step.
@@ -621,7 +622,9 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
             unsigned perr = 0;
             if (hipMemcpy(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess || perr) {
                 cx.err = 1;
-                fail("decode_codec: the persistent decoding step timed out at a hand-off (set FC_LAURA_PERSIST=0 to use the kernel chain)");
+                e->persist_on = false;
+                fail("decode_codec: the persistent decoding step timed out at a hand-off; this engine now uses the kernel chain "
+                     "(fc_laura_set_persistent_step(e, 1) re-enables it)");
                 return true;
             }
         }
@@ -660,7 +663,11 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
         unsigned perr = 0;
         HIP_TRY(hipMemcpyAsync(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost, cx.st));
         HIP_TRY(hipStreamSynchronize(cx.st));
-        if (perr) return fail("decode_codec: the persistent decoding step timed out at a hand-off (set FC_LAURA_PERSIST=0 to use the kernel chain)");
+        if (perr) {
+            e->persist_on = false;         // like the persistent LSTM: never a silent result, and the engine stays usable on the kernel chain
+            return fail("decode_codec: the persistent decoding step timed out at a hand-off; this engine now uses the kernel chain "
+                        "(fc_laura_set_persistent_step(e, 1) re-enables it)");
+        }
     }
     std::vector<int> gen(B);
     HIP_TRY(hipMemcpyAsync(gen.data(), n_gen, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, cx.st));

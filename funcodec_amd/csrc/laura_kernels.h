@@ -152,6 +152,7 @@ struct StepPersistArgs {
     int KS2;                        // k slices of w_2 (step_persist_ksplit)
     int wtile;                      // floats of one LDS weight tile (set by launch_step_persist)
     unsigned long long* trace;      // tuning aid (FC_LAURA_TRACE): [G][64 units][8] s_memtime stamps of the last launch, or null
+    int test_timeout;               // test hook (FC_LAURA_PERSIST_TEST=timeout): behave as if a hand-off had timed out
 };
 int step_persist_ksplit(int d, int ff);
 size_t step_persist_sync_words(int NL);

@@ -611,6 +611,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_persist_kernel(StepPersistAr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const unsigned seq = *a.seq;
+    if (a.test_timeout && wg == 0 && tid == 0) __hip_atomic_store(error_word(a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     Item it{-1, -a.G};
     next_item(a, wg, it);                 // first unit of this workgroup (phase order)
     if (it.ph < 0) return;

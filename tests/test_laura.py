@@ -503,6 +503,30 @@ def test_persistent_step_equals_the_kernel_chain(cfg_name, B, steps):
 
 
 @pytest.mark.gpu
+def test_persistent_step_timeout_is_loud_and_falls_back(monkeypatch):
+    """A hand-off of the persistent step that never completes (a workgroup not resident, a lost store) must end the call with an error
+    that names it -- bounded spins, no hang, no silent tokens -- and leave the engine usable: it switches itself to the kernel chain."""
+    from funcodec_amd.engine import EngineError
+    name = "laura_tiny_b3"
+    c, cfg, spec, sd, text, _ = case_inputs(name)
+    g = golden(name)
+    m = laura_engine(name)
+    lens = c["text_lengths"]
+    outs = torch.from_numpy(g["text_outs"])
+    assert m.engine.set_persistent_step(True)
+    ref = m.engine.decode_codec(outs, lens, 8, sampling=False)
+    monkeypatch.setenv("FC_LAURA_PERSIST_TEST", "timeout")
+    with pytest.raises(EngineError, match="timed out at a hand-off"):
+        m.engine.decode_codec(outs, lens, 8, sampling=False)
+    monkeypatch.delenv("FC_LAURA_PERSIST_TEST")
+    again = m.engine.decode_codec(outs, lens, 8, sampling=False)           # on the kernel chain now
+    assert again[1] == ref[1] and torch.equal(again[0], ref[0])
+    assert m.engine.set_persistent_step(True)                              # and back
+    back = m.engine.decode_codec(outs, lens, 8, sampling=False)
+    assert back[1] == ref[1] and torch.equal(back[0], ref[0])
+
+
+@pytest.mark.gpu
 def test_top_k_with_hundreds_of_tied_logits_is_deterministic():
     """A constant output layer makes all 1025 logits of a group equal: more than the 256 slots of the radix-select path tie at the k-th
     key.  The sampler must then order the candidates by (probability descending, index ascending) -- i.e. the top-k set is ids 0 .. k-1 --
