@@ -364,6 +364,176 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Round 4: the 3 x 3 layers (stride 1) through LDS.  The direct form above activates every loaded input sample once per lane that reads
+// it: 4-column lanes overlap by 2 columns (1.5x) and 2-row lanes by 2 rows (2x), 3 activations per sample, and the layer is bound by
+// v_exp_f32 + the affine / select work around it, not by HBM.  Here one workgroup owns an 8-row x 256-column output
+// tile of one (utterance, group): the (8 + 2) x (256 + 2) x CPG input patch is loaded once (all 16-byte pieces of a thread in flight
+// before the first use), affine'd / summed / ELU'd ONCE per sample (1.26 activations per sample with the halo) into LDS, and every lane
+// computes its 2 rows x 4 columns x OPG outputs from LDS reads (one 16-byte + one 8-byte read per (row, channel)); the group's weights are
+// uniform scalar loads.  Same contract: raw output + bias, one fp64 (sum, sum of squares) partial per workgroup.
+// -------------------------------------------------------------------------------------------------
+constexpr int G3_RF = 8, G3_TN = 256, G3_PW = 264;       // output rows / columns per workgroup, LDS row stride (258 used, 16-byte multiple)
+
+template <int CPG, int OPG, bool DUAL>
+__global__ __launch_bounds__(256) void gconv2d_3x3_lds_kernel(const GConvArgs p) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int PR = G3_RF + 2;                        // patch rows
+    constexpr int NPC = (G3_TN + 2 + 3) / 4;             // 16-byte pieces per patch row (65: columns 0 .. 259)
+    constexpr int NP = NPC * PR * CPG;                   // pieces of the patch
+    constexpr int NIT = (NP + 255) / 256;
+    constexpr int NW = OPG * CPG * 9;
+    extern __shared__ __attribute__((aligned(16))) float patch[];       // [CPG][PR][G3_PW]
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x, g = blockIdx.y, z = blockIdx.z;
+    const int FoT = (p.Fo + G3_RF - 1) / G3_RF;
+    const int b = z / FoT, fo0 = (z - b * FoT) * G3_RF;
+    const int n0 = tile * G3_TN;                         // first output column of the tile; patch column c is source column n0 - padL + c
+    const int row_max = p.Fo + 1;                        // last input row a valid output row reads (dangling rows are clamped onto it)
+    const size_t in_b = (size_t)b * p.in_sB + (size_t)(g * CPG) * p.Tin;
+    const float2* a0 = p.aff0 ? (const float2*)p.aff0 + (size_t)b * p.C + g * CPG : nullptr;
+    const float2* a1 = (DUAL && p.aff1) ? (const float2*)p.aff1 + (size_t)b * p.C + g * CPG : nullptr;
+    const int refl = 2 * (p.Leff - 1);
+    // ---- stage: every piece of this thread is requested before the first one is used
+    f32x4 v0[NIT], v1[DUAL ? NIT : 1];
+    int meta[NIT];                                       // (ci, rr, i) of the piece, -1 = none
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + tid;
+        const int ic = idx < NP ? idx : NP - 1;
+        const int i = ic % NPC, rem = ic / NPC, rr = rem % PR, ci = rem / PR;
+        meta[it] = idx < NP ? ic : -1;
+        int rm = fo0 + rr;
+        rm = rm > row_max ? row_max : rm;
+        const size_t off = in_b + (size_t)rm * p.in_sF + (size_t)ci * p.Tin;
+        const int q0 = n0 - p.padL + 4 * i;
+        if (q0 >= 0 && q0 + 3 < p.Tin) {                 // interior piece: one 16-byte load per source
+            v0[it] = *(const f32x4u*)(p.src0 + off + q0);
+            if (DUAL) v1[it] = *(const f32x4u*)(p.src1 + off + q0);
+        } else {                                         // padded edge: reflected gather, zeros outside the padded signal
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = q0 + j;
+                int src = q < 0 ? -q : q;
+                src = src >= p.Leff ? refl - src : src;
+                const bool ok = q >= -p.padL && src >= 0 && src < p.Tin;
+                v0[it][j] = ok ? p.src0[off + src] : 0.f;
+                if (DUAL) v1[it][j] = ok ? p.src1[off + src] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (meta[it] < 0) continue;
+        const int ic = meta[it];
+        const int i = ic % NPC, rem = ic / NPC, rr = rem % PR, ci = rem / PR;
+        const float2 A = a0 ? a0[ci] : make_float2(1.f, 0.f);
+        const float2 A1 = a1 ? a1[ci] : make_float2(1.f, 0.f);
+        const int q0 = n0 - p.padL + 4 * i;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + j;
+            int src = q < 0 ? -q : q;
+            src = src >= p.Leff ? refl - src : src;
+            const bool ok = q >= -p.padL && src >= 0 && src < p.Tin;
+            float v = fmaf(v0[it][j], A.x, A.y);
+            if (DUAL) v = v + fmaf(v1[it][j], A1.x, A1.y);
+            if (p.elu) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f); v = v > 0.f ? v : fmaf(e, p.alpha, -p.alpha); }
+            o[j] = ok ? v : 0.f;
+        }
+        *(f32x4*)(patch + ((size_t)ci * PR + rr) * G3_PW + 4 * i) = o;
+    }
+    __syncthreads();
+    // ---- compute: wave w -> output rows 2w, 2w + 1 of the tile; lane -> 4 columns
+    const float* wg = p.w + (size_t)g * NW;              // uniform: scalar loads
+    float acc[2][OPG][4];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int o = 0; o < OPG; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[f][o][j] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < CPG; ++ci) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                    // input rows 2w + a of the patch
+            const float* pr = patch + ((size_t)ci * PR + 2 * wid + a) * G3_PW + 4 * lane;
+            const f32x4 xa = *(const f32x4*)pr;
+            const f32x2 xb = *(const f32x2*)(pr + 4);
+            const float x[6] = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1]};
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int tap = a - f;                   // frequency tap of this input row for output row 2w + f
+                if (tap < 0 || tap > 2) continue;
+#pragma unroll
+                for (int o = 0; o < OPG; ++o)
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) {
+                        const float wv = wg[((o * CPG + ci) * 3 + tap) * 3 + kk];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[f][o][j] = fmaf(wv, x[j + kk], acc[f][o][j]);
+                    }
+            }
+        }
+    }
+    // ---- epilogue
+    const int nl = n0 + 4 * lane;
+    const bool live = nl < p.Tout;
+    float s1v = 0.f, s2v = 0.f;
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int fo = fo0 + 2 * wid + f;
+        if (fo >= p.Fo) continue;
+#pragma unroll
+        for (int o = 0; o < OPG; ++o) {
+            const int m = g * OPG + o;
+            const float bm = p.bias[m];
+            float ov[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ov[j] = acc[f][o][j] + bm;
+                if (live && nl + j < p.Tout) { s1v += ov[j]; s2v = fmaf(ov[j], ov[j], s2v); }
+            }
+            if (!live) continue;
+            float* orow = p.out + (size_t)b * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.Tout + nl;
+            if (nl + 3 < p.Tout) *(f32x4u*)orow = (f32x4){ov[0], ov[1], ov[2], ov[3]};
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (nl + j < p.Tout) orow[j] = ov[j];
+        }
+    }
+    if (p.partials) {
+        double d1 = (double)s1v, d2 = (double)s2v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            d1 += __shfl_xor(d1, off, 64);
+            d2 += __shfl_xor(d2, off, 64);
+        }
+        if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t slot = ((((size_t)b * FoT + (fo0 / G3_RF)) * p.G + g) * gridDim.x + tile) * 2;
+            p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+    }
+}
+
+static bool gconv2d_lds3(int kf, int kt, int st) {
+    // OFF by default.  Measured on MI355X (freqmpgr1, 64 x 10 s, both forms in one call, all 42 FreqCodec tests green with either): the 8
+    // launches of the 3 x 3 class take 3.04 ms through LDS against 2.58 ms direct.  The activations did drop from 3 to 1.26 per sample, but
+    // the layer is not VALU-bound enough for that to decide: a workgroup here loads, activates, barriers and then computes -- phases that
+    // only other workgroups can overlap, and 163 registers + 42 KB of LDS leave 3 of them per CU -- while the direct form has no barrier
+    // and every wave streams on its own.  What would beat it is a persistent tile loop with a double-buffered patch; FC_GCONV_LDS3=1
+    // selects this kernel for A / B runs.
+    static const int env = getenv("FC_GCONV_LDS3") ? atoi(getenv("FC_GCONV_LDS3")) : 0;
+    return env && kf == 3 && kt == 3 && st == 1;
+}
+
 bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st) {
     const bool shape = (kf == 1 && kt == 1 && st == 1) || (kf == 3 && kt == 3 && st == 1) || (kf == 8 && kt == 2 && st == 1) ||
                        (kf == 8 && kt == 4 && st == 2);
@@ -373,7 +543,10 @@ bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st) {
 // output frequency rows per lane: 2 for the 3 x 3 layers (4 input rows instead of 6: 6.9 -> 5.6 ms on freqmpgr1); the strided 8-row layers
 // measured slower with 2 (12 rows x two sources in flight: 4.4 -> 5.6 ms), 1 x 1 layers share nothing
 static int gconv2d_fo(int kf, int Fo) { return (kf == 3 && Fo > 1) ? 2 : 1; }
-int gconv2d_nblk(int Tout, int Fo, int G, int kf) { return cdiv(Tout, 1024) * cdiv(Fo, gconv2d_fo(kf, Fo)) * G; }
+int gconv2d_nblk(int Tout, int Fo, int G, int kf) {
+    if (gconv2d_lds3(kf, kf, 1)) return cdiv(Tout, G3_TN) * cdiv(Fo, G3_RF) * G;       // (the grouped layers are square: kt == kf for kf == 3)
+    return cdiv(Tout, 1024) * cdiv(Fo, gconv2d_fo(kf, Fo)) * G;
+}
 
 hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     GConvArgs a;
@@ -386,6 +559,23 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     a.in_sB = c.in_sB; a.in_sF = c.in_sF; a.out_sB = c.out_sB; a.out_sF = c.out_sF;
     const int fo_n = gconv2d_fo(c.kf, c.Fo);
     if (c.kf >= 4 ? c.sf != c.kf / 2 : c.sf != 1) return hipErrorInvalidValue;          // the kernel's compile-time row stride
+    if (gconv2d_lds3(c.kf, c.kt, c.st)) {
+        const int cpg3 = c.C / c.G, opg3 = c.M / c.G;
+        const int FoT = cdiv(c.Fo, G3_RF);
+        if ((long long)c.B * FoT > 65535 || c.G > 65535) return hipErrorInvalidValue;
+        dim3 grid3(cdiv(c.Tout, G3_TN), c.G, c.B * FoT), block3(256);
+        const size_t lds = (size_t)cpg3 * (G3_RF + 2) * G3_PW * sizeof(float);
+        const bool dual3 = c.src1 != nullptr;
+#define FC_G3(CP, OP)                                                                                                           \
+        if (cpg3 == CP && opg3 == OP) {                                                                                         \
+            if (dual3) hipLaunchKernelGGL((gconv2d_3x3_lds_kernel<CP, OP, true>), grid3, block3, lds, st, a);                    \
+            else hipLaunchKernelGGL((gconv2d_3x3_lds_kernel<CP, OP, false>), grid3, block3, lds, st, a);                         \
+            return hipGetLastError();                                                                                           \
+        }
+        FC_G3(2, 2) FC_G3(4, 2) FC_G3(2, 4)
+#undef FC_G3
+        return hipErrorInvalidValue;
+    }
     if ((long long)c.B * cdiv(c.Fo, fo_n) > 65535 || c.G > 65535) return hipErrorInvalidValue;
     dim3 grid(cdiv(c.Tout, 1024), c.G, c.B * cdiv(c.Fo, fo_n)), block(256);
     const int cpg = c.C / c.G, opg = c.M / c.G;
