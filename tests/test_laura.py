@@ -503,6 +503,47 @@ def test_persistent_step_equals_the_kernel_chain(cfg_name, B, steps):
 
 
 @pytest.mark.gpu
+def test_persistent_step_is_bit_stable_under_concurrent_load():
+    """The in-launch hand-offs of the persistent step (write-through stores + arrival counters, then PLAIN loads of the edge buffers) are
+    only correct if no consumer can see a stale line.  Idle chips and uniform load hide such failures (MI355X_MICROARCH.md): run the
+    recipe-size step 24 times while ANOTHER stream keeps the memory system and the CUs busy with the codec engine (a different load
+    every round), and require every teacher-forced log-probability of every run to be bit-identical to the first, unloaded one.
+    (The side load is the SoundStream-shaped codec, which has no LSTM: two PERSISTENT kernels -- this step and the persistent LSTM -- must not
+    run concurrently on one device, each needs every one of its workgroups resident; see INTEGRATION.md.)"""
+    from funcodec_amd.laura import LauraGenMI355X
+    from helpers import engine_for
+    cfg = laura_recipe_config("lauraphn")
+    spec = laura_spec_from_config(cfg)
+    m = LauraGenMI355X(spec, "cuda:0", max_positions=512)
+    m.load_state_dict(make_laura_state_dict(cfg, 6))
+    B, steps = 8, 48
+    lens = [20 + 3 * i for i in range(B)]
+    text = synthetic_text(cfg, B, lens, 23)
+    rng = np.random.Generator(np.random.PCG64(8))
+    forced = torch.from_numpy(rng.integers(0, spec.codebook_size, size=(B, steps, spec.predict_nq)).astype(np.int64))
+    codec = engine_for("ss320", 0)
+    assert codec.arch.lstm_layers == 0
+    wav = torch.from_numpy(synthetic_audio(6, 48000, 5)).cuda()
+    side = torch.cuda.Stream()
+    main = torch.cuda.Stream()                      # the decode loop replays a graph: not on the legacy default stream
+    with torch.no_grad():
+        outs, _ = m.encode(torch.from_numpy(text), torch.tensor(lens))
+        assert m.engine.set_persistent_step(True)
+        with torch.cuda.stream(main):
+            _, _, ref = m.engine.decode_codec(outs, lens, steps, sampling=False, forced=forced, return_logp=True)
+        torch.cuda.synchronize()
+        for it in range(24):
+            with torch.cuda.stream(side):
+                for _ in range(1 + it % 4):
+                    codec.engine.encode_decode(wav[: 1 + it % 6], 32)
+            with torch.cuda.stream(main):
+                _, _, lp = m.engine.decode_codec(outs, lens, steps, sampling=False, forced=forced, return_logp=True)
+            torch.cuda.synchronize()
+            assert torch.equal(lp, ref), (it, float((lp - ref).abs().max()))
+    codec.engine.check_status()
+
+
+@pytest.mark.gpu
 def test_persistent_step_timeout_is_loud_and_falls_back(monkeypatch):
     """A hand-off of the persistent step that never completes (a workgroup not resident, a lost store) must end the call with an error
     that names it -- bounded spins, no hang, no silent tokens -- and leave the engine usable: it switches itself to the kernel chain."""
