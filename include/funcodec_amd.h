@@ -26,7 +26,8 @@ extern "C" {
 #endif
 
 #define FC_MAX_RATIOS 8
-#define FC_ABI_VERSION 5
+#define FC_ABI_VERSION 5     /* layout of fc_arch / fc_laura_arch.  Round 4 added entry points without changing a struct (fc_laura_set_persistent_step,
+                              * fc_debug_freq_features) and one more value of fc_arch.input_channels (2 = codec_domain mag_angle): still 5 */
 
 typedef struct fc_engine fc_engine;
 
