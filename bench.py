@@ -450,6 +450,8 @@ def laura_side(batch: int = 8, text_len: int = 100, prompt_frames: int = 75, new
                         "frac": round((w_bytes + kv_bytes) / (ar_step_us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4),
                         "traffic": (laura_step_pmc_traffic() or {}).get("bytes_per_step"), "traffic_detail": laura_step_pmc_traffic(),
                         "algorithmic_bytes_per_step": round(w_bytes + kv_bytes), "weights_bytes": round(w_bytes), "kv_bytes_avg": round(kv_bytes),
+                        "traffic_over_algorithmic": round((laura_step_pmc_traffic() or {}).get("bytes_per_step", 0) / (w_bytes + kv_bytes), 2)
+                        if laura_step_pmc_traffic() else None,
                         "step_tflops": round(step_flops / (ar_step_us * 1e-6) / 1e12, 3)}}
     if batch == 8:
         # the decoding step is latency-bound (a chain of 62 dependent kernels), so its time barely depends on the batch: the same flow at
