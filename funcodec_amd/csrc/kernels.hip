@@ -1440,8 +1440,18 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
     }
     // two row sets per workgroup once there are enough rows to keep ~half the CUs busy that way (L2 traffic halves)
     static const int ablate = getenv("FC_ABLATE_RVQ") ? atoi(getenv("FC_ABLATE_RVQ")) : 0;
-    static const int two_env = getenv("FC_RVQ_TWO") ? atoi(getenv("FC_RVQ_TWO")) : 0;
-    const bool two = two_env && N >= 2048 && D <= 128;
+    // Round 4 (tools/rvq_scaling.py): the kernel's time is linear in the workgroups per CU (one 8-wave workgroup per CU, 183 registers).
+    // Up to 16 rows per CU the 16-row form is the fastest (497 vs 807 us at 4 000 rows); beyond that two row sets per workgroup -- the
+    // codebook fragments of a stage are loaded once for both, 32 rows per MFMA pass -- take 413 us per 32 rows per CU against 2 x 489:
+    // 846 vs 974 us at 8 000 rows, 1 613 vs 1 943 at 16 000.  FC_RVQ_TWO=0 / 1 forces one form (A / B runs).
+    static const int two_env = getenv("FC_RVQ_TWO") ? atoi(getenv("FC_RVQ_TWO")) : -1;
+    static int n_cus = 0;
+    if (!n_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const bool two = D <= 128 && (two_env >= 0 ? (two_env != 0 && N >= 2048) : N > 16 * n_cus);
     dim3 grid(ceil_div(N, two ? 32 : 16)), block(512);
 #define FC_RVQ_CASE(DD)                                                                                            \
     case DD:                                                                                                       \

@@ -152,6 +152,25 @@ def test_rvq_bit_exact_vs_c_oracle_random_shapes():
         assert np.array_equal(quant.cpu().numpy(), cq), N
 
 
+def test_rvq_two_row_set_form_is_bit_exact_vs_c_oracle():
+    """More than 16 rows per CU (> 4 096 rows: FreqCodec batches, 32-utterance calls) run the fused quantiser with TWO 16-row sets per
+    workgroup (round 4).  Same arithmetic order per row: codes and quantised vectors bit-exact against the plain-C restatement on every
+    row of a 6 000-row input (8 stages of the ds640 codebooks), and identical to the 16-row form's results on the same rows."""
+    import c_oracle
+    m = engine_for("ds640", 0)
+    cfg, arch, sd = state_for("ds640", 0)
+    cb = sd["quantizer.rq.model.embed"]
+    rng = np.random.Generator(np.random.PCG64(123))
+    x = (rng.standard_normal((6000, 128)) * 1.5).astype(np.float32)
+    x[7] = cb[0, 11]                          # exactly on a code vector
+    codes, quant = m.engine.rvq_encode(torch.from_numpy(x), 8)
+    cc, cq = c_oracle.rvq_encode(x, cb, 8)
+    assert np.array_equal(codes.cpu().numpy(), cc)
+    assert np.array_equal(quant.cpu().numpy(), cq)
+    c16, q16 = m.engine.rvq_encode(torch.from_numpy(x[:4000]), 8)       # <= 16 rows per CU: the 16-row form
+    assert torch.equal(c16, codes[:, :4000]) and torch.equal(q16, quant[:4000])
+
+
 def test_use_ddp_false_checkpoint_layout_against_reference_golden():
     """`use_ddp: false` checkpoints store one codebook per layer (`quantizer.rq.model.layers.{i}._codebook.embed`,
     core_vq.py:147-150,324-396).  Golden = core_vq.ResidualVectorQuantization itself, run in the build container."""
