@@ -36,8 +36,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     cases = sorted({w["case"] for w in WAIVERS})
     terminalreporter.write_line(f"tie waivers: {len(WAIVERS)} frame(s) in {len(cases)} case(s): " +
                                 ", ".join(f"{c} x{sum(1 for w in WAIVERS if w['case'] == c)}" for c in cases))
-    for r in REPORTS:
-        terminalreporter.write_line("report: " + json.dumps(r))
+    for r in REPORTS:      # one compact line per report (long per-stage lists and nested tables stay in the JSON file only)
+        short = {k: v for k, v in r.items() if not isinstance(v, (list, dict)) or len(v) <= 4}
+        terminalreporter.write_line("report: " + json.dumps(short))
     path = os.environ.get("FC_WAIVER_JSON", os.path.join(ROOT, "gpurun_out", "tie_waivers.json"))
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
