@@ -50,6 +50,12 @@ typedef const __attribute__((address_space(1))) f32x4u* gv4up;
 
 namespace {
 
+// profiling builds only (FC_BUILD_DEFINES="FC_PERSIST_ABL=<mask>", results are garbage): 1 no LayerNorm arithmetic, 2 reciprocal / rsqrt
+// approximations instead of the precise division and square root in it
+#ifndef FC_PERSIST_ABL
+#define FC_PERSIST_ABL 0
+#endif
+
 constexpr int kThreads = 512, kWaves = 8;
 constexpr int kCntStride = 32;            // words between two arrival counters (128 bytes)
 constexpr int kCntPerPhase = 16;
@@ -276,9 +282,6 @@ __device__ __forceinline__ void stage_rows(const float* src, int ld, int col0, i
     tr.stamp(5);
     wg_barrier();
     tr.stamp(6);
-#ifndef FC_PERSIST_ABL
-#define FC_PERSIST_ABL 0       // profiling builds only (results are garbage): 1 no LayerNorm arithmetic, 2 no precise division / square root in it
-#endif
     if (gamma) {       // two-pass LayerNorm, one wave per row, the row in registers (<= 4 pieces of 16 bytes per lane)
         for (int b = w; b < B && !(FC_PERSIST_ABL & 1); b += kWaves) {
             float* xr = Xs + b * XS;
