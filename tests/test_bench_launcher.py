@@ -40,3 +40,23 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = _run(["--gpus", "4", "--dry-run-launcher"], env_extra={"WORLD_SIZE": "1", "RANK": "0"}, drop=())
     # under an existing WORLD_SIZE the script must not re-launch, and a rank count that contradicts --gpus is an error, not a silent N = 1 run
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not _json_lines(r.stdout)
+
+
+def test_roofline_objects_carry_both_fractions_and_the_traffic_ratio():
+    """the bench line reports the fraction of the roof at the SUSTAINED clock next to the nominal one, the measured / algorithmic
+    traffic ratio, and the dominant conv class inside the `roofline` object the driver parses.  Pure host logic over a synthetic profile."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prof = [dict(kernel="lstm_persist_kernel<NS>", total_ms=12.6, flops=100.66e9 * 10, bytes=5e9, launches=10),
+            dict(kernel="conv_mfma_kernel<128, 128, 2, 2, 0, 9, false>", total_ms=11.3, flops=1.2e12, bytes=267e6 * 15, launches=15),
+            dict(kernel="reshead_kernel<32>", total_ms=2.0, flops=1e9, bytes=8e9, launches=10)]
+    out = bench.kernel_rooflines(prof, 5)
+    top, conv, hbm = out["roofline"], out["roofline_conv"], out["roofline_hbm"]
+    assert top["kernel"].startswith("lstm_persist_kernel") and conv["kernel"].startswith("conv_mfma_kernel")
+    for o in (top, conv):
+        assert 0 < o["frac"] < o["frac_at_sustained_clock"] < 1 and o["sustained_clock_ghz"] == bench.SUSTAINED_GHZ
+        assert abs(o["frac_at_sustained_clock"] * bench.PEAK_F32_SUSTAINED - o["achieved"]) < 0.05
+    assert top["conv_class"]["kernel"] == conv["kernel"] and top["conv_class"]["frac"] == conv["frac"]
+    if conv.get("traffic"):                       # the committed PMC passes know this instantiation
+        assert conv["traffic_over_algorithmic"] == round(conv["traffic"] / conv["algorithmic_bytes_per_launch"], 2) > 1.0
+    assert hbm["bound"] == "hbm" and abs(hbm["frac"] - 0.5) < 1e-6
