@@ -10,7 +10,7 @@
 //   phase 5l + 1  ATT   B * H * NS units  one (utterance, head, key range): flash-decoding partial (o, max, sum)
 //   phase 5l + 2  OUT   d/16 tiles        combine the partials while staging, linear_out, + x_l            -> xm_l
 //   phase 5l + 3  FF1   ff/16 tiles       LayerNorm(xm_l), w_1, activation                                  -> h_l
-//   phase 5l + 4  FF2   d/16 tiles        w_2 h_l + xm_l                                                    -> x_{l+1}
+//   phase 5l + 4  FF2   KS2 x d/16 units  (k slice, row tile) of w_2 h_l; slice 0 adds xm_l and the bias      -> KS2 partial x_{l+1}
 //   phase 5 NL    DEC   ceil(V/16) tiles  after_norm, output layer                                          -> logits (next kernel: sampler)
 //
 // * The weights of a unit do not depend on data: while a workgroup computes its current GEMV unit, waves 1..7 request the 16-row tile of
