@@ -736,7 +736,10 @@ def test_freq_codec_against_reference_golden(name):
         if ours_differs.any():
             record_report(name, engine_frames_differing_from_fixture=np.argwhere(ours_differs).tolist(),
                           reference_self_disagreement_frames=np.argwhere(ref_disagrees).tolist(),
-                          explained_by_reference_variants=int((ours_differs & ref_disagrees).sum()))
+                          explained_by_reference_variants=int((ours_differs & ref_disagrees).sum()),
+                          encoder_out_rms_vs_fixture=rms(r["enc_out"], g["encoder_out"]),
+                          reference_variants_encoder_out_rms=MAN["cases"].get(name + "_variants", {}).get("summary", {}) and
+                          {k: v["encoder_out_rms_diff"] for k, v in MAN["cases"][name + "_variants"]["summary"].items()})
         else:
             assert rms(r["quantized"], g["quantized"]) <= qtol
     r2 = m.engine.encode_decode(wav, c["n_q"], use_scale=True)
