@@ -580,6 +580,44 @@ def launcher_dry_run(args):
         raise SystemExit("launcher dry run: gathered codes differ from the expected tensor")
 
 
+class _RehearsalEngine:
+    """FC_BENCH_REHEARSAL=1: stands in for the engine so that the WHOLE main() flow of an N-rank run -- sharding, per-rank inputs, the step
+    loop with its micro-batches, the gather of the codes, fences, max-over-ranks timing, the JSON line -- can be executed on a CPU-only box
+    over gloo (tests/test_bench_launcher.py).  It computes nothing: codes are a function of the global utterance index, the line it
+    produces says so in `metric` and `data`.  The N > 1 path has never run on hardware (no multi-GPU box has been available to any round);
+    this is what keeps it from failing on a typo the first time it does."""
+    micro_batch = 16
+
+    def __init__(self, arch, first_utt):
+        self.arch, self.first = arch, first_utt
+        self.calls = 0
+
+    def encode_decode(self, wav, n_q, use_scale=True):
+        B, T = wav.shape
+        tf = -(-T // self.arch.hop_length)
+        u = self.first + self.calls_base + torch.arange(B, dtype=torch.int64)
+        codes = (u[None, :, None] * 7 + torch.arange(n_q)[:, None, None] + torch.arange(tf)[None, None, :]) % 1024
+        self.calls_base += B
+        return dict(codes=codes.contiguous(), recon=torch.zeros(B, 1, T))
+
+    calls_base = 0
+
+    def new_step(self):
+        self.calls_base = 0
+
+    def set_profiling(self, on):
+        pass
+
+    def read_profile(self):
+        return []
+
+    def check_status(self):
+        pass
+
+    def work(self, B, T, n_q):
+        return dict(total_flops=1.0, conv_flops=1.0, conv_bytes=1.0, total_bytes=1.0, total_launches=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -622,14 +660,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    rehearsal = bool(int(os.environ.get("FC_BENCH_REHEARSAL", "0")))      # CPU rehearsal of the control flow (see _RehearsalEngine): never a measurement
+    if not rehearsal and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
+    if not rehearsal:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from funcodec_amd.config import arch_from_config, recipe_config
     from funcodec_amd.model import EncodecMI355X
@@ -638,24 +682,29 @@ def main():
 
     cfg = recipe_config(CONFIG)
     arch = arch_from_config(cfg)
-    model = EncodecMI355X(arch, f"cuda:{local_rank}")
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state(cfg, arch).items()})
-    eng = model.engine
-    eng.micro_batch = max(eng.micro_batch, MICRO_BATCH)      # one engine call per bench micro-batch
-
     # N = 1: Config B (16 utterances, one engine call).  N > 1: Config C (128 utterances per GPU, micro-batches of 32).
     utts_per_gpu = int(os.environ.get("FC_BENCH_UTTS", MICRO_BATCH if world == 1 else 128))     # freqcodec: 64 (configs[3])
     total_utts = utts_per_gpu * world
     lo, hi = shard_range(total_utts, rank, world)
     shard_sizes = [shard_range(total_utts, r, world)[1] - shard_range(total_utts, r, world)[0] for r in range(world)]
+    if rehearsal:
+        model, eng = None, _RehearsalEngine(arch, lo)
+    else:
+        model = EncodecMI355X(arch, f"cuda:{local_rank}")
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic_state(cfg, arch).items()})
+        eng = model.engine
+    eng.micro_batch = max(eng.micro_batch, MICRO_BATCH)      # one engine call per bench micro-batch
+    n_samples = int(os.environ.get("FC_BENCH_SAMPLES", SAMPLES)) if rehearsal else SAMPLES
     if world == 1:
-        wav = torch.from_numpy(synthetic_audio(hi - lo, SAMPLES, 1234)).cuda()
+        wav = torch.from_numpy(synthetic_audio(hi - lo, n_samples, 1234)).to(dev)
     else:   # per-rank seeds: no rank generates the whole 1024-utterance set
-        wav = torch.from_numpy(synthetic_audio(hi - lo, SAMPLES, 1234 + rank)).cuda()
+        wav = torch.from_numpy(synthetic_audio(hi - lo, n_samples, 1234 + rank)).to(dev)
     n_q = arch.num_quantizers
 
     def step():
         parts, r = [], None
+        if rehearsal:
+            eng.new_step()
         for i in range(0, wav.shape[0], MICRO_BATCH):      # one engine call per micro-batch; outputs as the reference returns them
             r = eng.encode_decode(wav[i:i + MICRO_BATCH], n_q, use_scale=True)
             parts.append(r["codes"])
@@ -667,7 +716,8 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not rehearsal:
+            torch.cuda.synchronize()
 
     eng.set_profiling(False)
     for _ in range(args.warmup):
@@ -680,7 +730,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.check_status()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(r["recon"]).all())
@@ -693,7 +743,8 @@ def main():
     if rank == 0 and not args.no_event_profile:
         prof_steps = max(1, min(args.profile_steps, args.steps))
         eng.set_profiling(True)
-        torch.cuda.synchronize()
+        fence_local = (lambda: None) if rehearsal else torch.cuda.synchronize
+        fence_local()
         for _ in range(prof_steps):
             for i in range(0, min(wav.shape[0], MICRO_BATCH), MICRO_BATCH):     # one micro-batch per profiled step
                 eng.encode_decode(wav[i:i + MICRO_BATCH], n_q, use_scale=True)
@@ -701,8 +752,8 @@ def main():
         eng.set_profiling(False)
 
     if rank == 0:
-        audio_s = total_utts * SAMPLES / 16000.0 * args.steps
-        work = eng.work(MICRO_BATCH, SAMPLES, n_q)
+        audio_s = total_utts * n_samples / 16000.0 * args.steps
+        work = eng.work(MICRO_BATCH, n_samples, n_q)
         nmb = utts_per_gpu / MICRO_BATCH                  # engine calls per step per GPU
         step_s = dt / args.steps
         out = {
@@ -720,7 +771,7 @@ def main():
                                     "encodec 16k-nq32ds640 (57.6M, synthetic seeded checkpoint), ")) +
                                    f"run_mod=inference (encode + 32-stage RVQ "
                                    f"+ decode), {utts_per_gpu} x 10 s utterances per GPU in micro-batches of {MICRO_BATCH}, n_q=32",
-                       "utterances_per_gpu": utts_per_gpu, "samples_per_utterance": SAMPLES, "micro_batch": MICRO_BATCH,
+                       "utterances_per_gpu": utts_per_gpu, "samples_per_utterance": n_samples, "micro_batch": MICRO_BATCH,
                        "global_utterances": total_utts,
                        "ranks_seen": dist.get_world_size() if world > 1 else 1,
                        "parallelism": f"utterance-sharded x{world}, all_gather(codes) over RCCL" if world > 1 else "single GPU"},
@@ -741,7 +792,16 @@ def main():
                            if (world == 1 and CONFIG == "ds640" and pmc_step_traffic()) else None},
             "timed_region": "in-engine HIP-event brackets OFF; the per-kernel table below is a separate pass",
         }
-        out["transfers"] = transfer_times(wav, r["codes"])
+        if rehearsal:
+            out["metric"] = "REHEARSAL of the control flow with a stand-in engine (FC_BENCH_REHEARSAL=1): not a measurement"
+            out["data"] = "none (stand-in engine)"
+            out["value"] = 0.0
+            exp_u = torch.arange(total_utts, dtype=torch.int64)
+            tf = codes.shape[2]
+            expect = (exp_u[None, :, None] * 7 + torch.arange(n_q)[:, None, None] + torch.arange(tf)[None, None, :]) % 1024
+            out["gather_ok"] = bool(torch.equal(codes, expect))
+        else:
+            out["transfers"] = transfer_times(wav, r["codes"])
         if prof:
             out.update(kernel_rooflines(prof, prof_steps))
             if "roofline" in out:
@@ -750,9 +810,9 @@ def main():
             out["config"]["scaling_base"] = ("efficiency is to be computed against secondary.config_c_shard_b128.value of the --gpus 1 line (same "
                                              "per-rank shape: 128 x 10 s in micro-batches of 32), NOT against the N = 1 contract value (Config B, "
                                              "16 utterances in one call)")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not rehearsal:
             out["cpu_baseline"] = cpu_baseline()
-        if world == 1 and CONFIG == "ds640" and not args.no_secondary:
+        if world == 1 and CONFIG == "ds640" and not args.no_secondary and not rehearsal:
             # the next scope rows, measured AFTER the headline timing so that they cannot disturb it
             sec = {}
             try:

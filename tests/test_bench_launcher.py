@@ -60,3 +60,25 @@ def test_roofline_objects_carry_both_fractions_and_the_traffic_ratio():
     if conv.get("traffic"):                       # the committed PMC passes know this instantiation
         assert conv["traffic_over_algorithmic"] == round(conv["traffic"] / conv["algorithmic_bytes_per_launch"], 2) > 1.0
     assert hbm["bound"] == "hbm" and abs(hbm["frac"] - 0.5) < 1e-6
+
+
+def test_the_whole_n_rank_flow_of_bench_main_runs_on_cpu_with_a_stand_in_engine():
+    """The N > 1 path of bench.py has never run on hardware (no multi-GPU box in any round).  FC_BENCH_REHEARSAL=1 swaps the engine for a
+    stand-in and runs everything else of main() for real -- self-launch, ranks from the environment, shard_range, per-rank inputs, the step
+    loop over micro-batches (2 + 2 + 1 here), gather_codes inside the step, barrier + max-over-ranks timing, ONE JSON line from rank 0 with
+    config.ranks_seen / scaling_base -- over gloo on CPU, and checks the gathered codes of all 10 utterances."""
+    env = {"FC_BENCH_REHEARSAL": "1", "FC_BENCH_UTTS": "5", "FC_BENCH_SAMPLES": "6400", "FC_BENCH_MICRO": "2"}
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], env_extra=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["ranks_seen"] == 2 and out["config"]["global_utterances"] == 10 and out["config"]["micro_batch"] == 2
+    assert "config_c_shard_b128" in out["config"]["scaling_base"]
+    assert out["gather_ok"] is True and "REHEARSAL" in out["metric"] and out["value"] == 0.0
+    # and the single-rank flow (no launcher, no gather)
+    r1 = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline"], env_extra=env)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    o1 = _json_lines(r1.stdout)[0]
+    assert o1["n_gpus"] == 1 and o1["gather_ok"] is True and o1["config"]["ranks_seen"] == 1
