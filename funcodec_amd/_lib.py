@@ -7,7 +7,7 @@ import os
 from . import build as _build
 
 FC_MAX_RATIOS = 8
-FC_ABI_VERSION = 5
+FC_ABI_VERSION = 6
 
 
 class FcArch(C.Structure):
@@ -24,6 +24,7 @@ class FcArch(C.Structure):
         ("ratios_f", C.c_int32 * FC_MAX_RATIOS),
         ("enc_conv_group_ratio", C.c_int32), ("dec_conv_group_ratio", C.c_int32), ("dec_tr_conv_group_ratio", C.c_int32),
         ("codec_dim", C.c_int32), ("codec_range", C.c_float),
+        ("q0_ds_ratio", C.c_int32),
     ]
 
 
@@ -73,6 +74,7 @@ SYMBOLS = {
     "fc_decode_codes": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     "fc_encode_decode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "fc_rvq_encode": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    "fc_q0_source_frames": (C.c_int, [C.c_int, _P]),
     "fc_layer_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "fc_layer_out_len": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "fc_lstm_forward": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),

@@ -45,6 +45,9 @@ class ArchSpec:
     encoder_hop_length: int = 320
     quantizer_sampling_rate: int = 16000
     use_ddp: bool = True
+    # > 1: the first stage quantises the nearest-neighbour half-rate sequence (ddp_core_vq.py:354-356,396-404; the value itself is not
+    # used by the reference beyond "> 1": it always halves)
+    q0_ds_ratio: int = 1
     # conv wrapper flavour (modules/normed_modules/conv.py): GroupNorm(1, C) after every conv, or weight-normalised convs /
     # plain convs without an output norm; causal = all padding on the left, transposed convs trimmed on the right only
     norm: str = "time_group_norm"
@@ -105,6 +108,17 @@ class ArchSpec:
 def _unsupported(key: str, value: Any, why: str = "") -> NotImplementedError:
     return NotImplementedError(
         f"config key {key}={value!r} is outside the MI355X hot-path scope (SURVEY.md §8){': ' + why if why else ''}")
+
+
+def _q0_ds_ratio(q: Dict[str, Any]) -> int:
+    """quantizer_conf.q0_ds_ratio (costume_quantizer.py:19,47 -> vq.py:55,83 -> ddp_core_vq.py:354-356).  Only the distributed quantiser
+    implements it: with use_ddp false the reference's constructor raises (core_vq.ResidualVectorQuantization takes no such keyword)."""
+    r = q.get("q0_ds_ratio", 1)
+    if not isinstance(r, int) or isinstance(r, bool) or r < 1:
+        raise _unsupported("quantizer_conf.q0_ds_ratio", r, "a positive integer")
+    if r > 1 and not q.get("use_ddp", True):
+        raise _unsupported("quantizer_conf.q0_ds_ratio with use_ddp: false", r, "only the distributed quantiser has a first-stage down-sampling")
+    return r
 
 
 def _check_seanet_conf(conf: Dict[str, Any], which: str) -> Dict[str, Any]:
@@ -204,8 +218,7 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
 
     ratios2 = shared("ratios", [[4, 1], [4, 1], [4, 2], [4, 1]])
     dimension = int(enc.get("dimension", 128))
-    if q.get("q0_ds_ratio", 1) != 1:
-        raise _unsupported("quantizer_conf.q0_ds_ratio", q.get("q0_ds_ratio"))
+    q0_ds_ratio = _q0_ds_ratio(q)
     # CostumeQuantizer's projection / tanh range (costume_quantizer.py:23-35), as for the time-domain codec
     codec_dim = q.get("codec_dim", None)
     codec_dim = dimension if codec_dim is None else int(codec_dim)
@@ -238,7 +251,7 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=codec_dim, num_quantizers=int(q.get("num_quantizers", 8)),
         codec_range=None if codec_range is None else float(codec_range),
         encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
-        use_ddp=bool(q.get("use_ddp", True)), norm=str(shared("norm", "weight_norm")), causal=bool(shared("causal", False)),
+        use_ddp=bool(q.get("use_ddp", True)), q0_ds_ratio=q0_ds_ratio, norm=str(shared("norm", "weight_norm")), causal=bool(shared("causal", False)),
         segment_dur=None if seg is None else float(seg), overlap_ratio=0.01 if ov is None else float(ov),
         model_type="freq_codec", n_fft=int(dc.get("n_fft", 512)), stft_hop=int(dc.get("hop_length", 160)),
         enc_conv_group_ratio=int(enc.get("conv_group_ratio", -1)), dec_conv_group_ratio=int(dec.get("conv_group_ratio", -1)),
@@ -307,8 +320,7 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     codec_range = q.get("codec_range", None)
     if codec_range is not None and not float(codec_range) > 0:
         raise _unsupported("quantizer_conf.codec_range", codec_range)
-    if q.get("q0_ds_ratio", 1) != 1:
-        raise _unsupported("quantizer_conf.q0_ds_ratio", q["q0_ds_ratio"])
+    q0_ds_ratio = _q0_ds_ratio(q)
     # decoder_conf values that differ from encoder_conf are refused (shared()), never silently ignored
     act_params = dict(shared("activation_params", {"alpha": 1.0}) or {})
     norm_params = dict(shared("norm_params", {}) or {})
@@ -342,6 +354,7 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         encoder_hop_length=int(q.get("encoder_hop_length", 320)),
         quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
         use_ddp=bool(q.get("use_ddp", True)),
+        q0_ds_ratio=q0_ds_ratio,
         norm=str(shared("norm", "weight_norm")),
         causal=bool(shared("causal", False)),
         segment_dur=None if segment_dur is None else float(segment_dur),
@@ -416,6 +429,8 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     `tinyfreq` / `tinyfreq640`: the same shapes with 4 base filters, 16-dim / 64-entry codebooks (small fixtures)."""
     if name.startswith("freqfuzz"):
         return fuzz_freq_recipe_config(int(name[8:]))
+    q0 = name.endswith("q0")                          # quantizer_conf.q0_ds_ratio = 2: first stage on the half-rate sequence
+    name = name[:-2] if q0 else name
     cd = name.endswith("cd")                          # CostumeQuantizer projection to codec_dim = 32 + tanh range (costume_quantizer.py:23-35)
     name = name[:-2] if cd else name
     wnc = name.endswith("wnc")                        # weight_norm + causal 2-D nets (conv.py:317-447 with causal = True)
@@ -453,6 +468,8 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
           "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 640 if ds640 else 320}
     if cd:
         qc.update(codec_dim=32, codec_range=2.0)
+    if q0:
+        qc.update(q0_ds_ratio=2)
     return {
         "input_size": 2 if angle else 3, "sampling_rate": 16000,
         "encoder": "encodec_seanet_encoder_2d", "encoder_conf": enc,
@@ -509,6 +526,12 @@ def recipe_config(name: str) -> Dict[str, Any]:
         return fuzz_recipe_config(int(name[4:]))
     if name.startswith(("freqmp", "tinyfreq", "freqfuzz")):
         return freq_recipe_config(name)
+    if name in ("tinyq0", "ds320q0", "ss320q0"):
+        # quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:354-356,396-404): first stage on the half-rate sequence.  "tinyq0" asks for 3:
+        # the reference halves whatever the value is, and so must the engine
+        cfg = recipe_config({"tinyq0": "tiny", "ds320q0": "ds320", "ss320q0": "ss320"}[name])
+        cfg["quantizer_conf"]["q0_ds_ratio"] = 3 if name == "tinyq0" else 2
+        return cfg
     if name in ("ds320cd64", "tinycd"):   # CostumeQuantizer with codec_dim != input_size and a tanh range (costume_quantizer.py:23-35)
         cfg = recipe_config("ds320" if name == "ds320cd64" else "tiny")
         cfg["quantizer_conf"]["codec_dim"] = 64 if name == "ds320cd64" else 32

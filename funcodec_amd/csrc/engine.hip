@@ -1523,7 +1523,10 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
     float* xq = (e->q_proj || ranged) ? cx.alloc<float>((size_t)B * Tf * Dc) : emb;
     float* quant_c = e->q_proj ? cx.alloc<float>((size_t)B * Tf * Dc) : quantized;       // quantised rows in codebook space
     float* qbdt_c = cx.alloc<float>((size_t)B * Dc * Tf);
-    cx.launches += 2 + (ranged ? 1 : 0);
+    // quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:396-404): stage 0 of frame t quantises frame q0_source_frame(t, Tf) (kernels.h)
+    const bool q0 = e->arch.q0_ds_ratio > 1;
+    int* q0map = q0 ? cx.alloc<int>((size_t)B * Tf) : nullptr;
+    cx.launches += 2 + (ranged ? 1 : 0) + (q0 ? 1 : 0);
     cx.rvq_flops += 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * Dc;
     if (!cx.dry && !cx.err) {
         if (last.T != Tf) return fail("internal: frame count mismatch");
@@ -1538,9 +1541,13 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
                 return fail("combine launch failed");
         }
         if (ranged && fc::launch_tanh_range(xq, (size_t)B * Tf * Dc, e->arch.codec_range, cx.st) != hipSuccess) return fail("tanh launch failed");
+        if (q0) {
+            if (Tf < 2) return fail("quantizer_conf.q0_ds_ratio > 1 needs at least 2 frames (the reference's F.interpolate(size=[Tf // 2]) raises on 0)");
+            if (fc::launch_q0_map(q0map, B, Tf, cx.st) != hipSuccess) return fail("q0 map launch failed");
+        }
         ProfSpan sp(e, cx, e->profiling ? e->prof_class(kRvqClass) : 0, 2.0 * B * Tf * (double)n_q * e->arch.codebook_size * Dc, 0.0);
         if (fc::launch_rvq_encode(xq, B * Tf, Dc, e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quant_c, qbdt_c,
-                                  sub_quants, Tf, cx.st) != hipSuccess)
+                                  sub_quants, Tf, cx.st, q0map) != hipSuccess)
             return fail("rvq launch failed (codebook size must be a multiple of 64, dim in {16,32,64,128,256,512})");
     }
     float* qbdt = qbdt_c;
@@ -1934,8 +1941,21 @@ int fc_rvq_encode(fc_engine* e, const float* x, int N, int n_q, int64_t* codes, 
     (void)workspace; (void)workspace_bytes;
     if (!x || !codes || N <= 0) return fail("bad argument");
     if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
+    int* q0map = nullptr;
+    if (e->arch.q0_ds_ratio > 1) {      // the rows are ONE utterance of N frames; the stage-0 source-row table lives in the caller's workspace
+        if (N < 2) return fail("quantizer_conf.q0_ds_ratio > 1 needs at least 2 frames");
+        if (!workspace || workspace_bytes < (size_t)N * sizeof(int)) return fail("fc_rvq_encode with q0_ds_ratio > 1 needs a workspace of N * 4 bytes");
+        q0map = (int*)workspace;
+        HIP_TRY(fc::launch_q0_map(q0map, 1, N, (hipStream_t)stream));
+    }
     HIP_TRY(fc::launch_rvq_encode(x, N, e->cdim(), e->arch.codebook_size, n_q, e->cb, e->cb_frag, e->enorm, codes, quantized,
-                                  nullptr, nullptr, N, (hipStream_t)stream));
+                                  nullptr, nullptr, N, (hipStream_t)stream, q0map));
+    return 0;
+}
+
+int fc_q0_source_frames(int Tf, int32_t* frames) {
+    if (Tf < 2 || !frames) return fail("fc_q0_source_frames: Tf >= 2 and a host buffer of Tf entries");
+    for (int t = 0; t < Tf; ++t) frames[t] = fc::q0_source_frame(t, Tf);
     return 0;
 }
 

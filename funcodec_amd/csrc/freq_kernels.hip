@@ -94,6 +94,12 @@ __global__ __launch_bounds__(256) void halo_rows_kernel(float* __restrict__ buf,
     const float* s = buf + ((size_t)b * Fp + halo + (srcf < 0 ? 0 : (srcf >= F ? F - 1 : srcf))) * C * T;
     const bool z = zero || srcf < 0 || srcf >= F;
     const size_t n = (size_t)C * T;
+    if ((n & 3) == 0) {                                   // rows of C * T floats start 16-byte aligned when C * T is a multiple of 4
+        const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n / 4; e += (size_t)gridDim.x * 256)
+            ((f32x4*)d)[e] = z ? zz : ((const f32x4*)s)[e];
+        return;
+    }
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) d[e] = z ? 0.f : s[e];
 }
 

@@ -124,7 +124,29 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
                              const float* enorm,
                              int64_t* codes /*[nq][N]*/, float* quant /*[N][D] or null*/,
                              float* quant_bdt /*[B][D][Tf] or null*/, float* subq /*[nq][B][D][Tf] or null*/,
-                             int Tf, hipStream_t st);
+                             int Tf, hipStream_t st, const int* src0 /* [N] stage-0 source rows (q0_ds_ratio > 1) or null */ = nullptr);
+
+// quantizer_conf.q0_ds_ratio > 1 (DistributedResidualVectorQuantization.forward, ddp_core_vq.py:396-404): the first stage quantises
+// F.interpolate(residual, size=[Tf // 2]) and its output (and indices) go back through F.interpolate(size=[Tf]), both mode "nearest"
+// -- whatever the ratio's value is, the reference halves.  Row-wise that is: stage 0 of frame t quantises frame q0_source_frame(t, Tf).
+// torch's nearest source index (ATen UpSample.h nearest_idx / UpSampleKernel.cpp HelperInterpNearest): min(int(floorf(dst * scale)),
+// in - 1) with scale = float(in) / out computed in fp32; out == 2 * in reduces to dst >> 1.  tests/test_host.py checks this function
+// against F.interpolate for every Tf in 2 .. 4096.
+__host__ __device__ inline int q0_source_frame(int t, int Tf) {
+    const int half = Tf / 2;
+    int j;                                              // half-rate frame that output frame t copies (up: half -> Tf)
+    if (Tf == 2 * half) j = t >> 1;
+    else {
+        const float up = (float)half / (float)Tf;
+        j = (int)floorf((float)t * up);
+        if (j > half - 1) j = half - 1;
+    }
+    const float down = (float)Tf / (float)half;          // input frame that half-rate frame j copied (down: Tf -> half)
+    int s = (int)floorf((float)j * down);
+    if (s > Tf - 1) s = Tf - 1;
+    return s;
+}
+hipError_t launch_q0_map(int* map /* [B][Tf] */, int B, int Tf, hipStream_t st);
 // codes [B][Tf][nq] (i64) -> emb [B][Tf][D] and/or emb_bdt [B][D][Tf]
 // status: host-visible engine status words (FC_STATUS_*), or null; an index outside [0, K) sets FC_STATUS_BAD_CODE
 hipError_t launch_rvq_decode(const int64_t* codes, int B, int Tf, int nq, int D, int K, const float* cb,

@@ -1110,13 +1110,15 @@ hipError_t launch_transpose_btd(const float* in, int B, int T, int D, float* out
 // RS = row sets of 16 rows per workgroup.  The stage is L2-bandwidth bound when one codebook load feeds only 16 rows
 // (every workgroup streams the whole 512 KiB stage codebook: 250 workgroups x 512 KiB = 128 MiB per stage at config B);
 // with RS = 2 the same registers feed two independent 16-row MFMA accumulators (same arithmetic per row).
-template <int D, int RS>
+// Q0: the stage-0 source-row table `src0` is honoured (quantizer_conf.q0_ds_ratio > 1); a template parameter so that the benchmark's
+// instantiations keep their register allocation (183 registers, no spill).
+template <int D, int RS, bool Q0 = false>
 __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict__ x, int N, int K, int nq,
                                                          const float* __restrict__ cb, const float* __restrict__ cbf,
                                                          const float* __restrict__ enorm,
                                                          int64_t* __restrict__ codes, float* __restrict__ quant,
                                                          float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf,
-                                                         int ablate) {
+                                                         int ablate, const int* __restrict__ src0) {
     constexpr int NQ4 = D / 16;
     constexpr int ROWS = 16 * RS;
     // residual rows, padded by 4 floats: the |x|^2 chains read R[r][32 j + i] from 64 lanes (r, j) at once -- with a row stride of
@@ -1136,7 +1138,9 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
     for (int e = tid; e < ROWS * D; e += 512) {
         const int r = e / D, d = e - r * D;
         const int n = row0 + r;
-        R[r][d] = n < N ? x[(size_t)n * D + d] : 0.f;
+        // src0 (quantizer_conf.q0_ds_ratio > 1, ddp_core_vq.py:396-404): stage 0 quantises the row its frame copies from the
+        // half-rate sequence; the residual update of that stage starts again from the row itself (below)
+        R[r][d] = n < N ? x[(size_t)(Q0 ? src0[n] : n) * D + d] : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < NEL; ++it) qreg[it] = 0.f;
@@ -1267,9 +1271,11 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
         for (int it = 0; it < NEL; ++it) {
             const int e = tid + 512 * it, r = e / D, d = e - r * D;
             if (ROWS * D % 512 != 0 && e >= ROWS * D) continue;
-            R[r][d] = R[r][d] - qv[it];
-            qreg[it] = qreg[it] + qv[it];
             const int n = row0 + r;
+            float res = R[r][d];
+            if (Q0 && i == 0 && n < N) res = x[(size_t)n * D + d];
+            R[r][d] = res - qv[it];
+            qreg[it] = qreg[it] + qv[it];
             if (subq && n < N && !(ablate & 4)) {
                 const int bb = n / Tf, t = n - bb * Tf;
                 const int Bn = N / Tf;
@@ -1294,12 +1300,13 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
 // Wide codebooks (D = 512, the SoundStream recipe): same arithmetic and the same argmax / update flow as rvq_encode_kernel,
 // but a (row, code) chain is fed in chunks of 256 dims -- the 2x fragment of the row (re-read from LDS per chunk) and the two
 // in-flight codebook fragments then fit the register file -- and the running quantised sum lives in registers instead of LDS.
-template <int D>
+template <int D, bool Q0 = false>
 __global__ __launch_bounds__(512) void rvq_encode_wide_kernel(const float* __restrict__ x, int N, int K, int nq,
                                                               const float* __restrict__ cb, const float* __restrict__ cbf,
                                                               const float* __restrict__ enorm,
                                                               int64_t* __restrict__ codes, float* __restrict__ quant,
-                                                              float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf) {
+                                                              float* __restrict__ quant_bdt, float* __restrict__ subq, int Tf,
+                                                              const int* __restrict__ src0) {
     static_assert(D % 256 == 0, "chunks of 256 dims");
     constexpr int NC = D / 256, CQ = 16, NEL = 16 * D / 512;
     __shared__ __attribute__((aligned(16))) float R[16][D];
@@ -1314,7 +1321,7 @@ __global__ __launch_bounds__(512) void rvq_encode_wide_kernel(const float* __res
 #pragma unroll
     for (int i2 = 0; i2 < NEL; ++i2) {
         const int e = tid + 512 * i2, r = e / D, d = e - r * D, n = row0 + r;
-        R[r][d] = n < N ? x[(size_t)n * D + d] : 0.f;
+        R[r][d] = n < N ? x[(size_t)(Q0 ? src0[n] : n) * D + d] : 0.f;       // Q0 / src0: see rvq_encode_kernel
         qreg[i2] = 0.f;
     }
     const int codes_per_wave = (K >> 3) < 16 ? 16 : (K >> 3);
@@ -1409,7 +1416,9 @@ __global__ __launch_bounds__(512) void rvq_encode_wide_kernel(const float* __res
         for (int i2 = 0; i2 < NEL; ++i2) {
             const int e = tid + 512 * i2, r = e / D, d = e - r * D, n = row0 + r;
             const float qv = cbi[(size_t)sel[r] * D + d];
-            R[r][d] = R[r][d] - qv;
+            float res = R[r][d];
+            if (Q0 && i == 0 && n < N) res = x[(size_t)n * D + d];
+            R[r][d] = res - qv;
             qreg[i2] = qreg[i2] + qv;
             if (subq && n < N) {
                 const int bb = n / Tf, t = n - bb * Tf, Bn = N / Tf;
@@ -1429,13 +1438,28 @@ __global__ __launch_bounds__(512) void rvq_encode_wide_kernel(const float* __res
     }
 }
 
+// quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:396-404): map[b * Tf + t] = b * Tf + q0_source_frame(t, Tf)   (kernels.h)
+__global__ __launch_bounds__(256) void q0_map_kernel(int* __restrict__ map, int Tf) {
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (t < Tf) map[(size_t)b * Tf + t] = b * Tf + q0_source_frame(t, Tf);
+}
+
+hipError_t launch_q0_map(int* map, int B, int Tf, hipStream_t st) {
+    if (B <= 0 || Tf < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(q0_map_kernel, dim3(ceil_div(Tf, 256), B), dim3(256), 0, st, map, Tf);
+    return hipGetLastError();
+}
+
 hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const float* cb, const float* cb_frag,
-                             const float* enorm, int64_t* codes, float* quant, float* quant_bdt, float* subq, int Tf, hipStream_t st) {
+                             const float* enorm, int64_t* codes, float* quant, float* quant_bdt, float* subq, int Tf, hipStream_t st,
+                             const int* src0) {
     if (N <= 0) return hipSuccess;
     if (K % 16 != 0 || (K > 128 && K % 128 != 0)) return hipErrorInvalidValue;
     if (D == 512) {
-        hipLaunchKernelGGL((rvq_encode_wide_kernel<512>), dim3(ceil_div(N, 16)), dim3(512), 0, st, x, N, K, nq, cb, cb_frag, enorm, codes,
-                           quant, quant_bdt, subq, Tf);
+        if (src0) hipLaunchKernelGGL((rvq_encode_wide_kernel<512, true>), dim3(ceil_div(N, 16)), dim3(512), 0, st, x, N, K, nq, cb, cb_frag, enorm,
+                                     codes, quant, quant_bdt, subq, Tf, src0);
+        else hipLaunchKernelGGL((rvq_encode_wide_kernel<512>), dim3(ceil_div(N, 16)), dim3(512), 0, st, x, N, K, nq, cb, cb_frag, enorm, codes,
+                           quant, quant_bdt, subq, Tf, src0);
         return hipGetLastError();
     }
     // two row sets per workgroup once there are enough rows to keep ~half the CUs busy that way (L2 traffic halves)
@@ -1451,14 +1475,16 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
         hipDeviceProp_t prop;
         n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    const bool two = D <= 128 && (two_env >= 0 ? (two_env != 0 && N >= 2048) : N > 16 * n_cus);
+    const bool two = !src0 && D <= 128 && (two_env >= 0 ? (two_env != 0 && N >= 2048) : N > 16 * n_cus);
     dim3 grid(ceil_div(N, two ? 32 : 16)), block(512);
 #define FC_RVQ_CASE(DD)                                                                                            \
     case DD:                                                                                                       \
         if (two) hipLaunchKernelGGL((rvq_encode_kernel<(DD <= 128 ? DD : 16), 2>), grid, block, 0, st, x, N, K, nq, cb, cb_frag, enorm, codes, quant, \
-                                    quant_bdt, subq, Tf, ablate);                                                  \
+                                    quant_bdt, subq, Tf, ablate, src0);                                            \
+        else if (src0) hipLaunchKernelGGL((rvq_encode_kernel<DD, 1, true>), grid, block, 0, st, x, N, K, nq, cb, cb_frag, enorm, codes, quant, quant_bdt, \
+                                subq, Tf, ablate, src0);                                                           \
         else hipLaunchKernelGGL((rvq_encode_kernel<DD, 1>), grid, block, 0, st, x, N, K, nq, cb, cb_frag, enorm, codes, quant, quant_bdt, \
-                                subq, Tf, ablate);                                                                 \
+                                subq, Tf, ablate, src0);                                                           \
         break;
     switch (D) {
         FC_RVQ_CASE(16)

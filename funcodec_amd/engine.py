@@ -92,6 +92,7 @@ class CodecEngine:
         a.dec_tr_conv_group_ratio = arch.dec_tr_conv_group_ratio
         a.codec_dim = arch.codebook_dim if arch.codebook_dim != arch.dimension else 0
         a.codec_range = float(arch.codec_range or 0.0)
+        a.q0_ds_ratio = int(arch.q0_ds_ratio)
         h = C.c_void_p()
         self._check(self.lib.fc_engine_create(C.byref(a), self.device.index, C.byref(h)))
         self._h = h
@@ -329,7 +330,9 @@ class CodecEngine:
             raise EngineError(f"rvq_encode: rows must have {self.arch.codebook_dim} dims, got {D}")
         codes = torch.empty((n_q, N), dtype=torch.int64, device=self.device)
         quant = torch.empty((N, D), dtype=torch.float32, device=self.device)
-        self._check(self.lib.fc_rvq_encode(self._h, _ptr(x), N, n_q, _ptr(codes), _ptr(quant), None, 0, self._stream()))
+        ws = torch.empty(N, dtype=torch.int32, device=self.device) if self.arch.q0_ds_ratio > 1 else None     # stage-0 source-row table
+        self._check(self.lib.fc_rvq_encode(self._h, _ptr(x), N, n_q, _ptr(codes), _ptr(quant), _ptr(ws) if ws is not None else None,
+                                           0 if ws is None else 4 * N, self._stream()))
         return codes, quant
 
     @_on_device

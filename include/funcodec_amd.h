@@ -26,8 +26,9 @@ extern "C" {
 #endif
 
 #define FC_MAX_RATIOS 8
-#define FC_ABI_VERSION 5     /* layout of fc_arch / fc_laura_arch.  Round 4 added entry points without changing a struct (fc_laura_set_persistent_step,
-                              * fc_debug_freq_features) and one more value of fc_arch.input_channels (2 = codec_domain mag_angle): still 5 */
+#define FC_ABI_VERSION 6     /* layout of fc_arch / fc_laura_arch.  6 (round 4): fc_arch.q0_ds_ratio appended; fc_arch.input_channels = 2 with
+                              * model_type 0 is the stereo time-domain codec.  (Round 4 also added entry points that changed no struct:
+                              * fc_laura_set_persistent_step, fc_debug_freq_features, fc_q0_source_frames.) */
 
 typedef struct fc_engine fc_engine;
 
@@ -61,9 +62,11 @@ typedef struct fc_arch {
     int32_t n_residual_layers;      /* residual blocks per stage (1 in the encodec recipes, 3 in the SoundStream recipe) */
     int32_t dilation_base;          /* block j of a stage dilates its k=3 conv by dilation_base**j (seanet_encoder.py:127-133) */
     /* ABI version 4: the STFT-domain codec (FreqCodec, funcodec/models/codec_freq.py:123-210; SEANetEncoder2d / SEANetDecoder2d,
-     * funcodec/models/encoder/seanet_encoder.py:252-363, decoder/seanet_decoder.py:244-360).  model_type 0 ignores the rest. */
+     * funcodec/models/encoder/seanet_encoder.py:252-363, decoder/seanet_decoder.py:244-360).  model_type 0 ignores the rest except input_channels. */
     int32_t model_type;             /* 0 = encodec (time domain), 1 = freq_codec (codec_domain [mag_phase, mag_phase] or [mag_angle, mag_angle]) */
-    int32_t input_channels;         /* encoder input / decoder output channels of the 2-D nets, which also names the codec_domain like the
+    int32_t input_channels;         /* model_type 0: audio channels, 1 (0 reads as 1) or 2 = stereo (config input_size / decoder_conf.channels;
+                                     * codec_basic.py:342-344,366: the volume scale is taken from the channel mean); wav buffers are [B][C][T].
+                                     * model_type 1: encoder input / decoder output channels of the 2-D nets, which also names the codec_domain like the
                                      * reference's input_size does (codec_freq.py:356-379): 3 = mag_phase (log-magnitude, phase re, phase im),
                                      * 2 = mag_angle (log-magnitude, torch.angle) */
     int32_t n_fft;                  /* 512  (model_conf.domain_conf.n_fft) */
@@ -78,6 +81,10 @@ typedef struct fc_arch {
     int32_t codec_dim;              /* quantizer_conf.codec_dim: 0 (or = dimension) = none; else the codebooks live in codec_dim dims behind
                                        input_proj / output_proj Linears (checkpoint keys quantizer.input_proj.*, quantizer.output_proj.*) */
     float   codec_range;            /* quantizer_conf.codec_range: 0 = none; else the quantiser input is tanh(x) * codec_range */
+    /* ABI version 6 */
+    int32_t q0_ds_ratio;            /* quantizer_conf.q0_ds_ratio (funcodec/modules/quantization/ddp_core_vq.py:354-356,396-404): <= 1 = off;
+                                       > 1: the FIRST quantiser stage sees the nearest-neighbour half-rate sequence (the reference halves
+                                       whatever the value is) and its output / indices are repeated back to Tf frames */
 } fc_arch;
 
 /* ---- lifetime ------------------------------------------------------------------------------------ */
@@ -164,9 +171,15 @@ int fc_engine_status(fc_engine* e, unsigned* flags);
 
 /* ---- per-op entry points (so tests can pin each kernel against torch.nn.functional) -------------- */
 /* DRVQ.forward on rows: x dev f32 [N,D], codebooks as loaded; codes dev i64 [n_q,N];
- * quantized dev f32 [N,D] or NULL. */
+ * quantized dev f32 [N,D] or NULL.  With fc_arch.q0_ds_ratio > 1 the rows are ONE utterance of N >= 2 frames and
+ * `workspace` must hold N * 4 bytes (the stage-0 source-row table); otherwise the workspace is unused. */
 int fc_rvq_encode(fc_engine* e, const float* x, int N, int n_q, int64_t* codes, float* quantized,
                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* HOST function, no GPU: frames[t] = the frame whose stage-0 code frame t receives when quantizer_conf.q0_ds_ratio > 1, i.e. the
+ * composition of the reference's two nearest-neighbour F.interpolate calls (ddp_core_vq.py:396-404: Tf -> Tf // 2 -> Tf) that the
+ * kernels apply as a row table.  Exported so that the restatement of torch's index arithmetic is tested against torch itself. */
+int fc_q0_source_frames(int Tf, int32_t* frames /* host, Tf entries */);
 
 /* One SConv1d / SConvTranspose1d of the plan, addressed by its checkpoint prefix (e.g.
  * "encoder.model.3.conv", "decoder.model.3.convtr"): y = GroupNorm(conv(pad(act(x)))) as the reference

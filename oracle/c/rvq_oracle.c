@@ -67,7 +67,31 @@ static float dot2_mfma_order(const float* x, const float* e, int D) {
 
 /* x [N][D] rows, cb [nq][K][D]; codes [nq][N] (int64), quant [N][D] (may be NULL).
  * Returns 0, or -1 on bad arguments. */
+int rvq_oracle_encode_src0(const float* x, int N, int D, int K, int nq, const float* cb, int64_t* codes, float* quant, const int32_t* src0);
 int rvq_oracle_encode(const float* x, int N, int D, int K, int nq, const float* cb, int64_t* codes, float* quant) {
+    return rvq_oracle_encode_src0(x, N, D, K, nq, cb, codes, quant, NULL);
+}
+
+/* torch's nearest-neighbour source index for F.interpolate(mode="nearest") on CPU (ATen/native/UpSample.h nearest_idx,
+ * cpu/UpSampleKernel.cpp HelperInterpNearest): scale = float(in) / out in fp32, src = min(int(floorf(dst * scale)), in - 1). */
+static int nearest_src(int dst, int in, int out) {
+    const float scale = (float)in / (float)out;
+    int src = (int)floorf((float)dst * scale);
+    return src < in - 1 ? src : in - 1;
+}
+
+/* quantizer_conf.q0_ds_ratio > 1, ddp_core_vq.py:396-404: stage 0 runs on F.interpolate(residual, size=[Tf // 2]) and its
+ * quantised output and indices return through F.interpolate(size=[Tf]).  Stage 0 is row-wise, so frame t ends up with the
+ * stage-0 result of frame src[t] = down[up[t]], where down[j] = nearest_src(j, Tf, Tf / 2) and up[t] = nearest_src(t, Tf / 2, Tf). */
+int rvq_oracle_q0_source(int Tf, int32_t* src) {
+    const int half = Tf / 2;
+    if (half < 1) return -1;
+    for (int t = 0; t < Tf; ++t) src[t] = nearest_src(nearest_src(t, half, Tf), Tf, half);
+    return 0;
+}
+
+/* src0 != NULL: stage 0 of row n quantises row src0[n] (q0_ds_ratio, above); every later stage and the residual are row n's own */
+int rvq_oracle_encode_src0(const float* x, int N, int D, int K, int nq, const float* cb, int64_t* codes, float* quant, const int32_t* src0) {
     if (D % 16 != 0 || N < 0) return -1;
     float* enorm = (float*)malloc(sizeof(float) * (size_t)nq * K);
     float* res = (float*)malloc(sizeof(float) * D);
@@ -78,11 +102,12 @@ int rvq_oracle_encode(const float* x, int N, int D, int K, int nq, const float* 
         for (int d = 0; d < D; ++d) out[d] = 0.f;
         for (int i = 0; i < nq; ++i) {
             const float* E = cb + (size_t)i * K * D;
-            const float xn = sq_norm_4chains(res, D);
+            const float* qin = (src0 && i == 0) ? x + (size_t)src0[n] * D : res;
+            const float xn = sq_norm_4chains(qin, D);
             float best = -INFINITY;
             int bi = 0;
             for (int k = 0; k < K; ++k) {
-                const float g = dot2_mfma_order(res, E + (size_t)k * D, D);
+                const float g = dot2_mfma_order(qin, E + (size_t)k * D, D);
                 volatile float t1 = xn - g;
                 volatile float t2 = t1 + enorm[(size_t)i * K + k];
                 const float dist = -t2;

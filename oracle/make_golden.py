@@ -84,6 +84,13 @@ CASES = [
     ("tinycd_b2_t900", "tinycd", 12, 1.0, "tones", 101, 2, 900, None),
     ("tinyrange_b2_t640", "tinyrange", 13, 1.0, "noise", 103, 2, 640, None),
     ("ds320cd64_b1_t8000", "ds320cd64", 0, 1.0, "noise", 102, 1, 8000, 8000),
+    # quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:354-356,396-404): first stage on the nearest-neighbour half-rate sequence; even and odd
+    # frame counts (126 / 127, 50 / 51), a ratio of 3 (the reference halves regardless), the 512-dim quantiser kernel (25 frames)
+    ("tinyq0_b3_t1003", "tinyq0", 7, 1.0, "tones", 111, 3, 1003, None),
+    ("tinyq0_b2_t1013", "tinyq0", 7, 1.0, "noise", 112, 2, 1013, None),
+    ("ds320q0_b1_t16000", "ds320q0", 0, 1.0, "noise", 113, 1, 16000, None),
+    ("ds320q0_b2_t16200_bw4000", "ds320q0", 0, 1.0, "tones", 114, 2, 16200, 4000),
+    ("ss320q0_b1_t8000", "ss320q0", 0, 1.0, "noise", 115, 1, 8000, None),
     # pseudo-random small architectures (funcodec_amd/config.py::fuzz_recipe_config): ratios like 3 / 5 / 8, kernel sizes 3 / 5 / 7,
     # compress 1 / 4, 1- and 2-layer LSTMs, dilation bases 1 / 3, ELU alpha 0.7, GroupNorm eps 1e-3, audio_normalize off ...
     ("fuzz2_b2_t5000", "fuzz2", 2, 1.0, "tones", 91, 2, 5000, None),       # GroupNorm, ratios 8,5,3,3, compress 4, 1-layer LSTM(256)
@@ -108,6 +115,8 @@ FREQ_CASES = [
     ("tinyfreqseg_b2_t6000", "tinyfreqseg", 8, "tones", 85, 2, 6000),
     # CostumeQuantizer's input / output projection (codec_dim = 32 != dimension = 16) and tanh range behind the 2-D encoder
     ("tinyfreqcd_b2_t2000", "tinyfreqcd", 9, "tones", 86, 2, 2000),
+    # q0_ds_ratio behind the 2-D encoder (the quantiser is the same CostumeQuantizer)
+    ("tinyfreqq0_b2_t2100", "tinyfreqq0", 9, "tones", 116, 2, 2100),
     # 2-D nets with weight_norm instead of GroupNorm, non-causal and causal (conv.py:317-447: causal time padding / right-only time trim)
     ("tinyfreqwn_b2_t2200", "tinyfreqwn", 10, "tones", 87, 2, 2200),
     ("tinyfreqwnc_b2_t2600", "tinyfreqwnc", 11, "tones", 88, 2, 2600),

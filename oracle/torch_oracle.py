@@ -220,9 +220,14 @@ class Oracle:
         residual = x
         out = torch.zeros_like(x)
         all_idx, all_sub = [], []
+        tt = x.shape[2]
+        q0_ds = qc.get("q0_ds_ratio", 1) > 1                      # ddp_core_vq.py:354-356
         for i in range(n_q):
             e = self.embed[i]
-            xi = residual.permute(0, 2, 1)                        # rearrange b d n -> b n d  (:318)
+            quant_in = residual
+            if q0_ds and i == 0:                                  # :395-397 (mode "nearest"; the reference halves whatever the ratio is)
+                quant_in = F.interpolate(quant_in, size=[tt // 2])
+            xi = quant_in.permute(0, 2, 1)                        # rearrange b d n -> b n d  (:318)
             shape = xi.shape
             flat = xi.reshape(-1, shape[-1])                      # preprocess (... d -> (...) d)
             embed_t = e.t()
@@ -230,6 +235,9 @@ class Oracle:
             ind = dist.max(dim=-1).indices
             ind = ind.view(*shape[:-1])
             quant = F.embedding(ind, e).permute(0, 2, 1)          # :190-192, :323
+            if q0_ds and i == 0:                                  # :404-406
+                quant = F.interpolate(quant, size=[tt])
+                ind = F.interpolate(ind.unsqueeze(1).float(), size=[tt]).squeeze(1).long()
             residual = residual - quant
             out = out + quant
             all_idx.append(ind)

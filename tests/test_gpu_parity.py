@@ -171,6 +171,27 @@ def test_rvq_two_row_set_form_is_bit_exact_vs_c_oracle():
     assert torch.equal(c16, codes[:, :4000]) and torch.equal(q16, quant[:4000])
 
 
+@pytest.mark.parametrize("cfg_name,seed,Tf,n_q", [("tinyq0", 7, 126, 6), ("tinyq0", 7, 127, 6), ("tinyq0", 7, 2, 6), ("tinyq0", 7, 3, 6),
+                                                  ("ds320q0", 0, 501, 8), ("ss320q0", 0, 77, 4)])
+def test_rvq_q0_ds_ratio_is_bit_exact_vs_c_oracle(cfg_name, seed, Tf, n_q):
+    """quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:396-404) in the fused quantiser: stage 0 of frame t runs on frame
+    fc_q0_source_frames(Tf)[t], every later stage on the frame's own residual.  Bit-exact against the plain-C restatement on every row
+    (16-, 128- and 512-dim kernels; even / odd / minimal frame counts); the same rows through an engine WITHOUT the option differ."""
+    import c_oracle
+    m = engine_for(cfg_name, seed)
+    cfg, arch, sd = state_for(cfg_name, seed)
+    cb = sd["quantizer.rq.model.embed"]
+    rng = np.random.Generator(np.random.PCG64(1000 + Tf))
+    x = (rng.standard_normal((Tf, arch.codebook_dim)) * 1.5).astype(np.float32)
+    codes, quant = m.engine.rvq_encode(torch.from_numpy(x), n_q)
+    cc, cq = c_oracle.rvq_encode_q0(x, cb, n_q, Tf)
+    assert np.array_equal(codes.cpu().numpy(), cc)
+    assert np.array_equal(quant.cpu().numpy(), cq)
+    if Tf > 3:
+        plain, _ = c_oracle.rvq_encode(x, cb, n_q)
+        assert not np.array_equal(plain, cc)
+
+
 def test_use_ddp_false_checkpoint_layout_against_reference_golden():
     """`use_ddp: false` checkpoints store one codebook per layer (`quantizer.rq.model.layers.{i}._codebook.embed`,
     core_vq.py:147-150,324-396).  Golden = core_vq.ResidualVectorQuantization itself, run in the build container."""

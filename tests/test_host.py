@@ -129,6 +129,8 @@ def test_arch_from_recipe_configs():
     lambda c: c["model_conf"].update(segment_dur=1.0, overlap_ratio=1.5),
     lambda c: c["quantizer_conf"].update(codec_dim=48),                          # a width the quantiser kernels are not built for
     lambda c: c["quantizer_conf"].update(codec_range=-1.0),
+    lambda c: c["quantizer_conf"].update(q0_ds_ratio=0),
+    lambda c: c["quantizer_conf"].update(q0_ds_ratio=2, use_ddp=False),          # only the distributed quantiser has it (core_vq.py takes no such keyword)
     lambda c: c["decoder_conf"].update(ratios=[8, 5, 4]),
 ])
 def test_out_of_scope_configs_are_refused(mut):
@@ -156,6 +158,8 @@ def test_config_defaults_follow_the_reference_constructor():
         cfg["decoder_conf"][key] = val
         with pytest.raises(NotImplementedError):
             arch_from_config(cfg)
+    assert arch_from_config(recipe_config("tinyq0")).q0_ds_ratio == 3 and arch_from_config(recipe_config("ds320")).q0_ds_ratio == 1
+    assert arch_from_config(recipe_config("tinyfreqq0")).q0_ds_ratio == 2
     a = arch_from_config(recipe_config("ds320cd64"))                    # CostumeQuantizer projection + tanh range
     assert (a.dimension, a.codebook_dim, a.codec_range) == (128, 64, 2.5)
     from funcodec_amd.plan import expected_tensors as _et

@@ -148,6 +148,46 @@ def test_c_oracle_rvq_matches_reference_golden(name):
     assert np.array_equal(emb, quant)
 
 
+@pytest.mark.parametrize("name", ["tinyq0_b3_t1003", "tinyq0_b2_t1013", "ds320q0_b2_t16200_bw4000"])
+def test_c_oracle_q0_ds_ratio_matches_reference_golden(name):
+    """quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:396-404): the plain-C quantiser with its own restatement of torch's nearest-
+    neighbour index arithmetic reproduces the real reference's indices and quantised vectors from the reference's encoder output
+    (even and odd frame counts; q0_ds_ratio 3 behaves like 2)."""
+    import c_oracle
+    from helpers import state_for
+    c = MAN["cases"][name]
+    g = golden(name)
+    cfg, arch, sd = state_for(c["config"], c["weight_seed"], c["codebook_decay"])
+    assert arch.q0_ds_ratio > 1
+    enc = g["encoder_out"]                                  # [B, Tf, D]
+    B, Tf, D = enc.shape
+    codes, quant = c_oracle.rvq_encode_q0(enc.reshape(-1, D), sd["quantizer.rq.model.embed"], c["n_q"], Tf)
+    assert np.array_equal(codes.reshape(c["n_q"], B, Tf), g["indices"].astype(np.int64))
+    assert np.array_equal(quant.reshape(B, Tf, D), g["quantized"])
+    # stage 0 really is at half rate: frames 2j and 2j + 1 of an even-length utterance share their first index
+    if Tf % 2 == 0:
+        i0 = g["indices"][0]
+        assert np.array_equal(i0[:, 0::2], i0[:, 1::2])
+
+
+def test_q0_source_frames_restate_torch_nearest_interpolate():
+    """The row table the kernels use (C ABI fc_q0_source_frames, host-only) and the C oracle's own version against torch itself:
+    F.interpolate(F.interpolate(arange(Tf), size=[Tf // 2]), size=[Tf]) for every Tf in 2 .. 2100 and a few large ones."""
+    import ctypes as C
+    import c_oracle
+    import torch.nn.functional as F
+    from funcodec_amd import _lib
+    lib = _lib.load()
+    for Tf in list(range(2, 2101)) + [4095, 4096, 4097, 10001, 65535]:
+        a = torch.arange(Tf, dtype=torch.float32)[None, None]
+        want = F.interpolate(F.interpolate(a, size=[Tf // 2]), size=[Tf])[0, 0].long().numpy()
+        out = (C.c_int32 * Tf)()
+        assert lib.fc_q0_source_frames(Tf, out) == 0
+        assert np.array_equal(np.frombuffer(out, np.int32), want), Tf
+        assert np.array_equal(c_oracle.q0_source(Tf), want), Tf
+    assert lib.fc_q0_source_frames(1, (C.c_int32 * 1)()) != 0
+
+
 def test_c_oracle_small_dims_and_ties():
     """D=16/K=64 (the tiny config) and a planted exact tie: the first index must win."""
     import c_oracle
