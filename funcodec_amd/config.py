@@ -303,9 +303,11 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
             raise _unsupported(f"encoder_conf.{key} != decoder_conf.{key}", (a, b))
         return a
 
+    # audio channels: the encoder's first conv takes `input_size` channels (gan_speech_codec.py:318-320, seanet_encoder.py:99), the decoder's
+    # last conv emits decoder_conf.channels; Encodec._encode asserts <= 2 (codec_basic.py:344).  The two must agree for an encode -> decode model.
     input_size = cfg.get("input_size", 1)
-    if input_size != 1 or dec.get("channels", 1) != 1:
-        raise _unsupported("input_size/channels", (input_size, dec.get("channels", 1)), "mono only")
+    if input_size not in (1, 2) or dec.get("channels", 1) != input_size:
+        raise _unsupported("input_size/channels", (input_size, dec.get("channels", 1)), "1 / 1 (mono) or 2 / 2 (stereo)")
     if m.get("codec_domain", "time") not in ("time", None):
         raise _unsupported("model_conf.codec_domain", m["codec_domain"])
     if m.get("bypass_quantizer", False):
@@ -332,7 +334,7 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     ratios = tuple(int(r) for r in shared("ratios", [8, 5, 4, 2]))
     arch = ArchSpec(
         sample_rate=int(m.get("target_sample_hz", 24000)),
-        input_channels=1,
+        input_channels=int(input_size),
         audio_normalize=bool(m.get("audio_normalize", True)),
         n_filters=int(shared("n_filters", 32)),
         dimension=int(enc.get("dimension", 128)),
@@ -526,6 +528,13 @@ def recipe_config(name: str) -> Dict[str, Any]:
         return fuzz_recipe_config(int(name[4:]))
     if name.startswith(("freqmp", "tinyfreq", "freqfuzz")):
         return freq_recipe_config(name)
+    if name in ("tinyst", "ds320st", "tinystwn", "ds320stseg"):
+        # stereo (the reference's "48 kHz" flavour, seanet_encoder.py:63-65: channels = 2): input_size 2, decoder_conf.channels 2; volume scale
+        # from the channel mean (codec_basic.py:366-371).  "tinystwn": weight_norm causal convs; "ds320stseg": segmented overlap-add
+        cfg = recipe_config({"tinyst": "tiny", "ds320st": "ds320", "tinystwn": "tinywn", "ds320stseg": "ds320seg"}[name])
+        cfg["input_size"] = 2
+        cfg["decoder_conf"]["channels"] = 2
+        return cfg
     if name in ("tinyq0", "ds320q0", "ss320q0"):
         # quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:354-356,396-404): first stage on the half-rate sequence.  "tinyq0" asks for 3:
         # the reference halves whatever the value is, and so must the engine

@@ -139,6 +139,8 @@ struct fc_engine {
     ConvLayer q_in, q_out;                                                 // CostumeQuantizer.input_proj / output_proj as k = 1 GEMMs (codec_dim != dimension)
     bool q_proj = false;
     int cdim() const { return q_proj ? arch.codec_dim : arch.dimension; }
+    // audio channels of the time-domain codec (wav / recon buffers are [B][C][T]); FreqCodec is mono (codec_freq.py squeezes dim 1)
+    int audio_ch() const { return arch.model_type == 0 && arch.input_channels == 2 ? 2 : 1; }
     std::vector<std::vector<ConvLayer>> dec_up_phases;                    // decoder stage s: one transposed 1-D GEMM per frequency phase
     int halo2 = 3;                                                        // frequency halo rows of the 2-D activations
     float* win2 = nullptr;                                                // squared Hann window [n_fft] (istft envelope)                       // "encoder.model.1" -> block (fc_resblock_forward)
@@ -428,7 +430,7 @@ void build_plan(fc_engine* e) {
     };
     // ---- encoder
     int idx = 0, mult = 1;
-    e->enc_first = mk_conv(name("encoder", idx, ".conv"), 1, nf, a.kernel_size, 1);
+    e->enc_first = mk_conv(name("encoder", idx, ".conv"), e->audio_ch(), nf, a.kernel_size, 1);
     idx++;
     e->enc_stages.resize(a.n_ratios);
     for (int s = 0; s < a.n_ratios; ++s) {
@@ -486,7 +488,7 @@ void build_plan(fc_engine* e) {
         mult /= 2;
     }
     idx++;
-    e->dec_last = mk_conv(name("decoder", idx, ".conv"), nf, 1, a.last_kernel_size, 1, false, true);
+    e->dec_last = mk_conv(name("decoder", idx, ".conv"), nf, e->audio_ch(), a.last_kernel_size, 1, false, true);
 
     // ---- conv wrapper flavour of every SConv1d / SConvTranspose1d of the nets (conv.py:20-56)
     {
@@ -1510,7 +1512,7 @@ int do_encode(fc_engine* e, Ctx& cx, const float* wav, int T, int n_q, int64_t* 
         sc = scale ? scale : cx.alloc<float>(B);
         cx.launches++;
         if (!cx.dry && !cx.err) {
-            if (fc::launch_volume(wav, B, T, sc, cx.st) != hipSuccess) return fail("volume kernel launch failed");
+            if (fc::launch_volume(wav, B, e->audio_ch(), T, sc, cx.st) != hipSuccess) return fail("volume kernel launch failed");
         }
     }
     Act last = e->arch.model_type == 1 ? run_encoder_2d(e, cx, wav, T, sc) : run_encoder(e, cx, wav, T, sc);
@@ -1573,8 +1575,9 @@ int do_decode(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf, const float* sc
     cx.launches++;
     if (!cx.dry && !cx.err) {
         if (out_len > last.T) return fail("out_len exceeds Tf*hop");
-        // final GroupNorm apply (decoder.model.N.conv.norm has C = 1), x scale (codec_basic.py:406-407), trim (:711)
-        if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, scale, cx.B, 1, last.T, out_len, wav, out_len, 0, 1, cx.st) != hipSuccess)
+        // final GroupNorm apply (decoder.model.N.conv.norm has C = audio channels), x scale (codec_basic.py:406-407), trim (:711)
+        const int C = e->audio_ch();
+        if (fc::launch_combine(src_of(last), fc::Src(), 0, 1.f, scale, cx.B, C, last.T, out_len, wav, (long long)C * out_len, out_len, 1, cx.st) != hipSuccess)
             return fail("combine launch failed");
     }
     return cx.err;
@@ -1644,6 +1647,8 @@ int fc_engine_create(const fc_arch* arch, int device, fc_engine** out) {
     for (int i = 0; i < arch->n_ratios; ++i)
         if (arch->ratios[i] < 1) return fail("ratios must be >= 1");
     if (arch->model_type != 0 && arch->model_type != 1) return fail("fc_arch.model_type must be 0 (encodec) or 1 (freq_codec, mag_phase)");
+    if (arch->model_type == 0 && (arch->input_channels < 0 || arch->input_channels > 2))
+        return fail("encodec: input_channels must be 1 (0 reads as 1) or 2 (stereo; the reference asserts channels <= 2, codec_basic.py:344)");
     if (arch->model_type == 1) {
         if (arch->norm_type != 0 && arch->norm_type != 1) return fail("freq_codec: norm must be time_group_norm or weight_norm");
         if (arch->input_channels != 3 && arch->input_channels != 2)

@@ -114,7 +114,7 @@ hipError_t launch_combine(const Src& s0, const Src& s1, int elu, float alpha, co
 hipError_t launch_tanh_range(float* x, size_t n, float range, hipStream_t st);
 
 // scale[b] = 1e-8 + sqrt(mean_t x[b][t]^2)
-hipError_t launch_volume(const float* wav, int B, int T, float* scale, hipStream_t st);
+hipError_t launch_volume(const float* wav /* [B][C][T], C = 1 | 2 */, int B, int C, int T, float* scale, hipStream_t st);
 
 // [B][T][D] -> [B][D][T]
 hipError_t launch_transpose_btd(const float* in, int B, int T, int D, float* out, hipStream_t st);

@@ -84,6 +84,8 @@ class CodecEngine:
         a.dilation_base = arch.dilation_base
         a.model_type = {"encodec": 0, "freq_codec": 1}[arch.model_type]
         a.input_channels = arch.input_channels
+        # audio channels of the time-domain codec (stereo: wav / recon tensors are [B,2,T]); FreqCodec is mono
+        self.channels = 2 if (arch.model_type == "encodec" and arch.input_channels == 2) else 1
         a.n_fft = arch.n_fft
         a.stft_hop = arch.stft_hop
         for i, r in enumerate(arch.ratios_f):
@@ -202,6 +204,15 @@ class CodecEngine:
     def _dev(self, t: torch.Tensor, dtype) -> torch.Tensor:
         return t.to(device=self.device, dtype=dtype).contiguous()
 
+    def _wav_in(self, wav: torch.Tensor) -> torch.Tensor:
+        """[B,T] (mono engines) or [B,C,T] with C = the model's audio channels, on the device, contiguous fp32."""
+        wav = self._dev(wav, torch.float32)
+        if wav.dim() == 2 and self.channels == 1:
+            return wav
+        if wav.dim() != 3 or wav.shape[1] != self.channels:
+            raise EngineError(f"wav must be [B,{self.channels},T]" + (" or [B,T]" if self.channels == 1 else "") + f", got {tuple(wav.shape)}")
+        return wav
+
     # -- hot path ------------------------------------------------------------------------------
     @staticmethod
     def _cat(parts, dims):
@@ -214,9 +225,9 @@ class CodecEngine:
 
     @_on_device
     def encode(self, wav: torch.Tensor, n_q: int, want_sub_quants: bool = True, want_enc_out: bool = False):
-        """wav [B,T] -> dict(codes [n_q,B,Tf] i64, quantized [B,Tf,D], sub_quants [n_q,B,D,Tf], scale [B,1]|None)."""
-        wav = self._dev(wav, torch.float32)
-        B, T = wav.shape
+        """wav [B,T] (or [B,C,T]) -> dict(codes [n_q,B,Tf] i64, quantized [B,Tf,D], sub_quants [n_q,B,D,Tf], scale [B,1]|None)."""
+        wav = self._wav_in(wav)
+        B, T = wav.shape[0], wav.shape[-1]
         if B > self.micro_batch:
             parts = [self.encode(wav[i:i + self.micro_batch], n_q, want_sub_quants, want_enc_out)
                      for i in range(0, B, self.micro_batch)]
@@ -236,8 +247,8 @@ class CodecEngine:
 
     @_on_device
     def encode_decode(self, wav: torch.Tensor, n_q: int, use_scale: bool = True, want_sub_quants: bool = True):
-        wav = self._dev(wav, torch.float32)
-        B, T = wav.shape
+        wav = self._wav_in(wav)
+        B, T = wav.shape[0], wav.shape[-1]
         if B > self.micro_batch:
             parts = [self.encode_decode(wav[i:i + self.micro_batch], n_q, use_scale, want_sub_quants)
                      for i in range(0, B, self.micro_batch)]
@@ -248,7 +259,7 @@ class CodecEngine:
         quant = torch.empty((B, Tf, D), dtype=torch.float32, device=dev)
         subq = torch.empty((n_q, B, self.arch.codebook_dim, Tf), dtype=torch.float32, device=dev) if want_sub_quants else None
         scale = torch.empty((B,), dtype=torch.float32, device=dev) if self.arch.audio_normalize else None
-        recon = torch.empty((B, 1, min(T, self.decoded_samples(Tf))), dtype=torch.float32, device=dev)   # like recon[:, :, :T] of the reference
+        recon = torch.empty((B, self.channels, min(T, self.decoded_samples(Tf))), dtype=torch.float32, device=dev)   # like recon[:, :, :T] of the reference
         ws = self._workspace(B, T)
         self._check(self.lib.fc_encode_decode(self._h, _ptr(wav), B, T, n_q, int(use_scale), _ptr(codes), _ptr(quant),
                                               _ptr(subq), _ptr(scale), _ptr(recon), _ptr(ws), ws.numel(), self._stream()))
@@ -264,7 +275,7 @@ class CodecEngine:
             parts = [self.decode_codes(tokens[i:i + self.micro_batch]) for i in range(0, B, self.micro_batch)]
             return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
         L = self.decoded_samples(Tf)
-        wav = torch.empty((B, 1, L), dtype=torch.float32, device=self.device)
+        wav = torch.empty((B, self.channels, L), dtype=torch.float32, device=self.device)
         emb = torch.empty((B, Tf, self.arch.dimension), dtype=torch.float32, device=self.device)
         ws = self._workspace(B, Tf * self.hop_length)
         self._check(self.lib.fc_decode_codes(self._h, _ptr(tokens), B, Tf, n_q, L, _ptr(wav), _ptr(emb), _ptr(ws), ws.numel(),
@@ -285,7 +296,7 @@ class CodecEngine:
         L = self.decoded_samples(Tf)
         out_len = L if out_len is None else int(out_len)
         sc = None if scale is None else self._dev(scale.reshape(-1), torch.float32)
-        wav = torch.empty((B, 1, out_len), dtype=torch.float32, device=self.device)
+        wav = torch.empty((B, self.channels, out_len), dtype=torch.float32, device=self.device)
         ws = self._workspace(B, Tf * self.hop_length)
         self._check(self.lib.fc_decode_emb(self._h, _ptr(emb), _ptr(sc), B, Tf, out_len, _ptr(wav), _ptr(ws), ws.numel(),
                                            self._stream()))
@@ -295,7 +306,8 @@ class CodecEngine:
     def overlap_add(self, frames, stride: int, out_len: Optional[int] = None) -> torch.Tensor:
         """_linear_overlap_add (codec_basic.py:77-116) of decoded segments: frames = list of [B,1,L_f] device tensors
         (frame f starts at f*stride) -> [B,1,out_len or total]."""
-        frames = [self._dev(f.reshape(f.shape[0], -1), torch.float32) for f in frames]
+        shape = tuple(frames[0].shape[:-1]) if frames[0].dim() == 3 else (frames[0].shape[0], 1)      # [B,C]: every channel row is overlap-added alone
+        frames = [self._dev(f.reshape(-1, f.shape[-1]), torch.float32) for f in frames]
         B = frames[0].shape[0]
         lens = [int(f.shape[1]) for f in frames]
         total = stride * (len(frames) - 1) + lens[-1]
@@ -305,7 +317,7 @@ class CodecEngine:
         out = torch.empty((B, 1, out_len), dtype=torch.float32, device=self.device)
         self._check(self.lib.fc_overlap_add(_ptr(ptrs), _ptr(lens_d), len(frames), B, lens[0], int(stride), out_len, _ptr(out),
                                             self._stream()))
-        return out
+        return out.view(*shape, out_len)
 
     def debug_freq_features(self, buf: Optional[torch.Tensor], mode: int) -> None:
         """Test hook (fc_debug_freq_features): the next encode / encode_decode call of this thread hands its STFT-domain feature tensor

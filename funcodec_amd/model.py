@@ -43,14 +43,13 @@ class EncodecMI355X:
         self.engine.load_state_dict(state)
 
     # -- helpers -------------------------------------------------------------------------------
-    @staticmethod
-    def _as_b1t(speech: torch.Tensor) -> torch.Tensor:
+    def _as_bct(self, speech: torch.Tensor) -> torch.Tensor:
         if speech.dim() == 2:
             speech = speech.unsqueeze(1)
         assert speech.dim() == 3, "speech must be [B,T] or [B,C,T]"          # codec_basic.py:342
         assert 0 < speech.shape[1] <= 2                                       # codec_basic.py:344
-        if speech.shape[1] != 1:
-            raise NotImplementedError("stereo input is outside the MI355X hot-path scope (SURVEY.md §8)")
+        if speech.shape[1] != self.engine.channels:      # the reference's first conv would raise on the channel mismatch
+            raise ValueError(f"this model takes {self.engine.channels}-channel audio (config input_size), got {speech.shape[1]} channels")
         return speech
 
     # -- Encodec._encode / _decode with segment_dur set (codec_basic.py:334-359,382-396,77-116) --
@@ -60,7 +59,7 @@ class EncodecMI355X:
         reference's _decode, every frame is decoded to its FULL length ceil(len/hop)*hop (longer than the segment when the
         segment length is not a multiple of the hop), the triangle window is sized from the first decoded frame, and the
         overlap-add result is trimmed to the input length last (fc_overlap_add)."""
-        B, T = wav.shape
+        B, T = wav.shape[0], wav.shape[-1]
         seg, stride = self.arch.segment_length, self.arch.segment_stride
         offsets = list(range(0, T, stride))
         lens = [min(seg, T - o) for o in offsets]
@@ -69,7 +68,7 @@ class EncodecMI355X:
         for i, n in enumerate(lens):
             by_len.setdefault(n, []).append(i)
         for n, ids in by_len.items():
-            stack = torch.cat([wav[:, offsets[i]:offsets[i] + n] for i in ids], 0).contiguous()   # [len(ids)*B, n]
+            stack = torch.cat([wav[..., offsets[i]:offsets[i] + n] for i in ids], 0).contiguous()   # [len(ids)*B, (C,) n]
             r = self.engine.encode(stack, n_q)
             rec = None
             if need_recon:
@@ -90,9 +89,9 @@ class EncodecMI355X:
     @torch.no_grad()
     def inference(self, speech: torch.Tensor, need_recon: bool = True, bit_width: int = None,
                   use_scale: bool = True) -> Dict[str, torch.Tensor]:
-        speech = self._as_b1t(speech)
+        speech = self._as_bct(speech)
         n_q = self.arch.num_quantizers_for_bandwidth(bit_width)
-        wav = speech[:, 0, :]
+        wav = speech[:, 0, :] if self.engine.channels == 1 else speech
         if self.arch.segment_length is not None:
             wav = wav.to(self.device, torch.float32)
             return self._inference_segmented(wav, n_q, need_recon, use_scale)

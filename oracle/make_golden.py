@@ -84,6 +84,11 @@ CASES = [
     ("tinycd_b2_t900", "tinycd", 12, 1.0, "tones", 101, 2, 900, None),
     ("tinyrange_b2_t640", "tinyrange", 13, 1.0, "noise", 103, 2, 640, None),
     ("ds320cd64_b1_t8000", "ds320cd64", 0, 1.0, "noise", 102, 1, 8000, 8000),
+    # stereo models (input_size 2, decoder_conf.channels 2; codec_basic.py:342-344,366: volume scale from the channel mean): channel c of
+    # utterance b is row 2 b + c of the seeded mono generator
+    ("tinyst_b3_t1003", "tinyst", 14, 1.0, "tones", 121, 3, 1003, None),
+    ("tinystwn_b2_t777", "tinystwn", 15, 1.0, "noise", 122, 2, 777, None),
+    ("ds320st_b2_t16000", "ds320st", 0, 1.0, "noise", 123, 2, 16000, None),
     # quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:354-356,396-404): first stage on the nearest-neighbour half-rate sequence; even and odd
     # frame counts (126 / 127, 50 / 51), a ratio of 3 (the reference halves regardless), the 512-dim quantiser kernel (25 frames)
     ("tinyq0_b3_t1003", "tinyq0", 7, 1.0, "tones", 111, 3, 1003, None),
@@ -141,6 +146,8 @@ SEG_CASES = [
     # segment length 8000 is NOT a multiple of the hop 640: frames decode to 8320 samples, the window and the overlap
     # contributions come from the untrimmed frames (codec_basic.py:382-396)
     ("ds640seg_b2_t20000", "ds640seg", 0, "tones", 42, 2, 20000),
+    # stereo + segmented: frames are [B, 2, n] slices, the overlap-add runs per channel row
+    ("ds320stseg_b2_t20000", "ds320stseg", 0, "tones", 43, 2, 20000),
 ]
 
 
@@ -196,10 +203,12 @@ def main():
             if key not in cache:
                 cache[key] = build_reference(cfg_name, wseed, decay, tmp)
             s2t, cfg, sd = cache[key]
-            wav = case_audio(akind, aseed, B, T)
-            x = torch.from_numpy(wav)
-            idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=bw, use_scale=True, run_mod="inference")
-            idx_e, _, _, _ = s2t(x.unsqueeze(1), bit_width=bw, run_mod="encode")
+            C = int(cfg.get("input_size", 1))              # 2 = stereo: [B, 2, T], channel c of utterance b = row b * 2 + c of the mono generator
+            wav = case_audio(akind, aseed, B * C, T)
+            x3 = torch.from_numpy(wav).reshape(B, C, T)
+            x = x3 if C > 1 else x3[:, 0]
+            idx, embs, recon, subs = s2t(x3, bit_width=bw, use_scale=True, run_mod="inference")
+            idx_e, _, _, _ = s2t(x3, bit_width=bw, run_mod="encode")
             assert torch.equal(idx[0], idx_e[0])
             quant, scale = embs[0]
             # decode path from the reference's own indices: [B,Tf,nq]
@@ -208,7 +217,7 @@ def main():
             _, _, recon_emb, _ = s2t(quant, run_mod="decode_emb")
             # intermediate: encoder output from the reference modules
             with torch.no_grad():
-                emb_ref, scale_ref = s2t.model._encode_frame(x.unsqueeze(1))
+                emb_ref, scale_ref = s2t.model._encode_frame(x3)
 
             # ---- pin the restated oracle against the reference, bit for bit -----------------
             orc = Oracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
@@ -231,6 +240,8 @@ def main():
             manifest["cases"][name] = dict(config=cfg_name, weight_seed=wseed, codebook_decay=decay,
                                            audio_kind=akind, audio_seed=aseed, batch=B, samples=T,
                                            bit_width=bw, n_q=int(idx[0].shape[0]), frames=int(idx[0].shape[2]))
+            if C > 1:
+                manifest["cases"][name]["channels"] = C
             print(f"[golden] {name}: idx{tuple(idx[0].shape)} recon{tuple(recon.shape)} oracle==reference OK")
 
         # ---- segmented overlap-add mode (model_conf.segment_dur, codec_basic.py:334-359,382-396): 0.5 s frames, 10 % overlap
@@ -238,8 +249,10 @@ def main():
             if only is not None and name not in only:
                 continue
             s2t, cfg, sd = build_reference(cfg_name, wseed, 1.0, tmp)
-            x = torch.from_numpy(synthetic_audio(B, T, aseed, akind))
-            idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=None, use_scale=True, run_mod="inference")
+            C = int(cfg.get("input_size", 1))
+            x3 = torch.from_numpy(synthetic_audio(B * C, T, aseed, akind)).reshape(B, C, T)
+            x = x3 if C > 1 else x3[:, 0]
+            idx, embs, recon, subs = s2t(x3, bit_width=None, use_scale=True, run_mod="inference")
             assert len(idx) == 3 and recon.shape[-1] == T
             orc = Oracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
             o = orc.inference(x, bit_width=None, use_scale=True)
@@ -254,6 +267,8 @@ def main():
             manifest["cases"][name] = dict(kind="segmented", config=cfg_name, weight_seed=wseed, codebook_decay=1.0,
                                            audio_kind=akind, audio_seed=aseed, batch=B, samples=T, bit_width=None,
                                            n_q=int(idx[0].shape[0]), frames=[int(i.shape[2]) for i in idx])
+            if C > 1:
+                manifest["cases"][name]["channels"] = C
             print(f"[golden] {name}: {len(idx)} frames {[tuple(i.shape) for i in idx]} oracle==reference OK")
 
         # ---- `use_ddp: false` quantiser (core_vq.ResidualVectorQuantization, core_vq.py:324-396): the CostumeQuantizer wrapper
@@ -326,7 +341,7 @@ def main():
             grabbed = {}
             hook = s2t.model.encoder.register_forward_pre_hook(lambda mod, args: grabbed.__setitem__("features", args[0].detach().clone()))
             with torch.no_grad():
-                emb_ref, scale_ref = s2t.model._encode_frame(x.unsqueeze(1))
+                emb_ref, scale_ref = s2t.model._encode_frame(x3)
             hook.remove()
             assert torch.equal(o["encoder_out"], emb_ref), f"{name}: oracle encoder != reference"
             assert torch.equal(o["features"], grabbed["features"]), f"{name}: oracle features != the reference encoder's input"

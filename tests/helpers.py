@@ -68,9 +68,12 @@ def freq_oracle_for(cfg_name, seed):
     return FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
 
 
-def audio(B, T, seed, kind="noise"):
+def audio(B, T, seed, kind="noise", channels=1):
     """Test audio of a golden case: seeded synthetic audio, or (kind "wav:<name>") one of the reference's own demo
-    recordings committed under tests/golden/wav/ (decoded like the product's reader: PCM16 / 2^15)."""
+    recordings committed under tests/golden/wav/ (decoded like the product's reader: PCM16 / 2^15).  channels = 2 (stereo cases):
+    [B, 2, T], channel c of utterance b = row 2 b + c of the mono generator (as oracle/make_golden.py builds them)."""
+    if channels > 1:
+        return torch.from_numpy(synthetic_audio(B * channels, T, seed, kind)).reshape(B, channels, T)
     if kind.startswith("wav:"):
         from funcodec_amd.io import read_wav
         x, sr = read_wav(os.path.join(GOLD, "wav", kind[4:] + ".wav"))

@@ -35,7 +35,7 @@ def test_native_library_is_loaded_and_device_is_gfx950():
 def test_e2e_against_reference_golden(name):
     c = MAN["cases"][name]
     m = engine_for(c["config"], c["weight_seed"], c["codebook_decay"])
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1))
     g = golden(name)
     r = m.engine.encode(wav, c["n_q"], want_enc_out=True)
     if "encoder_out" in g:                         # the two 10 s fixtures store indices / scale / quantized / recon only
@@ -47,7 +47,7 @@ def test_e2e_against_reference_golden(name):
     rep = index_report(r["codes"], g["indices"].astype(np.int64))
     r2 = m.engine.encode_decode(wav, c["n_q"], use_scale=True)
     assert torch.equal(r2["codes"], r["codes"])
-    assert r2["recon"].shape == (c["batch"], 1, c["samples"])
+    assert r2["recon"].shape == (c["batch"], c.get("channels", 1), c["samples"])
     cfg, arch, sd = state_for(c["config"], c["weight_seed"], c["codebook_decay"])
     projected = arch.codebook_dim != arch.dimension      # CostumeQuantizer.output_proj: a GEMM after the (exact) code-vector sum
     qtol = 1e-5 * float(np.sqrt((g["quantized"] ** 2).mean())) if projected else 0.0
@@ -93,20 +93,52 @@ def test_segmented_mode_against_reference_golden(name):
     m = engine_for(c["config"], c["weight_seed"], c["codebook_decay"])
     assert m.arch.segment_length == 8000 and m.arch.segment_stride == 7200
     # ds640seg: 8000 % 640 != 0 -> frames decode to 13 * 640 = 8320 samples; window and overlap use the untrimmed frames
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1))
     g = golden(name)
-    r = m.inference(wav.unsqueeze(1), bit_width=c["bit_width"], use_scale=True)
+    r = m.inference(wav if wav.dim() == 3 else wav.unsqueeze(1), bit_width=c["bit_width"], use_scale=True)
     assert len(r["code_indices"]) == len(c["frames"]) and len(r["sub_quants"]) == len(c["frames"])
     for f, idx in enumerate(r["code_indices"]):
         assert idx.shape == (c["n_q"], c["batch"], c["frames"][f])
         rep = index_report(idx, g[f"indices_{f}"].astype(np.int64))
         assert rep["mismatched_indices"] == 0, (f, rep)
         assert np.allclose(r["code_embeddings"][f][1].cpu().numpy(), g[f"scale_{f}"], rtol=1e-5)
-    assert r["recon_speech"].shape == (c["batch"], 1, c["samples"])
+    assert r["recon_speech"].shape == (c["batch"], c.get("channels", 1), c["samples"])
     assert rms(r["recon_speech"], g["recon"]) < WAV_RMS_TOL
     # frames of one call are independent utterances: the first frame alone gives the same codes
-    one = m.engine.encode(wav[:, :8000], c["n_q"])
+    one = m.engine.encode(wav[..., :8000], c["n_q"])
     assert torch.equal(one["codes"], r["code_indices"][0])
+
+
+def test_stereo_model_channel_contract():
+    """Stereo checkpoints (config input_size 2 / decoder_conf.channels 2; codec_basic.py:342-344,366): [B, 2, T] in, [B, 2, T] out; the volume
+    scale comes from the channel MEAN, so swapping the channels keeps it; a mono tensor or a third channel is refused like the reference's
+    first conv / assert would; a mono model refuses stereo input."""
+    c = MAN["cases"]["tinyst_b3_t1003"]
+    m = engine_for(c["config"], c["weight_seed"], c["codebook_decay"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], 2)
+    r = m.inference(wav)
+    assert r["recon_speech"].shape == (3, 2, 1003) and r["code_indices"][0].shape == (c["n_q"], 3, c["frames"])
+    sw = m.engine.encode(wav.flip(1), c["n_q"])
+    assert torch.equal(sw["scale"].cpu(), r["code_embeddings"][0][1].cpu())
+    assert not torch.equal(sw["codes"], r["code_indices"][0])
+    with pytest.raises(ValueError):
+        m.inference(wav[:, 0])                      # [B, T] -> one channel
+    with pytest.raises(AssertionError):
+        m.inference(torch.cat([wav, wav[:, :1]], 1))
+    with pytest.raises(Exception):
+        m.engine.encode(wav[:, 0], c["n_q"])
+    mono = engine_for("tiny", 7)
+    with pytest.raises(ValueError):
+        mono.inference(wav)
+    # the drop-in class takes the same tensor
+    from funcodec_amd.bin.codec_inference import Speech2Token
+    s2t = Speech2Token.__new__(Speech2Token)
+    s2t.model, s2t.check_status, s2t.dtype = m, True, "float32"
+    idx, embs, recon, subs = s2t(wav.numpy(), run_mod="inference")
+    assert torch.equal(idx[0], r["code_indices"][0]) and recon.shape == (3, 2, 1003)
+    tok = idx[0].permute(1, 2, 0).contiguous()
+    _, _, dec, _ = s2t(tok, run_mod="decode")
+    assert dec.shape == (3, 2, c["frames"] * m.engine.hop_length)
 
 
 @pytest.mark.parametrize("name", ["rvq_flat", "rvq_decay08"])
@@ -689,7 +721,7 @@ def test_freq_codec_against_reference_golden(name):
     from helpers import freq_engine_for, freq_state_for
     c = MAN["cases"][name]
     m = freq_engine_for(c["config"], c["weight_seed"])
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1))
     g = golden(name)
     r = m.engine.encode(wav, c["n_q"], want_enc_out=True)
     # `stft_self_noise` (MANIFEST.json, measured by oracle/make_golden.py): how far the REFERENCE's own encoder output moves when its
@@ -809,7 +841,7 @@ def test_freq_codec_mag_angle_against_reference_golden(name):
     c = MAN["cases"][name]
     m = freq_engine_for(c["config"], c["weight_seed"])
     assert m.arch.input_channels == 2
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"]).cuda()
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1)).cuda()
     g = golden(name)
     gf = torch.from_numpy(g["features"]).cuda().contiguous()           # [B, 2, F, frames]
     # 1. features modulo 2 pi
@@ -868,7 +900,7 @@ def test_freq_codec_segmented_mode_against_reference_golden(name):
     c = MAN["cases"][name]
     m = freq_engine_for(c["config"], c["weight_seed"])
     assert m.arch.segment_length == 2400 and m.arch.segment_stride == 2160
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1))
     g = golden(name)
     r = m.inference(wav.unsqueeze(1), bit_width=None, use_scale=True)
     m.engine.check_status()

@@ -20,7 +20,7 @@ def test_torch_oracle_matches_reference_golden(name):
     if c["samples"] * c["batch"] > 200000:
         pytest.skip("10 s x 2 on the CPU oracle: covered by the GPU suite and by oracle/make_golden.py's own assertions")
     orc = oracle_for(c["config"], c["weight_seed"], c["codebook_decay"])
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1))
     g = golden(name)
     o = orc.inference(wav, bit_width=c["bit_width"], use_scale=True)
     rep = index_report(o["code_indices"][0], g["indices"].astype(np.int64))
@@ -63,7 +63,7 @@ def test_freq_oracle_matches_reference_golden(name):
     c = MAN["cases"][name]
     cfg = freq_recipe_config(c["config"])
     orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, c["weight_seed"]).items()})
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1))
     g = golden(name)
     o = orc.inference(wav, None, True)
     angle = c["config"].endswith("ang")                  # codec_domain mag_angle: 2 channels, and the fixture carries the reference's features
@@ -98,7 +98,7 @@ def test_freq_oracle_segmented_mode_matches_reference_golden(name):
     cfg = freq_recipe_config(c["config"])
     orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, c["weight_seed"]).items()})
     g = golden(name)
-    o = orc.inference(audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"]), None, True)
+    o = orc.inference(audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1)), None, True)
     assert [int(i.shape[2]) for i in o["code_indices"]] == c["frames"]
     assert rms(o["recon_speech"], g["recon"]) < 1e-4
     exact = SAME_BUILD and torch.get_num_threads() == MAN["threads"]
@@ -115,7 +115,7 @@ def test_torch_oracle_segmented_mode_matches_reference_golden(name):
     """model_conf.segment_dur set: per-frame encode / RVQ / decode and the triangle overlap-add (codec_basic.py:334-396)."""
     c = MAN["cases"][name]
     orc = oracle_for(c["config"], c["weight_seed"], c["codebook_decay"])
-    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"], c.get("channels", 1))
     g = golden(name)
     o = orc.inference(wav, bit_width=c["bit_width"], use_scale=True)
     assert [int(i.shape[2]) for i in o["code_indices"]] == c["frames"]
