@@ -121,7 +121,7 @@ size_t fc_engine_workspace_bytes(const fc_engine* e, int B, int T);
 /* ---- the hot path -------------------------------------------------------------------------------- */
 /* Encodec.inference_encoding (funcodec/models/codec_basic.py:720-764) = _encode_frame (:361-380) +
  * SEANetEncoder.forward + CostumeQuantizer.inference -> DRVQ.forward (ddp_core_vq.py:367-418).
- *   wav        dev f32 [B,T]
+ *   wav        dev f32 [B,T]       ([B,2,T] for a stereo model, fc_arch.input_channels = 2 with model_type 0; B and T keep their meaning)
  *   n_q        number of quantizers to run (1..num_quantizers)
  *   codes      dev i64 [n_q,B,Tf]                         (code_indices[0])
  *   quantized  dev f32 [B,Tf,D]   or NULL                 (code_embeddings[0][0])
@@ -134,7 +134,8 @@ int fc_encode(fc_engine* e, const float* wav, int B, int T, int n_q,
 
 /* Encodec.inference_decoding_emb (codec_basic.py:804-836) = _decode_frame (:398-408) + SEANetDecoder.forward.
  *   emb   dev f32 [B,Tf,D];  scale dev f32 [B] or NULL (multiplied in when non-NULL, :406-407)
- *   wav   dev f32 [B,out_len], out_len <= fc_engine_decoded_samples(Tf) (the first out_len samples are written) */
+ *   wav   dev f32 [B,out_len] ([B,2,out_len] for a stereo model), out_len <= fc_engine_decoded_samples(Tf) (the first out_len samples
+ *         of every channel are written) */
 int fc_decode_emb(fc_engine* e, const float* emb, const float* scale, int B, int Tf, int out_len,
                   float* wav, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -144,7 +145,8 @@ int fc_decode_codes(fc_engine* e, const int64_t* codes, int B, int Tf, int n_q, 
                     float* wav, float* emb_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Encodec.inference (codec_basic.py:670-718) / FreqCodec.inference (codec_freq.py): encode + decode in one enqueue;
- * recon [B, min(T, fc_engine_decoded_samples(frames))] (= the reference's recon[:, :, :T]; always T for model_type 0). */
+ * recon [B, min(T, fc_engine_decoded_samples(frames))] (= the reference's recon[:, :, :T]; always T for model_type 0; [B,2,T] for a
+ * stereo model). */
 int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int use_scale,
                      int64_t* codes, float* quantized, float* sub_quants, float* scale, float* recon,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -154,7 +156,8 @@ int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int 
  * frame order and divided once by the summed weights, exactly as the reference orders it.
  *   frames      dev array of n_frames dev pointers, frame f = f32 [B, lens[f]] (decoded, UNTRIMMED segment f, which
  *               starts at sample f*stride); lens dev i32 [n_frames]; frame0_len = lens[0] (sizes the window, host copy)
- *   out         dev f32 [B, out_len]: the first out_len samples of the sum (Encodec.inference trims to the input, :711) */
+ *   out         dev f32 [B, out_len]: the first out_len samples of the sum (Encodec.inference trims to the input, :711)
+ * Rows are independent: a stereo model passes B * 2 rows. */
 int fc_overlap_add(const float* const* frames, const int* lens, int n_frames, int B, int frame0_len, int stride,
                    int out_len, float* out, void* stream);
 
