@@ -235,8 +235,23 @@ struct GConvArgs {
     long long in_sB, in_sF, out_sB, out_sF;      // floats between utterances / frequency rows
 };
 
+// Where the group's weights come from: (KF >= 4) the strided 8-row layers read them as uniform SCALAR loads -- staged in LDS the compiler
+// preloaded all 128 .. 256 of them into vector registers (250 - 256 registers, 1 - 2 waves per SIMD for a latency-bound streaming kernel);
+// from SGPRs the kernels take 128 / 208 registers: 0.99 -> 0.64 and 0.77 -> 0.53 ms per 32-utterance call.  The 3 x 3 and 1 x 1 layers are
+// VALU-bound and measured 8 % / 4 % SLOWER that way (s_load waits in the arithmetic), they keep the LDS broadcasts.  -1 = by shape.
+#ifndef FC_GCONV_WSCALAR
+#define FC_GCONV_WSCALAR -1
+#endif
+#ifndef FC_GCONV_WAVES
+#define FC_GCONV_WAVES 0
+#endif
+#if FC_GCONV_WAVES > 0
+#define FC_GCONV_ATTR __attribute__((amdgpu_waves_per_eu(FC_GCONV_WAVES, FC_GCONV_WAVES)))
+#else
+#define FC_GCONV_ATTR
+#endif
 template <int CPG, int OPG, int KF, int KT, int ST, bool DUAL, int FO>
-__global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
+__global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvArgs p) {
     // FO = output frequency rows per lane (rows fo0, fo0 + 1): the KF + (FO - 1) SF input rows they read are loaded and activated once
     // instead of FO x KF times (3x3: 4 rows instead of 6; 8-row stride-4 layers: 12 instead of 16)
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -250,8 +265,13 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
     const int FoP = (p.Fo + FO - 1) / FO;        // row groups per utterance
     const int b = z / FoP, fo0 = (z - b * FoP) * FO;
     const int sf = p.sf;
-    for (int i = tid; i < NW; i += 256) wsh[i] = p.w[(size_t)g * NW + i];
-    __syncthreads();
+    constexpr bool WSCALAR = FC_GCONV_WSCALAR < 0 ? KF >= 4 : FC_GCONV_WSCALAR != 0;
+    const float* wgp = p.w + (size_t)g * NW;      // uniform per workgroup: scalar loads
+    if (!WSCALAR) {
+        for (int i = tid; i < NW; i += 256) wsh[i] = wgp[i];
+        __syncthreads();
+        wgp = wsh;
+    }
     const int n0 = tile * 1024 + 4 * tid;        // first output column of this lane
     const int q0 = n0 * ST - p.padL;             // source index (before reflection) of its first input column
     const bool vec_ok = q0 >= 0 && q0 + 4 * NV <= p.Tin;
@@ -337,7 +357,7 @@ __global__ __launch_bounds__(256) void gconv2d_kernel(const GConvArgs p) {
                     for (int o = 0; o < OPG; ++o)
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk) {
-                            const float wv = wsh[((o * CPG + ci) * KF + a) * KT + kk];
+                            const float wv = wgp[((o * CPG + ci) * KF + a) * KT + kk];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[f][o][j] = fmaf(wv, x[j * ST + kk], acc[f][o][j]);
                         }
@@ -563,7 +583,12 @@ bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st) {
 }
 // output frequency rows per lane: 2 for the 3 x 3 layers (4 input rows instead of 6: 6.9 -> 5.6 ms on freqmpgr1); the strided 8-row layers
 // measured slower with 2 (12 rows x two sources in flight: 4.4 -> 5.6 ms), 1 x 1 layers share nothing
-static int gconv2d_fo(int kf, int Fo) { return (kf == 3 && Fo > 1) ? 2 : 1; }
+static int gconv2d_fo(int kf, int Fo) {
+    static const int fo3 = getenv("FC_GCONV_FO3") ? atoi(getenv("FC_GCONV_FO3")) : 2;     // A / B aid: 1 .. 4 rows per lane for the 3 x 3 layers
+    if (kf != 3 || Fo <= 1) return 1;
+    const int f = fo3 < 1 ? 1 : (fo3 > 4 ? 4 : fo3);
+    return f < Fo ? f : Fo;
+}
 int gconv2d_nblk(int Tout, int Fo, int G, int kf) {
     if (gconv2d_lds3(kf, kf, 1)) return cdiv(Tout, G3_TN) * cdiv(Fo, G3_RF) * G;       // (the grouped layers are square: kt == kf for kf == 3)
     return cdiv(Tout, 1024) * cdiv(Fo, gconv2d_fo(kf, Fo)) * G;
@@ -606,6 +631,12 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
         if (fo_n == 2) {                                                                                                     \
             if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, (KF_ == 3 ? 2 : 1)>), grid, block, 0, st, a);    \
             else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, (KF_ == 3 ? 2 : 1)>), grid, block, 0, st, a);        \
+        } else if (fo_n == 3) {                                                                                              \
+            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, (KF_ == 3 ? 3 : 1)>), grid, block, 0, st, a);    \
+            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, (KF_ == 3 ? 3 : 1)>), grid, block, 0, st, a);        \
+        } else if (fo_n == 4) {                                                                                              \
+            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, (KF_ == 3 ? 4 : 1)>), grid, block, 0, st, a);    \
+            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, (KF_ == 3 ? 4 : 1)>), grid, block, 0, st, a);        \
         } else {                                                                                                             \
             if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, 1>), grid, block, 0, st, a);            \
             else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, 1>), grid, block, 0, st, a);                \
@@ -634,22 +665,50 @@ struct GConvTrArgs {
     double* partials;        // [B][(Fin + 1) fr][ttiles][2]
     int C, cout, Fin, Tin, fr, f_l, Fout, trimL, Tout;
     long long out_sB;
+    int nx, ny, nz;          // logical grid: column tiles, (input-row pairs x channel chunks) or untrimmed output rows, utterances
+    int cs;                  // channel chunks per input-row pair (<= fr)
 };
 
+#ifndef FC_GCONVTR_DPP
+#define FC_GCONVTR_DPP 1
+#endif
+#ifndef FC_GCONVTR_XCD
+#define FC_GCONVTR_XCD 1
+#endif
+#ifndef FC_GCONVTR_ROWS
+#define FC_GCONVTR_ROWS 1
+#endif
 template <int TR>
 __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     constexpr int NI = 4 / TR + 1;                   // input columns behind 4 untrimmed output columns
     __shared__ double red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int tile = blockIdx.x, fu = blockIdx.y, b = blockIdx.z;
-    const int q = fu / p.fr, ph_f = fu - q * p.fr;
+    // XCD-aware order (round 4).  Neighbouring input-row pairs share a row (row q is read again for pair q + 1): in dispatch order
+    // (workgroup w -> XCD w % 8, observed) they sat on different XCDs and every XCD's L2 fetched the input again.  1-D grid of 8 * per
+    // workgroups; XCD x walks the contiguous range [x * per, (x + 1) * per) of the (tile, row, utterance) order.
+    int tile, yi, b;
+    if (FC_GCONVTR_XCD) {
+        const unsigned w = blockIdx.x, per = gridDim.x >> 3;
+        const unsigned v = (w & 7u) * per + (w >> 3);
+        if (v >= (unsigned)(p.nx * p.ny * p.nz)) return;
+        tile = v % p.nx; yi = (v / p.nx) % p.ny; b = v / (p.nx * p.ny);
+    } else { tile = blockIdx.x; yi = blockIdx.y; b = blockIdx.z; }
+    // FC_GCONVTR_ROWS (round 4): one workgroup = one input-row pair (q, q - 1) and ALL fr output rows q fr .. q fr + fr - 1 it feeds: the four
+    // (channel, row) pieces of a channel pair are loaded once and multiplied fr times (fr = 4: 4 load instructions per 4 stores instead of
+    // 16 -- the kernel is bound by the address path).  Otherwise one workgroup per untrimmed output row.
+    // ... and one of `cs` chunks of the output channels (cs <= fr): the layers behind the bottleneck have few rows and many channels -- 544
+    // workgroups x 64 serial channel iterations on 1 536 workgroup slots before the split.
+    const int q = FC_GCONVTR_ROWS ? yi / p.cs : yi / p.fr;
+    const int chunk = FC_GCONVTR_ROWS ? yi - q * p.cs : 0;
+    const int ph_lo = FC_GCONVTR_ROWS ? 0 : yi - q * p.fr, ph_hi = FC_GCONVTR_ROWS ? p.fr : ph_lo + 1;
+    const int co_per = (p.cout + p.cs - 1) / p.cs;
+    const int co_lo = FC_GCONVTR_ROWS ? chunk * co_per : 0;
+    const int co_hi = FC_GCONVTR_ROWS ? (co_lo + co_per < p.cout ? co_lo + co_per : p.cout) : p.cout;
     const int tu0 = tile * 1024 + 4 * tid;           // first untrimmed output column of this lane (a multiple of 4, hence of TR)
     const int Tu = (p.Tin + 1) * TR;
     const bool live = tu0 < Tu;
     const int i0 = tu0 / TR;                         // input column of tap s = 0 for the lane's first output
-    const int fo = fu - p.f_l;
-    const bool row_ok = fo >= 0 && fo < p.Fout;
     const size_t rowsz = (size_t)p.C * p.Tin;
     const float* zq = p.z + ((size_t)b * (p.Fin + 2) + (q + 1)) * rowsz;       // input row q (row Fin = the zero halo)
     const float* zm = zq - rowsz;                                               // input row q - 1 (row -1 = the zero halo)
@@ -658,9 +717,26 @@ __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
     // wave-uniform: every lane's columns i0 - 1 .. i0 + max(NI, 4) - 2 lie inside the input row (all but the first and the last wave of a row)
     const bool fast = __all(live && i0 >= 1 && i0 + (NI > 4 ? NI - 2 : 2) < p.Tin);
     if (live) {
-        for (int co = 0; co < p.cout; ++co) {
+        for (int co = co_lo; co < co_hi; ++co) {
             float x[2][2][NI];                       // [ci][row q / q - 1][columns i0 - 1 .. i0 + NI - 2]
-            if (fast) {
+            if (fast && TR == 1 && FC_GCONVTR_DPP) {
+                // TR = 1: the lane's own 4 columns i0 .. i0 + 3 in ONE 16-byte load; column i0 - 1 is the left neighbour's last column
+                // (DPP wave_shr:1), only lane 0 of a wave loads it.
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const float* row = (r ? zm : zq) + (size_t)(2 * co + ci) * p.Tin + i0;
+                        const f32x4 v = *(const f32x4u*)row;
+                        float left = 0.f;
+                        if (lane == 0) left = row[-1];
+                        left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, left), __builtin_bit_cast(int, v[3]),
+                                                                                     0x138, 0xF, 0xF, false));       // wave_shr:1
+                        x[ci][r][0] = left;
+#pragma unroll
+                        for (int j = 1; j < NI; ++j) x[ci][r][j] = v[(j - 1) & 3];
+                    }
+            } else if (fast) {
                 // whole wave inside the row: ONE 16-byte load (+ one dword for the fifth column of TR = 1) per (channel, row) instead of
                 // NI dword loads -- the kernel is bound by the address path (PMC: TA busy 89 - 92 %, tools/pmc_ta.sh), not by HBM or latency
                 // (issuing the loads of channel pair co + 1 ahead of the arithmetic of pair co changed nothing: 1.64 vs 1.63 ms)
@@ -687,38 +763,42 @@ __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
                         }
                     }
             }
-            float acc[4];
             const float bm = p.bias[co];
+            for (int ph_f = ph_lo; ph_f < ph_hi; ++ph_f) {
+                const int fu = q * p.fr + ph_f, fo = fu - p.f_l;
+                const bool row_ok = fo >= 0 && fo < p.Fout;
+                float acc[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+                for (int j = 0; j < 4; ++j) acc[j] = 0.f;
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
+                for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const float* wr = p.w + ((size_t)(2 * co + ci) * kf + ph_f + r * p.fr) * kt;     // uniform: scalar loads
+                    for (int r = 0; r < 2; ++r) {
+                        const float* wr = p.w + ((size_t)(2 * co + ci) * kf + ph_f + r * p.fr) * kt;     // uniform: scalar loads
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int ph = j % TR, ii = j / TR;          // output column tu0 + j = (i0 + ii) TR + ph
-                        acc[j] = fmaf(wr[ph], x[ci][r][ii + 1], acc[j]);           // tap s = 0: column i0 + ii
-                        acc[j] = fmaf(wr[ph + TR], x[ci][r][ii], acc[j]);          // tap s = 1: column i0 + ii - 1
+                        for (int j = 0; j < 4; ++j) {
+                            const int ph = j % TR, ii = j / TR;          // output column tu0 + j = (i0 + ii) TR + ph
+                            acc[j] = fmaf(wr[ph], x[ci][r][ii + 1], acc[j]);           // tap s = 0: column i0 + ii
+                            acc[j] = fmaf(wr[ph + TR], x[ci][r][ii], acc[j]);          // tap s = 1: column i0 + ii - 1
+                        }
                     }
+                float ov[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ov[j] = acc[j] + bm;
+                    if (tu0 + j < Tu) { s1v += ov[j]; s2v = fmaf(ov[j], ov[j], s2v); }
                 }
-            float ov[4];
+                if (row_ok) {
+                    float* orow = p.out + (size_t)b * p.out_sB + ((size_t)fo * p.cout + co) * p.Tout;
+                    const int to0 = tu0 - p.trimL;
+                    if (to0 >= 0 && to0 + 3 < p.Tout) *(f32x4u*)(orow + to0) = (f32x4){ov[0], ov[1], ov[2], ov[3]};     // one 16-byte store (round 3)
+                    else
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ov[j] = acc[j] + bm;
-                if (tu0 + j < Tu) { s1v += ov[j]; s2v = fmaf(ov[j], ov[j], s2v); }
-            }
-            if (row_ok) {
-                float* orow = p.out + (size_t)b * p.out_sB + ((size_t)fo * p.cout + co) * p.Tout;
-                const int to0 = tu0 - p.trimL;
-                if (to0 >= 0 && to0 + 3 < p.Tout) *(f32x4u*)(orow + to0) = (f32x4){ov[0], ov[1], ov[2], ov[3]};     // one 16-byte store (round 3)
-                else
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int to = to0 + j;
-                        if (to >= 0 && to < p.Tout) orow[to] = ov[j];
-                    }
+                        for (int j = 0; j < 4; ++j) {
+                            const int to = to0 + j;
+                            if (to >= 0 && to < p.Tout) orow[to] = ov[j];
+                        }
+                }
             }
         }
     }
@@ -731,9 +811,15 @@ __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
     if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
     __syncthreads();
     if (tid == 0 && p.partials) {                        // weight_norm nets: no GroupNorm statistics
-        const size_t slot = (((size_t)b * gridDim.y + fu) * gridDim.x + tile) * 2;
-        p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        // partial slots stay one per (utterance, untrimmed output row, tile): the cs workgroups of an input-row pair share its fr slots --
+        // chunk c fills slot c and zeroes slots c + cs, c + 2 cs, ...
+        const int nrows = (p.Fin + 1) * p.fr;
+        const int step = FC_GCONVTR_ROWS ? p.cs : 1, first = FC_GCONVTR_ROWS ? chunk : ph_lo;
+        for (int ph_f = first; ph_f < ph_hi; ph_f += step) {
+            const size_t slot = (((size_t)b * nrows + (q * p.fr + ph_f)) * p.nx + tile) * 2;
+            p.partials[slot] = ph_f == first ? ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3] : 0.0;
+            p.partials[slot + 1] = ph_f == first ? ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3] : 0.0;
+        }
     }
 }
 
@@ -746,7 +832,16 @@ hipError_t launch_gconvtr2d(const float* z, const float* w, const float* bias, f
     a.z = z; a.w = w; a.bias = bias; a.out = out; a.partials = partials;
     a.C = C; a.cout = cout; a.Fin = Fin; a.Tin = Tin; a.fr = fr; a.f_l = f_l; a.Fout = Fout; a.trimL = trimL; a.Tout = Tout; a.out_sB = out_sB;
     if ((Fin + 1) * fr > 65535 || B > 65535) return hipErrorInvalidValue;
-    dim3 grid(cdiv((Tin + 1) * tr, 1024), (Fin + 1) * fr, B), block(256);
+    static const int cs_env = getenv("FC_GCONVTR_CS") ? atoi(getenv("FC_GCONVTR_CS")) : 0;       // A / B aid
+    a.nx = cdiv((Tin + 1) * tr, 1024);
+    a.cs = 1;
+    while (a.cs * 2 <= fr && a.cs * 2 <= cout && (long long)a.nx * (Fin + 1) * B * a.cs < 6144) a.cs *= 2;   // >= 4 workgroups per slot, or all there are
+    if (cs_env > 0) a.cs = cs_env < fr ? (cs_env < cout ? cs_env : cout) : (fr < cout ? fr : cout);
+    a.ny = FC_GCONVTR_ROWS ? (Fin + 1) * a.cs : (Fin + 1) * fr; a.nz = B;
+    const long long total = (long long)a.nx * a.ny * a.nz;
+    if (total > (1ll << 30)) return hipErrorInvalidValue;
+    dim3 grid(a.nx, a.ny, a.nz), block(256);
+    if (FC_GCONVTR_XCD) grid = dim3((unsigned)(8 * ((total + 7) / 8)), 1, 1);
     if (tr == 1) hipLaunchKernelGGL(gconvtr2d_kernel<1>, grid, block, 0, st, a);
     else if (tr == 2) hipLaunchKernelGGL(gconvtr2d_kernel<2>, grid, block, 0, st, a);
     else return hipErrorInvalidValue;
