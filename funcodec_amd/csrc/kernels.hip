@@ -339,6 +339,157 @@ __global__ __launch_bounds__(256) void conv_fewout_rows_kernel(const Cout1Args p
     }
 }
 
+// PLAIN-input form of the rows kernel (round 4): the source is one already materialised tensor (no affine, no ELU, one source -- the 2-D
+// nets' last Conv2d, whose input `combine2d` activates once).  The profile of the kernel above on that layer (2.3 ms per 32-utterance call,
+// 0.21 of the fp32 peak) is its STAGING, not its 672 FMAs per 8 channels: 1 500 instructions and ~100 waits to gather / select / activate / store
+// 8 channel rows into LDS, two barriers per chunk, nothing in flight during the arithmetic.  Here every staged value goes HBM -> LDS by DMA
+// (no registers, no VALU): 4 channels per stage into a double-buffered LDS tile (the same 33 KiB);
+//   * lanes whose 16-byte piece lies inside the row: `global_load_lds_dwordx4`, 1 KiB per wave instruction, one per channel row;
+//   * the columns no such lane covers (reflect padding at the row ends, the 8 tail columns): `global_load_lds_dword` with the reflected
+//     source address per lane, wave w serving row w; columns that are zeros for every channel (beyond the padding) are zeroed once.
+// Per stage: the stage's 48 LDS values into registers | DMA of stage s + 1 | 336 FMAs from registers under that DMA | vmcnt(0) + ONE barrier.
+// (hipcc drains vmcnt before the first LDS access behind an LDS DMA: nothing touches LDS between the DMA issue and the end of the stage.)
+// LDS column c' of a row = source column t0 - padL + c', as in the kernel above: a lane's window starts at its own 16-byte aligned column.
+constexpr int C1P_CH = 4;
+
+template <int K, int MO>
+__global__ __launch_bounds__(256) void conv_fewout_rows_plain_kernel(const Cout1Args p) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+    typedef const __attribute__((address_space(4))) float* cfp_t;
+    __shared__ __attribute__((aligned(16))) float Xs[2][C1P_CH][C1L_ROW];
+    __shared__ double red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int breal = p.Fo > 1 ? b / p.Fo : b, fo = p.Fo > 1 ? b - breal * p.Fo : 0;
+    const int t0 = tile * C1L_TN, gbase = t0 - p.padL;               // source column of LDS column 0
+    const float* s0 = p.src0 + (size_t)breal * p.in_sB0 + (size_t)fo * p.in_sB1;
+    const int g0 = gbase + 4 * tid;
+    const bool vec_ok = g0 >= 0 && g0 + 3 < p.T;                     // this lane's 16-byte piece lies inside the row
+    // columns no 16-byte lane covers: [0, cl) and [cr, C1L_ROW)
+    const int cl = gbase < 0 ? (((-gbase + 3) >> 2) << 2) : 0;
+    int first_bad = (p.T - gbase) >> 2;                               // smallest tid with gbase + 4 tid + 3 >= T
+    first_bad = first_bad < (cl >> 2) ? (cl >> 2) : (first_bad > 256 ? 256 : first_bad);
+    const int cr = 4 * first_bad;
+    const int refl = 2 * (p.Leff - 1);
+    // this wave's edge columns (it serves row `wid` of every stage): column -> reflected source index, or -1 (a zero for every channel)
+    constexpr int NE = (C1L_ROW + 63) / 64 + 1;                       // 64-column pieces: [0, cl) is one, [cr, C1L_ROW) at most 17
+    int esrc[2];                                                      // common case: two pieces (left + right); longer ranges loop below
+    auto edge_src = [&](int col) __attribute__((always_inline)) {
+        const int g = gbase + col;
+        int src = g < 0 ? -g : g;
+        src = src >= p.Leff ? refl - src : src;
+        return (col < C1L_ROW && g >= -p.padL && src >= 0 && src < p.T) ? src : -1;
+    };
+    (void)NE;
+    esrc[0] = lane < cl ? edge_src(lane) : -1;
+    esrc[1] = edge_src(cr + lane);
+    // zeros: every edge column of both buffers once (the DMA below rewrites the ones that have a source, for every stage)
+    for (int e = tid; e < 2 * C1P_CH * C1L_ROW; e += 256) {
+        const int col = e % C1L_ROW;
+        if (col < cl || col >= cr) (&Xs[0][0][0])[e] = 0.f;
+    }
+    __syncthreads();
+    const int nstage = (p.Cin + C1P_CH - 1) / C1P_CH;
+    auto stage_dma = [&](int st) __attribute__((always_inline)) {
+        float* X = &Xs[st & 1][0][0];
+        if (vec_ok) {
+#pragma unroll
+            for (int r = 0; r < C1P_CH; ++r) {
+                const int c = st * C1P_CH + r < p.Cin ? st * C1P_CH + r : p.Cin - 1;      // past the last channel: a dropped re-read
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(s0 + (size_t)c * p.T + g0), (lds_ptr_t)(X + r * C1L_ROW + 256 * wid), 16, 0, 0);
+            }
+        }
+        {   // edge columns of row `wid`
+            const int c = st * C1P_CH + wid < p.Cin ? st * C1P_CH + wid : p.Cin - 1;
+            const float* row = s0 + (size_t)c * p.T;
+            float* Xr = X + wid * C1L_ROW;
+            if (esrc[0] >= 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(row + esrc[0]), (lds_ptr_t)Xr, 4, 0, 0);
+            if (esrc[1] >= 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(row + esrc[1]), (lds_ptr_t)(Xr + cr), 4, 0, 0);
+            for (int base = cr + 64; base < C1L_ROW; base += 64) {    // rows much shorter than the tile
+                const int src = edge_src(base + lane);
+                if (src >= 0) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(row + src), (lds_ptr_t)(Xr + base), 4, 0, 0);
+            }
+        }
+    };
+    float acc[MO][4];
+#pragma unroll
+    for (int m = 0; m < MO; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[m][j] = 0.f;
+    stage_dma(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int st = 0; st < nstage; ++st) {
+        f32x4 q[C1P_CH][3];
+#pragma unroll
+        for (int r = 0; r < C1P_CH; ++r)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) q[r][v] = *(const f32x4*)&Xs[st & 1][r][4 * tid + 4 * v];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the values are in registers before the other buffer is rewritten
+        if (st + 1 < nstage) stage_dma(st + 1);
+#pragma unroll
+        for (int r = 0; r < C1P_CH; ++r) {
+            const int c = st * C1P_CH + r;
+            if (c >= p.Cin) break;                                    // uniform
+            float x[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) x[i] = q[r][i >> 2][i & 3];
+            // the MO x K weights of the channel in one go (one wait per channel instead of one per output channel).  Uniform address,
+            // CONSTANT address space: behind the asm barriers above hipcc no longer proves the weights unclobbered and would fetch them
+            // with vector loads -- whose vmcnt waits then drain the DMA in front of the FMAs
+            float wv[MO][K];
+#pragma unroll
+            for (int m = 0; m < MO; ++m) {
+                const cfp_t wr = (cfp_t)(p.w + ((size_t)m * p.Cin + c) * K);
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk) wv[m][kk] = wr[kk];
+            }
+#pragma unroll
+            for (int m = 0; m < MO; ++m)
+#pragma unroll
+                for (int kk = 0; kk < K; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[m][j] = fmaf(wv[m][kk], x[j + kk], acc[m][j]);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // ---- epilogue: bias, store, statistics of the valid outputs (as above)
+    float s1v = 0.f, s2v = 0.f;
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        float o[4];
+        const float bm = p.bias[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = acc[m][j] + bm;
+            const int n = t0 + 4 * tid + j;
+            if (n < p.T) { s1v += o[j]; s2v = fmaf(o[j], o[j], s2v); }
+        }
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        float* orow = p.out + (size_t)breal * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.out_sM + t0 + 4 * tid;
+        if (t0 + 4 * tid + 3 < p.T) *(f32x4u*)orow = (f32x4){o[0], o[1], o[2], o[3]};
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (t0 + 4 * tid + j < p.T) orow[j] = o[j];
+    }
+    if (p.partials) {
+        double d1 = (double)s1v, d2 = (double)s2v;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            d1 += __shfl_xor(d1, off, 64);
+            d2 += __shfl_xor(d2, off, 64);
+        }
+        if (lane == 0) { red[0][wid] = d1; red[1][wid] = d2; }
+        __syncthreads();
+        if (tid == 0) {
+            const size_t slot = ((size_t)breal * p.part_sB0 + (size_t)fo * gridDim.x + tile) * 2;
+            p.partials[slot] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+            p.partials[slot + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        }
+    }
+}
+
 constexpr int C1_WOUT = 248, C1_TN = 4 * C1_WOUT, C1_UN = 4;    // outputs per wave / per workgroup; channels per load group
 
 // lane i <- lane i + 1 over the whole wavefront (DPP wave_shl:1; lane 63 gets 0)
@@ -512,6 +663,14 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
     if (c.B > 65535) return hipErrorInvalidValue;
     dim3 grid(ceil_div(c.Tout, tile_n), c.B), block(256);
     const bool rows = tile_n == C1L_TN;
+    // one materialised source, no prologue arithmetic: the all-DMA staging form (FC_FEWOUT_PLAIN=0: the general rows kernel, A / B aid)
+    static const int plain_env = getenv("FC_FEWOUT_PLAIN") ? atoi(getenv("FC_FEWOUT_PLAIN")) : 1;
+    if (rows && plain_env && !c.s0.aff && !c.s1.ptr && !c.elu && !ablate_env) {
+#define FC_C1P(KK, MM) if (c.k == KK && c.M == MM) { hipLaunchKernelGGL((conv_fewout_rows_plain_kernel<KK, MM>), grid, block, 0, st, a); return hipGetLastError(); }
+        FC_C1P(3, 1) FC_C1P(3, 2) FC_C1P(3, 3) FC_C1P(3, 4) FC_C1P(5, 1) FC_C1P(5, 2) FC_C1P(5, 3) FC_C1P(5, 4)
+        FC_C1P(7, 1) FC_C1P(7, 2) FC_C1P(7, 3) FC_C1P(7, 4)
+#undef FC_C1P
+    }
 #define FC_C1M(KK, MM)                                                                                  \
     case MM:                                                                                            \
         if (rows) {                                                                                     \
