@@ -973,7 +973,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1,
                      L.BM >= 128 ? 2 : 4, mode, nu, row ? "true" : "false");
             if (fc::conv_cout1_ok(c))
-                snprintf(nm, sizeof(nm), "%s<%d, %s, %d>", fc::conv_fewout_rows(c) ? "conv_fewout_rows_kernel" : "conv_cout1_kernel", c.k, c.s1.ptr ? "true" : "false", c.M);
+                fc::conv_fewout_name(c, nm, sizeof(nm));
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);
@@ -1268,7 +1268,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
                      row ? "true" : "false");
             if (fc::conv_cout1_ok(c))
-                snprintf(nm, sizeof(nm), "%s<%d, %s, %d>", fc::conv_fewout_rows(c) ? "conv_fewout_rows_kernel" : "conv_cout1_kernel", c.k, c.s1.ptr ? "true" : "false", c.M);
+                fc::conv_fewout_name(c, nm, sizeof(nm));
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl, by);
@@ -1375,7 +1375,7 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
             snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
                      row ? "true" : "false");
             if (fc::conv_cout1_ok(c))
-                snprintf(nm, sizeof(nm), "%s<%d, %s, %d>", fc::conv_fewout_rows(c) ? "conv_fewout_rows_kernel" : "conv_cout1_kernel", c.k, c.s1.ptr ? "true" : "false", c.M);
+                fc::conv_fewout_name(c, nm, sizeof(nm));
             cls = e->prof_class(nm);
         }
         ProfSpan sp(e, cx, cls, fl / sf, by / sf);

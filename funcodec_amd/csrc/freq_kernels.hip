@@ -239,6 +239,7 @@ struct GConvArgs {
 // preloaded all 128 .. 256 of them into vector registers (250 - 256 registers, 1 - 2 waves per SIMD for a latency-bound streaming kernel);
 // from SGPRs the kernels take 128 / 208 registers: 0.99 -> 0.64 and 0.77 -> 0.53 ms per 32-utterance call.  The 3 x 3 and 1 x 1 layers are
 // VALU-bound and measured 8 % / 4 % SLOWER that way (s_load waits in the arithmetic), they keep the LDS broadcasts.  -1 = by shape.
+// (All 72 weights of the 3 x 3 kernel pinned in SGPRs: 65 SGPR spills; volatile LDS reads at every use: 256 registers.  Neither was run.)
 #ifndef FC_GCONV_WSCALAR
 #define FC_GCONV_WSCALAR -1
 #endif

@@ -47,6 +47,7 @@ struct ConvLaunch {
 int conv_nblk(const ConvLaunch& c);                         // stat partials per utterance
 bool conv_cout1_ok(const ConvLaunch& c);                    // launch_conv() will take a few-output FMA kernel (1..4 output channels)
 bool conv_fewout_rows(const ConvLaunch& c);                 // ... its LDS form for short rows (else the streaming form)
+void conv_fewout_name(const ConvLaunch& c, char* buf, size_t n); // the kernel symbol launch_conv picks for a few-output layer (profile class name)
 size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
 size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row);

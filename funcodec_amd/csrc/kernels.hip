@@ -85,6 +85,15 @@ bool conv_cout1_ok(const ConvLaunch& c);
 // outputs per workgroup of the few-output FMA kernels: the LDS form (1024) on short rows / 2-D layers, the streaming form (992) else
 static int conv_fewout_tile(const ConvLaunch& c) { return (c.Fo > 1 || c.Tout < 8192) ? 1024 : 992; }
 bool conv_fewout_rows(const ConvLaunch& c) { return conv_fewout_tile(c) == 1024; }
+static bool conv_fewout_plain(const ConvLaunch& c) {        // rows form, one materialised source, no prologue arithmetic: all-DMA staging
+    static const int plain_env = getenv("FC_FEWOUT_PLAIN") ? atoi(getenv("FC_FEWOUT_PLAIN")) : 1;     // 0: the general rows kernel (A / B aid)
+    static const int ablate_env = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
+    return conv_fewout_rows(c) && plain_env && !c.s0.aff && !c.s1.ptr && !c.elu && !ablate_env;
+}
+void conv_fewout_name(const ConvLaunch& c, char* buf, size_t n) {
+    if (conv_fewout_plain(c)) snprintf(buf, n, "conv_fewout_rows_plain_kernel<%d, %d>", c.k, c.M);
+    else snprintf(buf, n, "%s<%d, %s, %d>", conv_fewout_rows(c) ? "conv_fewout_rows_kernel" : "conv_cout1_kernel", c.k, c.s1.ptr ? "true" : "false", c.M);
+}
 int conv_nblk(const ConvLaunch& c) {
     if (conv_cout1_ok(c)) return ceil_div(c.Tout, conv_fewout_tile(c));      // few-output FMA kernels: one partial per workgroup
     return ceil_div(c.Tout, c.BN) * ceil_div(c.M, c.BM);
@@ -663,9 +672,8 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
     if (c.B > 65535) return hipErrorInvalidValue;
     dim3 grid(ceil_div(c.Tout, tile_n), c.B), block(256);
     const bool rows = tile_n == C1L_TN;
-    // one materialised source, no prologue arithmetic: the all-DMA staging form (FC_FEWOUT_PLAIN=0: the general rows kernel, A / B aid)
-    static const int plain_env = getenv("FC_FEWOUT_PLAIN") ? atoi(getenv("FC_FEWOUT_PLAIN")) : 1;
-    if (rows && plain_env && !c.s0.aff && !c.s1.ptr && !c.elu && !ablate_env) {
+    // one materialised source, no prologue arithmetic: the all-DMA staging form
+    if (conv_fewout_plain(c)) {
 #define FC_C1P(KK, MM) if (c.k == KK && c.M == MM) { hipLaunchKernelGGL((conv_fewout_rows_plain_kernel<KK, MM>), grid, block, 0, st, a); return hipGetLastError(); }
         FC_C1P(3, 1) FC_C1P(3, 2) FC_C1P(3, 3) FC_C1P(3, 4) FC_C1P(5, 1) FC_C1P(5, 2) FC_C1P(5, 3) FC_C1P(5, 4)
         FC_C1P(7, 1) FC_C1P(7, 2) FC_C1P(7, 3) FC_C1P(7, 4)
