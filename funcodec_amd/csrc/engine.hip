@@ -1133,6 +1133,13 @@ Act run_decoder(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf) {
 }
 
 
+// FreqCodec: the direct kernels and the materialisation passes write the reflected / zero halo rows of their outputs themselves (round 4;
+// FC_HALO_FUSE=0: a halo_rows launch behind every producer, as before -- A / B aid)
+static bool halo_fuse_on() {
+    static const int v = getenv("FC_HALO_FUSE") ? atoi(getenv("FC_HALO_FUSE")) : 1;
+    return v != 0;
+}
+
 // ---- STFT-domain codec: execution over frequency-major activations --------------------------------------------------------------
 struct Act2 {              // raw [B][F + 2*halo][C][T] + pending GroupNorm affine [B][C] (null = final)
     float* buf = nullptr;
@@ -1160,11 +1167,12 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
             Act2 m;
             m.C = C; m.F = x0.F; m.T = x0.T; m.halo = x0.halo;
             m.buf = cx.alloc<float>((size_t)B * (m.F + 2 * m.halo) * C * m.T);
-            cx.launches += 2;
+            const bool fuse_halo = halo_fuse_on() && m.F > m.halo;      // the pass writes its own reflected halo rows
+            cx.launches += fuse_halo ? 1 : 2;
             if (!cx.dry && !cx.err) {
                 hipError_t er = fc::launch_combine2d(x0.buf, x0.aff, x0.halo, x1.buf, x1.aff, x1.halo, elu, e->arch.elu_alpha, B, m.F, C, m.T, m.buf,
-                                                     m.halo, cx.st);
-                if (er == hipSuccess) er = fc::launch_halo_rows(m.buf, B, m.F, m.halo, C, m.T, 0, cx.st);
+                                                     m.halo, cx.st, fuse_halo ? 1 : 0);
+                if (er == hipSuccess && !fuse_halo) er = fc::launch_halo_rows(m.buf, B, m.F, m.halo, C, m.T, 0, cx.st);
                 if (er != hipSuccess) { cx.err = 1; g_err = std::string("combine2d launch failed: ") + hipGetErrorString(er); }
             }
             x0 = m; x1 = Act2(); elu = 0; dual = false;
@@ -1185,6 +1193,8 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         c.padL = g.padL; c.padR = g.padR; c.elu = elu; c.alpha = e->arch.elu_alpha;
         c.in_sB = (long long)(x0.F + 2 * x0.halo) * rowsz; c.in_sF = rowsz;
         c.out_sB = (long long)(Fo + 2 * out_halo) * orow; c.out_sF = orow;
+        const bool fuse_halo = halo_fuse_on() && fc::gconv2d_fuses_halo(kf, L.k, L.stride, Fo, out_halo);
+        c.out_halo = fuse_halo ? out_halo : 0;
         const int nblk = fc::gconv2d_nblk(g.Tout, Fo, L.groups, kf);
         c.partials = L.has_norm ? cx.alloc<double>((size_t)B * nblk * 2) : nullptr;       // weight_norm nets: no statistics, no affine
         o.aff = L.has_norm ? cx.alloc<float>((size_t)B * L.cout * 2) : nullptr;
@@ -1192,7 +1202,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         const double fl = 2.0 * B * Fo * (double)L.cout * (C / L.groups) * kf * L.k * g.Tout;
         const double by = 4.0 * B * ((double)C * x0.F * x0.T * (dual ? 2 : 1) + (double)L.cout * Fo * g.Tout);
         cx.conv_flops += fl; cx.conv_bytes += by;
-        cx.launches += out_halo ? 3 : 2; cx.conv_launches += 1;
+        cx.launches += (out_halo && !fuse_halo) ? 3 : 2; cx.conv_launches += 1;
         if (cx.dry || cx.err) return o;
         hipError_t er;
         {
@@ -1207,7 +1217,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         }
         if (er == hipSuccess && L.has_norm)
             er = fc::launch_gn_finalize(c.partials, nblk, (double)L.cout * Fo * g.count_T, L.gamma, L.beta, L.cout, e->arch.gn_eps, B, o.aff, cx.st);
-        if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fo, out_halo, L.cout, g.Tout, 0, cx.st);
+        if (er == hipSuccess && out_halo && !fuse_halo) er = fc::launch_halo_rows(o.buf, B, Fo, out_halo, L.cout, g.Tout, 0, cx.st);
         if (er != hipSuccess) { cx.err = 1; g_err = "grouped 2-D conv launch failed (" + L.prefix + "): " + hipGetErrorString(er); }
         return o;
     }
@@ -1218,11 +1228,12 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         Act2 m;
         m.C = C; m.F = x0.F; m.T = x0.T; m.halo = x0.halo;
         m.buf = cx.alloc<float>((size_t)B * (m.F + 2 * m.halo) * C * m.T);
-        cx.launches += 2;
+        const bool fuse_halo = halo_fuse_on() && m.F > m.halo;
+        cx.launches += fuse_halo ? 1 : 2;
         if (!cx.dry && !cx.err) {
             hipError_t er = fc::launch_combine2d(x0.buf, x0.aff, x0.halo, dual ? x1.buf : nullptr, dual ? x1.aff : nullptr, x1.halo, elu,
-                                                 e->arch.elu_alpha, B, m.F, C, m.T, m.buf, m.halo, cx.st);
-            if (er == hipSuccess) er = fc::launch_halo_rows(m.buf, B, m.F, m.halo, C, m.T, 0, cx.st);
+                                                 e->arch.elu_alpha, B, m.F, C, m.T, m.buf, m.halo, cx.st, fuse_halo ? 1 : 0);
+            if (er == hipSuccess && !fuse_halo) er = fc::launch_halo_rows(m.buf, B, m.F, m.halo, C, m.T, 0, cx.st);
             if (er != hipSuccess) { cx.err = 1; g_err = std::string("combine2d launch failed: ") + hipGetErrorString(er); }
         }
         x0 = m; x1 = Act2(); elu = 0; dual = false;
@@ -1322,11 +1333,12 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
     const double fl = 2.0 * B * (Fin + 1) * (double)phases[0].M * 2 * C * 2 * (T + 1) * sf;
     const double by = 4.0 * B * ((double)C * Fin * T * (x1 ? 2 : 1) + (double)cout * Fout * g.Tout);
     cx.conv_flops += fl; cx.conv_bytes += by;
-    cx.launches += sf + 3 + (out_halo ? 1 : 0); cx.conv_launches += sf;
+    cx.launches += sf + 3 + (out_halo ? 1 : 0) - (halo_fuse_on() ? 1 : 0) - ((phases[0].w_group && halo_fuse_on() && out_halo && Fout > out_halo) ? 1 : 0);
+    cx.conv_launches += sf;
     if (cx.dry || cx.err) return o;
     hipError_t er = fc::launch_combine2d(x0.buf, x0.aff, x0.halo, x1 ? x1->buf : nullptr, x1 ? x1->aff : nullptr, x1 ? x1->halo : 0, 1,
-                                         e->arch.elu_alpha, B, Fin, C, T, z.buf, 1, cx.st);
-    if (er == hipSuccess) er = fc::launch_halo_rows(z.buf, B, Fin, 1, C, T, 1, cx.st);
+                                         e->arch.elu_alpha, B, Fin, C, T, z.buf, 1, cx.st, halo_fuse_on() ? 2 : 0);      // 2: its zero rows too
+    if (er == hipSuccess && !halo_fuse_on()) er = fc::launch_halo_rows(z.buf, B, Fin, 1, C, T, 1, cx.st);
     if (phases[0].w_group) {          // grouped (2 in / 1 out channel per group): one direct launch over the untrimmed output
         double* gpart = partials;
         if (er == hipSuccess) {
@@ -1338,12 +1350,13 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
             }
             ProfSpan sp(e, cx, cls, 2.0 * B * (double)cout * 8 * (Fin + 1) * sf * (T + 1) * st, by);
             er = fc::launch_gconvtr2d(z.buf, phases[0].w_group, phases[0].w_plain, o.buf + (long long)out_halo * orow, gpart, B, C, cout, Fin, T, sf, st,
-                                      f_l, Fout, t_trimL, g.Tout, (long long)(Fout + 2 * out_halo) * orow, cx.st);
+                                      f_l, Fout, t_trimL, g.Tout, (long long)(Fout + 2 * out_halo) * orow, cx.st,
+                                      (halo_fuse_on() && Fout > out_halo) ? out_halo : 0);
         }
         if (er == hipSuccess && has_norm)
             er = fc::launch_gn_finalize(gpart, gnblk, (double)cout * (Fin + 1) * sf * g.count_T, phases[0].gamma, phases[0].beta, cout, e->arch.gn_eps,
                                         B, o.aff, cx.st);
-        if (er == hipSuccess && out_halo) er = fc::launch_halo_rows(o.buf, B, Fout, out_halo, cout, g.Tout, 0, cx.st);
+        if (er == hipSuccess && out_halo && !(halo_fuse_on() && Fout > out_halo)) er = fc::launch_halo_rows(o.buf, B, Fout, out_halo, cout, g.Tout, 0, cx.st);
         if (er != hipSuccess) { cx.err = 1; g_err = "grouped 2-D transposed conv launch failed (" + S.prefix + "): " + hipGetErrorString(er); }
         return o;
     }

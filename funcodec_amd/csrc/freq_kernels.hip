@@ -116,9 +116,16 @@ hipError_t launch_halo_rows(float* buf, int B, int F, int halo, int C, int T, in
 // 4-byte-aligned vector type).  These materialisation passes are 13 % of a FreqCodec gr1 call and were streaming dword by dword.
 __global__ __launch_bounds__(256) void combine2d_kernel(const float* __restrict__ s0, const float* __restrict__ aff0, int h0,
                                                         const float* __restrict__ s1, const float* __restrict__ aff1, int h1,
-                                                        int elu, float alpha, int F, int C, int T, float* __restrict__ dst, int hd) {
+                                                        int elu, float alpha, int F, int C, int T, float* __restrict__ dst, int hd, int halo_mode) {
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
     const int b = blockIdx.z, fc = blockIdx.y, f = fc / C, c = fc - f * C;
+    // halo rows of dst written here instead of by a halo_rows launch (round 4): mode 1 = reflect (row -i = row i, row F-1+i = row F-1-i; the
+    // row's own workgroup stores it a second time), mode 2 = zeros (the edge rows' workgroups clear them).  Offsets in rows relative to row f.
+    int m0 = 0, m1 = 0;
+    if (halo_mode == 1) {
+        if (f >= 1 && f <= hd) m0 = -2 * f;
+        if (f <= F - 2 && f >= F - 1 - hd) m1 = 2 * (F - 1 - f);
+    }
     float2 A0 = make_float2(1.f, 0.f), A1 = make_float2(1.f, 0.f);
     if (aff0) A0 = ((const float2*)aff0)[(size_t)b * C + c];
     if (s1 && aff1) A1 = ((const float2*)aff1)[(size_t)b * C + c];
@@ -139,17 +146,31 @@ __global__ __launch_bounds__(256) void combine2d_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = act(x0[j], x1[j]);
             *(f32x4u*)(o + t) = v;
+            if (m0) *(f32x4u*)(o + (long long)m0 * C * T + t) = v;
+            if (m1) *(f32x4u*)(o + (long long)m1 * C * T + t) = v;
         } else {
-            for (int j = 0; t + j < T; ++j) o[t + j] = act(r0[t + j], r1[t + j]);
+            for (int j = 0; t + j < T; ++j) {
+                const float v = act(r0[t + j], r1[t + j]);
+                o[t + j] = v;
+                if (m0) o[(long long)m0 * C * T + t + j] = v;
+                if (m1) o[(long long)m1 * C * T + t + j] = v;
+            }
+        }
+        if (halo_mode == 2) {
+            for (int i = 1; i <= hd; ++i) {
+                if (f == 0) for (int j = 0; j < 4 && t + j < T; ++j) o[-(long long)i * C * T + t + j] = 0.f;
+                if (f == F - 1) for (int j = 0; j < 4 && t + j < T; ++j) o[(long long)i * C * T + t + j] = 0.f;
+            }
         }
     }
 }
 
 hipError_t launch_combine2d(const float* s0, const float* aff0, int h0, const float* s1, const float* aff1, int h1, int elu, float alpha,
-                            int B, int F, int C, int T, float* dst, int hd, hipStream_t st) {
+                            int B, int F, int C, int T, float* dst, int hd, hipStream_t st, int halo_mode) {
     int gx = cdiv(T, 256 * 4);
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(combine2d_kernel, dim3(gx, F * C, B), dim3(256), 0, st, s0, aff0, h0, s1, aff1, h1, elu, alpha, F, C, T, dst, hd);
+    if (halo_mode == 1 && F <= hd) return hipErrorInvalidValue;       // a reflected row would have no source: the caller keeps halo_rows
+    hipLaunchKernelGGL(combine2d_kernel, dim3(gx, F * C, B), dim3(256), 0, st, s0, aff0, h0, s1, aff1, h1, elu, alpha, F, C, T, dst, hd, hd > 0 ? halo_mode : 0);
     return hipGetLastError();
 }
 
@@ -233,6 +254,7 @@ struct GConvArgs {
     int padL, Leff, elu;
     float alpha;
     long long in_sB, in_sF, out_sB, out_sF;      // floats between utterances / frequency rows
+    int out_halo;                                // > 0: reflected halo rows of the output written by the rows' own workgroups (Fo > out_halo)
 };
 
 // Where the group's weights come from: (KF >= 4) the strided 8-row layers read them as uniform SCALAR loads -- staged in LDS the compiler
@@ -383,10 +405,23 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
             }
             if (!live) continue;
             float* orow = p.out + (size_t)b * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.Tout + n0;
-            if (n0 + 3 < p.Tout) *(f32x4u*)orow = (f32x4){ov[0], ov[1], ov[2], ov[3]};
-            else
+            // reflected halo rows of the output (row -i = row i, row Fo-1+i = row Fo-1-i): this row's second / third store
+            const int h = p.out_halo;
+            const long long mir0 = (h && fo >= 1 && fo <= h) ? -2ll * fo * p.out_sF : 0;
+            const long long mir1 = (h && fo <= p.Fo - 2 && fo >= p.Fo - 1 - h) ? 2ll * (p.Fo - 1 - fo) * p.out_sF : 0;
+            if (n0 + 3 < p.Tout) {
+                const f32x4 o4 = {ov[0], ov[1], ov[2], ov[3]};
+                *(f32x4u*)orow = o4;
+                if (mir0) *(f32x4u*)(orow + mir0) = o4;
+                if (mir1) *(f32x4u*)(orow + mir1) = o4;
+            } else
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (n0 + j < p.Tout) orow[j] = ov[j];
+                for (int j = 0; j < 4; ++j)
+                    if (n0 + j < p.Tout) {
+                        orow[j] = ov[j];
+                        if (mir0) orow[mir0 + j] = ov[j];
+                        if (mir1) orow[mir1 + j] = ov[j];
+                    }
         }
     }
     if (p.partials) {
@@ -590,6 +625,7 @@ static int gconv2d_fo(int kf, int Fo) {
     const int f = fo3 < 1 ? 1 : (fo3 > 4 ? 4 : fo3);
     return f < Fo ? f : Fo;
 }
+bool gconv2d_fuses_halo(int kf, int kt, int st, int Fo, int halo) { return halo > 0 && Fo > halo && !gconv2d_lds3(kf, kt, st); }
 int gconv2d_nblk(int Tout, int Fo, int G, int kf) {
     if (gconv2d_lds3(kf, kf, 1)) return cdiv(Tout, G3_TN) * cdiv(Fo, G3_RF) * G;       // (the grouped layers are square: kt == kf for kf == 3)
     return cdiv(Tout, 1024) * cdiv(Fo, gconv2d_fo(kf, Fo)) * G;
@@ -604,6 +640,7 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
     a.elu = c.elu; a.alpha = c.alpha;
     a.in_sB = c.in_sB; a.in_sF = c.in_sF; a.out_sB = c.out_sB; a.out_sF = c.out_sF;
+    a.out_halo = gconv2d_fuses_halo(c.kf, c.kt, c.st, c.Fo, c.out_halo) ? c.out_halo : 0;
     const int fo_n = gconv2d_fo(c.kf, c.Fo);
     if (c.kf >= 4 ? c.sf != c.kf / 2 : c.sf != 1) return hipErrorInvalidValue;          // the kernel's compile-time row stride
     if (gconv2d_lds3(c.kf, c.kt, c.st)) {
@@ -668,6 +705,7 @@ struct GConvTrArgs {
     long long out_sB;
     int nx, ny, nz;          // logical grid: column tiles, (input-row pairs x channel chunks) or untrimmed output rows, utterances
     int cs;                  // channel chunks per input-row pair (<= fr)
+    int out_halo;            // > 0: reflected halo rows of the (trimmed) output written by the rows' own workgroups (Fout > out_halo)
 };
 
 #ifndef FC_GCONVTR_DPP
@@ -792,12 +830,24 @@ __global__ __launch_bounds__(256) void gconvtr2d_kernel(const GConvTrArgs p) {
                 if (row_ok) {
                     float* orow = p.out + (size_t)b * p.out_sB + ((size_t)fo * p.cout + co) * p.Tout;
                     const int to0 = tu0 - p.trimL;
-                    if (to0 >= 0 && to0 + 3 < p.Tout) *(f32x4u*)(orow + to0) = (f32x4){ov[0], ov[1], ov[2], ov[3]};     // one 16-byte store (round 3)
-                    else
+                    const int h = p.out_halo;
+                    const long long rsz = (long long)p.cout * p.Tout;
+                    const long long mir0 = (h && fo >= 1 && fo <= h) ? -2ll * fo * rsz : 0;
+                    const long long mir1 = (h && fo <= p.Fout - 2 && fo >= p.Fout - 1 - h) ? 2ll * (p.Fout - 1 - fo) * rsz : 0;
+                    if (to0 >= 0 && to0 + 3 < p.Tout) {                                                                   // one 16-byte store (round 3)
+                        const f32x4 o4 = {ov[0], ov[1], ov[2], ov[3]};
+                        *(f32x4u*)(orow + to0) = o4;
+                        if (mir0) *(f32x4u*)(orow + mir0 + to0) = o4;
+                        if (mir1) *(f32x4u*)(orow + mir1 + to0) = o4;
+                    } else
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int to = to0 + j;
-                            if (to >= 0 && to < p.Tout) orow[to] = ov[j];
+                            if (to >= 0 && to < p.Tout) {
+                                orow[to] = ov[j];
+                                if (mir0) orow[mir0 + to] = ov[j];
+                                if (mir1) orow[mir1 + to] = ov[j];
+                            }
                         }
                 }
             }
@@ -828,10 +878,11 @@ bool gconvtr2d_ok(int cpg, int opg, int tr) { return cpg == 2 && opg == 1 && (tr
 int gconvtr2d_nblk(int Tin, int tr, int Fin, int fr) { return cdiv((Tin + 1) * tr, 1024) * (Fin + 1) * fr; }
 
 hipError_t launch_gconvtr2d(const float* z, const float* w, const float* bias, float* out, double* partials, int B, int C, int cout, int Fin,
-                            int Tin, int fr, int tr, int f_l, int Fout, int trimL, int Tout, long long out_sB, hipStream_t st) {
+                            int Tin, int fr, int tr, int f_l, int Fout, int trimL, int Tout, long long out_sB, hipStream_t st, int out_halo) {
     GConvTrArgs a;
     a.z = z; a.w = w; a.bias = bias; a.out = out; a.partials = partials;
     a.C = C; a.cout = cout; a.Fin = Fin; a.Tin = Tin; a.fr = fr; a.f_l = f_l; a.Fout = Fout; a.trimL = trimL; a.Tout = Tout; a.out_sB = out_sB;
+    a.out_halo = (out_halo > 0 && Fout > out_halo) ? out_halo : 0;
     if ((Fin + 1) * fr > 65535 || B > 65535) return hipErrorInvalidValue;
     static const int cs_env = getenv("FC_GCONVTR_CS") ? atoi(getenv("FC_GCONVTR_CS")) : 0;       // A / B aid
     a.nx = cdiv((Tin + 1) * tr, 1024);

@@ -83,21 +83,26 @@ struct GConvLaunch {
     int B = 0, C = 0, M = 0, G = 1, Tin = 0, Tout = 0, Fo = 0, kf = 1, kt = 1, sf = 1, st = 1, padL = 0, padR = 0, elu = 0;
     float alpha = 1.f;
     long long in_sB = 0, in_sF = 0, out_sB = 0, out_sF = 0;
+    int out_halo = 0;      // > 0: the kernel also writes the reflected halo rows of its output (row -i = row i, row Fo-1+i = row Fo-1-i) --
+                           // only honoured when gconv2d_fuses_halo() says so, else the caller runs launch_halo_rows
 };
 bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st);
+bool gconv2d_fuses_halo(int kf, int kt, int st, int Fo, int halo);
 int gconv2d_nblk(int Tout, int Fo, int G, int kf);
 hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st);
 // grouped ConvTranspose2d((2 fr, 2 tr), stride (fr, tr)), 2 input / 1 output channel per group, over the materialised ELU'd input z
 bool gconvtr2d_ok(int cpg, int opg, int tr);
 int gconvtr2d_nblk(int Tin, int tr, int Fin, int fr);
 hipError_t launch_gconvtr2d(const float* z, const float* w, const float* bias, float* out, double* partials, int B, int C, int cout, int Fin,
-                            int Tin, int fr, int tr, int f_l, int Fout, int trimL, int Tout, long long out_sB, hipStream_t st);
+                            int Tin, int fr, int tr, int f_l, int Fout, int trimL, int Tout, long long out_sB, hipStream_t st,
+                            int out_halo = 0 /* > 0 (and < Fout): reflected halo rows of the output written by the kernel */);
 hipError_t launch_polyphase_in(const float* wav, const float* div, int B, int T, int hop, int n_fft, int Mp, float* xp, hipStream_t st);
 hipError_t launch_stft_feats(const float* spec, int B, int F, int Tp, long long spec_sB, int halo, int C, float* feats, hipStream_t st);
 hipError_t launch_feats_relayout(float* eng, float* ref, int B, int C, int F, int Tp, int halo, int to_ref, hipStream_t st);
 hipError_t launch_halo_rows(float* buf, int B, int F, int halo, int C, int T, int zero, hipStream_t st);
 hipError_t launch_combine2d(const float* s0, const float* aff0, int h0, const float* s1, const float* aff1, int h1, int elu, float alpha,
-                            int B, int F, int C, int T, float* dst, int hd, hipStream_t st);
+                            int B, int F, int C, int T, float* dst, int hd, hipStream_t st,
+                            int halo_mode = 0 /* 1: also write dst's hd reflected halo rows (needs F > hd), 2: zero them */);
 hipError_t launch_spec_from_dec(const float* dec, const float* aff, int B, int F, int Tp, int halo, int C, float* spec, hipStream_t st);
 hipError_t launch_istft_finish(const float* ypoly, const float* win2, int B, int hop, int n_fft, int Mp, int Tp, const float* mul, int out_len,
                                float* wav, hipStream_t st);
