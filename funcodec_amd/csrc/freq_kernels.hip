@@ -273,7 +273,7 @@ struct GConvArgs {
 #else
 #define FC_GCONV_ATTR
 #endif
-template <int CPG, int OPG, int KF, int KT, int ST, bool DUAL, int FO>
+template <int CPG, int OPG, int KF, int KT, int ST, bool DUAL, int FO, bool NEEDMASK>
 __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvArgs p) {
     // FO = output frequency rows per lane (rows fo0, fo0 + 1): the KF + (FO - 1) SF input rows they read are loaded and activated once
     // instead of FO x KF times (3x3: 4 rows instead of 6; 8-row stride-4 layers: 12 instead of 16)
@@ -325,6 +325,10 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[f][o][j] = 0.f;
     const bool live = n0 < p.Tout;
+    // Round 4: the select that zeroes columns without a source is compiled in only for rows not longer than the padding (NEEDMASK, chosen by
+    // the launcher: Leff != Tin, the reference zero-extends those before reflecting) -- for longer rows every column a VALID output reads has
+    // a reflected source, and the columns without one feed discarded outputs only.  (Both variants behind a branch in one kernel, or the edge
+    // lanes' gathers as one divergent region per row instead of one per element: 256 registers, one wave per SIMD -- not run.)
     if (live) {
         // the stride between the FO rows' windows is a run-time value; the reference's 2-D nets use sf == KF / 2 for strided layers and
         // sf == 1 otherwise, which is what the (row, output) -> tap table below is unrolled for
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     float v0 = r0[ci][j >> 2][j & 3], v1 = DUAL ? r1[ci][j >> 2][j & 3] : 0.f;
-                    if (!vec_ok) {               // padded edge: gather by index
+                    if (!vec_ok) {
                         const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)ci * p.Tin + esrc[j];
                         v0 = p.src0[off];
                         if (DUAL) v1 = p.src1[off];
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
                     float v = fmaf(v0, A.x, A.y);
                     if (DUAL) v = v + fmaf(v1, A1.x, A1.y);
                     if (p.elu) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f); v = v > 0.f ? v : fmaf(e, p.alpha, -p.alpha); }
-                    x[j] = ((vmask >> j) & 1u) ? v : 0.f;
+                    x[j] = (!NEEDMASK || ((vmask >> j) & 1u)) ? v : 0.f;
                 }
 #pragma unroll
                 for (int f = 0; f < FO; ++f) {
@@ -664,27 +668,27 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     dim3 grid(cdiv(c.Tout, 1024), c.G, c.B * cdiv(c.Fo, fo_n)), block(256);
     const int cpg = c.C / c.G, opg = c.M / c.G;
     const bool dual = c.src1 != nullptr;
+    const bool nm = a.Leff != a.Tin;               // rows not longer than the padding: columns without a source must read as zeros
+#define FC_GCL(CP, OP, KF_, KT_, ST_, FO_)                                                                                    \
+    do {                                                                                                                     \
+        if (dual && nm) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, FO_, true>), grid, block, 0, st, a);         \
+        else if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, FO_, false>), grid, block, 0, st, a);         \
+        else if (nm) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, FO_, true>), grid, block, 0, st, a);           \
+        else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, FO_, false>), grid, block, 0, st, a);                  \
+    } while (0)
 #define FC_GC(CP, OP, KF_, KT_, ST_)                                                                                         \
     if (cpg == CP && opg == OP && c.kf == KF_ && c.kt == KT_ && c.st == ST_) {                                               \
-        if (fo_n == 2) {                                                                                                     \
-            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, (KF_ == 3 ? 2 : 1)>), grid, block, 0, st, a);    \
-            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, (KF_ == 3 ? 2 : 1)>), grid, block, 0, st, a);        \
-        } else if (fo_n == 3) {                                                                                              \
-            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, (KF_ == 3 ? 3 : 1)>), grid, block, 0, st, a);    \
-            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, (KF_ == 3 ? 3 : 1)>), grid, block, 0, st, a);        \
-        } else if (fo_n == 4) {                                                                                              \
-            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, (KF_ == 3 ? 4 : 1)>), grid, block, 0, st, a);    \
-            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, (KF_ == 3 ? 4 : 1)>), grid, block, 0, st, a);        \
-        } else {                                                                                                             \
-            if (dual) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, 1>), grid, block, 0, st, a);            \
-            else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, 1>), grid, block, 0, st, a);                \
-        }                                                                                                                    \
+        if (fo_n == 2) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 2 : 1));                                                    \
+        else if (fo_n == 3) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 3 : 1));                                               \
+        else if (fo_n == 4) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 4 : 1));                                               \
+        else FC_GCL(CP, OP, KF_, KT_, ST_, 1);                                                                               \
         return hipGetLastError();                                                                                            \
     }
 #define FC_GCS(KF_, KT_, ST_) FC_GC(2, 2, KF_, KT_, ST_) FC_GC(4, 2, KF_, KT_, ST_) FC_GC(2, 4, KF_, KT_, ST_)
     FC_GCS(1, 1, 1) FC_GCS(3, 3, 1) FC_GCS(8, 2, 1) FC_GCS(8, 4, 2)
 #undef FC_GCS
 #undef FC_GC
+#undef FC_GCL
     return hipErrorInvalidValue;
 }
 
