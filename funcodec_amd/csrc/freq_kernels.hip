@@ -328,7 +328,10 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
     // Round 4: the select that zeroes columns without a source is compiled in only for rows not longer than the padding (NEEDMASK, chosen by
     // the launcher: Leff != Tin, the reference zero-extends those before reflecting) -- for longer rows every column a VALID output reads has
     // a reflected source, and the columns without one feed discarded outputs only.  (Both variants behind a branch in one kernel, or the edge
-    // lanes' gathers as one divergent region per row instead of one per element: 256 registers, one wave per SIMD -- not run.)
+    // lanes' gathers as one divergent region per row instead of one per element: 256 registers, one wave per SIMD -- not run.  A ROLLED form --
+    // a real loop over row pairs with the frequency tap as a run-time index into a zero-padded LDS weight table, so that the 72 weights are
+    // not held in vector registers: 196 registers without the edge gathers, 256 with them, 107 spills at a forced 168 -- not run either: the
+    // per-element gather addresses, not the weights, are what fills the register file.)
     if (live) {
         // the stride between the FO rows' windows is a run-time value; the reference's 2-D nets use sf == KF / 2 for strided layers and
         // sf == 1 otherwise, which is what the (row, output) -> tap table below is unrolled for
