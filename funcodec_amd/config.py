@@ -509,7 +509,7 @@ def fuzz_recipe_config(seed: int) -> Dict[str, Any]:
     hop = 1
     for x in ratios:
         hop *= x
-    return {
+    cfg = {
         "input_size": 1, "sampling_rate": 16000,
         "encoder": "encodec_seanet_encoder", "encoder_conf": enc,
         "quantizer": "costume_quantizer",
@@ -521,6 +521,13 @@ def fuzz_recipe_config(seed: int) -> Dict[str, Any]:
         "model_conf": {"odim": dim, "multi_spectral_window_powers_of_two": [], "target_sample_hz": 16000,
                        "audio_normalize": r.random() < 0.7, "use_power_spec_loss": True, "segment_dur": None, "overlap_ratio": None},
     }
+    if seed >= 3000:          # round 4 (drawn last: the committed seeds keep their architectures): stereo models, first stage at half rate
+        if r.random() < 0.5:
+            cfg["input_size"] = 2
+            dec["channels"] = 2
+        if r.random() < 0.5:
+            cfg["quantizer_conf"]["q0_ds_ratio"] = r.choice([2, 2, 4])
+    return cfg
 
 
 def recipe_config(name: str) -> Dict[str, Any]:

@@ -21,9 +21,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         m.load_state_dict(tsd)
         orc = (FreqOracle if FREQ else Oracle)(cfg, tsd)
         B, T = 1 + seed % 3, 1200 + 211 * (seed % 17)
-        wav = audio(B, T, 5000 + seed, "tones" if seed % 2 else "noise")
+        ch = 2 if (not FREQ and arch.input_channels == 2) else 1
+        wav = audio(B, T, 5000 + seed, "tones" if seed % 2 else "noise", ch)
         o = orc.inference(wav, None, True)
-        r = m.inference(wav.cuda().unsqueeze(1), bit_width=None, use_scale=True)
+        r = m.inference(wav.cuda() if ch > 1 else wav.cuda().unsqueeze(1), bit_width=None, use_scale=True)
         m.engine.check_status()
         rep = index_report(r["code_indices"][0], o["code_indices"][0])
         ref = float(o["recon_speech"].double().pow(2).mean().sqrt()) if FREQ else 1.0
@@ -33,7 +34,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         print(f"{name}: n_fft {arch.n_fft}/{arch.stft_hop} rf {arch.ratios_f} gr {arch.enc_conv_group_ratio} " if FREQ else "", end="")
         print(f"{name}: ratios {arch.ratios} nf {arch.n_filters} k {arch.kernel_size}/{arch.last_kernel_size}/{arch.residual_kernel_size} "
               f"res {arch.n_residual_layers}x{arch.dilation_base} lstm {arch.lstm_layers} {arch.norm}{' causal' if arch.causal else ''} "
-              f"K {arch.codebook_size} nq {arch.num_quantizers}: frames_bad {rep['frames_bad']}/{rep['frames']} wav rms {w:.2e}{flag}", flush=True)
+              f"K {arch.codebook_size} nq {arch.num_quantizers}{' stereo' if arch.input_channels == 2 and not FREQ else ''}{' q0' if arch.q0_ds_ratio > 1 else ''}: frames_bad {rep['frames_bad']}/{rep['frames']} wav rms {w:.2e}{flag}", flush=True)
         del m
     except Exception as ex:
         bad += 1
