@@ -268,6 +268,9 @@ struct GConvArgs {
 #ifndef FC_GCONV_WAVES
 #define FC_GCONV_WAVES 0
 #endif
+#ifndef FC_GCONV_ABL
+#define FC_GCONV_ABL 0        // profiling builds (results are garbage): 1 no ELU arithmetic, 2 a quarter of the FMAs
+#endif
 #if FC_GCONV_WAVES > 0
 #define FC_GCONV_ATTR __attribute__((amdgpu_waves_per_eu(FC_GCONV_WAVES, FC_GCONV_WAVES)))
 #else
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
                     }
                     float v = fmaf(v0, A.x, A.y);
                     if (DUAL) v = v + fmaf(v1, A1.x, A1.y);
-                    if (p.elu) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f); v = v > 0.f ? v : fmaf(e, p.alpha, -p.alpha); }
+                    if (p.elu && !(FC_GCONV_ABL & 1)) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f); v = v > 0.f ? v : fmaf(e, p.alpha, -p.alpha); }
                     x[j] = (!NEEDMASK || ((vmask >> j) & 1u)) ? v : 0.f;
                 }
 #pragma unroll
@@ -387,7 +390,8 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
                     for (int o = 0; o < OPG; ++o)
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk) {
-                            const float wv = wgp[((o * CPG + ci) * KF + a) * KT + kk];
+                                    const float wv = wgp[((o * CPG + ci) * KF + a) * KT + kk];
+                            if (FC_GCONV_ABL & 2) { acc[f][o][0] += wv * x[kk]; continue; }       // profiling build: a quarter of the FMAs
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[f][o][j] = fmaf(wv, x[j * ST + kk], acc[f][o][j]);
                         }
