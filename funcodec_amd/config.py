@@ -45,6 +45,9 @@ class ArchSpec:
     encoder_hop_length: int = 320
     quantizer_sampling_rate: int = 16000
     use_ddp: bool = True
+    # model_conf.bypass_quantizer (codec_basic.py:148,700-701 / codec_freq.py:698): Encodec.inference returns the ENCODER output as the code
+    # embeddings, zero indices [B, Tf] and zero sub_quants, and decodes from the encoder output; inference_encoding still quantises
+    bypass_quantizer: bool = False
     # > 1: the first stage quantises the nearest-neighbour half-rate sequence (ddp_core_vq.py:354-356,396-404; the value itself is not
     # used by the reference beyond "> 1": it always halves)
     q0_ds_ratio: int = 1
@@ -202,8 +205,6 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
     # `stft_self_noise`).  The engine runs the recipe; what its parity tests pin is said in tests/test_gpu_parity.py (features modulo 2 pi,
     # the whole path from the reference's features, the decode path from the reference's codes).
     n_in = 3 if domain[0] == "mag_phase" else 2
-    if m.get("bypass_quantizer", False):
-        raise _unsupported("model_conf.bypass_quantizer", True)
     if cfg.get("input_size", 1) != n_in or dec.get("channels", 1) != n_in:
         raise _unsupported("input_size/channels", (cfg.get("input_size", 1), dec.get("channels", 1)),
                            "mag_phase: 3 (log-magnitude, phase re, phase im); mag_angle: 2 (log-magnitude, angle)")
@@ -251,7 +252,8 @@ def _freq_arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         codebook_size=int(q.get("codebook_size", 1024)), codebook_dim=codec_dim, num_quantizers=int(q.get("num_quantizers", 8)),
         codec_range=None if codec_range is None else float(codec_range),
         encoder_hop_length=int(q.get("encoder_hop_length", 320)), quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
-        use_ddp=bool(q.get("use_ddp", True)), q0_ds_ratio=q0_ds_ratio, norm=str(shared("norm", "weight_norm")), causal=bool(shared("causal", False)),
+        use_ddp=bool(q.get("use_ddp", True)), q0_ds_ratio=q0_ds_ratio, bypass_quantizer=bool(m.get("bypass_quantizer", False)),
+        norm=str(shared("norm", "weight_norm")), causal=bool(shared("causal", False)),
         segment_dur=None if seg is None else float(seg), overlap_ratio=0.01 if ov is None else float(ov),
         model_type="freq_codec", n_fft=int(dc.get("n_fft", 512)), stft_hop=int(dc.get("hop_length", 160)),
         enc_conv_group_ratio=int(enc.get("conv_group_ratio", -1)), dec_conv_group_ratio=int(dec.get("conv_group_ratio", -1)),
@@ -310,8 +312,6 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         raise _unsupported("input_size/channels", (input_size, dec.get("channels", 1)), "1 / 1 (mono) or 2 / 2 (stereo)")
     if m.get("codec_domain", "time") not in ("time", None):
         raise _unsupported("model_conf.codec_domain", m["codec_domain"])
-    if m.get("bypass_quantizer", False):
-        raise _unsupported("model_conf.bypass_quantizer", True)
     # the decoder's input_size is injected by build_model from quantizer.output_size()
     # (gan_speech_codec.py:325-329) == encoder dimension when codec_dim is unset
     dimension = int(enc.get("dimension", 128))
@@ -357,6 +357,7 @@ def arch_from_config(cfg: Dict[str, Any]) -> ArchSpec:
         quantizer_sampling_rate=int(q.get("sampling_rate", 24000)),
         use_ddp=bool(q.get("use_ddp", True)),
         q0_ds_ratio=q0_ds_ratio,
+        bypass_quantizer=bool(m.get("bypass_quantizer", False)),
         norm=str(shared("norm", "weight_norm")),
         causal=bool(shared("causal", False)),
         segment_dur=None if segment_dur is None else float(segment_dur),
@@ -541,6 +542,13 @@ def recipe_config(name: str) -> Dict[str, Any]:
         cfg = recipe_config({"tinyst": "tiny", "ds320st": "ds320", "tinystwn": "tinywn", "ds320stseg": "ds320seg"}[name])
         cfg["input_size"] = 2
         cfg["decoder_conf"]["channels"] = 2
+        return cfg
+    if name in ("tinybypass", "tinybypassseg"):          # model_conf.bypass_quantizer (codec_basic.py:700-701), also in segmented mode
+        cfg = recipe_config("tiny")
+        cfg["model_conf"]["bypass_quantizer"] = True
+        if name.endswith("seg"):
+            cfg["model_conf"]["segment_dur"] = 0.05          # 800-sample frames
+            cfg["model_conf"]["overlap_ratio"] = 0.1
         return cfg
     if name in ("tinyq0", "ds320q0", "ss320q0"):
         # quantizer_conf.q0_ds_ratio > 1 (ddp_core_vq.py:354-356,396-404): first stage on the half-rate sequence.  "tinyq0" asks for 3:

@@ -53,7 +53,7 @@ class EncodecMI355X:
         return speech
 
     # -- Encodec._encode / _decode with segment_dur set (codec_basic.py:334-359,382-396,77-116) --
-    def _inference_segmented(self, wav: torch.Tensor, n_q: int, need_recon: bool, use_scale: bool):
+    def _inference_segmented(self, wav: torch.Tensor, n_q: int, need_recon: bool, use_scale: bool, bypass: bool = False):
         """Every frame is an independent utterance for the engine (own volume scale, GroupNorm statistics, LSTM state), so
         all frames of equal length go through ONE engine call as extra batch rows; the ragged tail frames follow.  Like the
         reference's _decode, every frame is decoded to its FULL length ceil(len/hop)*hop (longer than the segment when the
@@ -69,13 +69,14 @@ class EncodecMI355X:
             by_len.setdefault(n, []).append(i)
         for n, ids in by_len.items():
             stack = torch.cat([wav[..., offsets[i]:offsets[i] + n] for i in ids], 0).contiguous()   # [len(ids)*B, (C,) n]
-            r = self.engine.encode(stack, n_q)
+            r = self._encode_or_bypass(stack, n_q, bypass)
             rec = None
             if need_recon:
                 rec = self.engine.decode_emb(r["quantized"], r["scale"] if use_scale else None)   # untrimmed: Tf*hop samples
             for j, i in enumerate(ids):
                 sl = slice(j * B, (j + 1) * B)
-                results[i] = dict(codes=r["codes"][:, sl], quantized=r["quantized"][sl], sub_quants=r["sub_quants"][:, sl],
+                results[i] = dict(codes=r["codes"][sl] if bypass else r["codes"][:, sl], quantized=r["quantized"][sl],
+                                  sub_quants=r["sub_quants"][sl] if bypass else r["sub_quants"][:, sl],
                                   scale=r["scale"][sl] if r.get("scale") is not None else None,
                                   recon=rec[sl] if need_recon else None)
         recon = None
@@ -85,17 +86,35 @@ class EncodecMI355X:
                     code_embeddings=[(r["quantized"], r["scale"] if use_scale else None) for r in results],
                     sub_quants=[r["sub_quants"] for r in results])
 
+    def _encode_or_bypass(self, wav: torch.Tensor, n_q: int, bypass: bool):
+        """engine.encode, or with model_conf.bypass_quantizer (codec_basic.py:700-701, Encodec.inference only) the encoder output in place of
+        the quantised embeddings, zero indices [B, Tf] and zero sub_quants like the reference builds them."""
+        if not bypass:
+            return self.engine.encode(wav, n_q)
+        r = self.engine.encode(wav, 1, want_sub_quants=False, want_enc_out=True)     # the quantiser's stage is computed and dropped
+        emb = r["enc_out"]
+        return dict(codes=torch.zeros(emb.shape[0], emb.shape[1], dtype=torch.long, device=emb.device), quantized=emb,
+                    sub_quants=torch.zeros_like(emb), scale=r["scale"])
+
     # -- Encodec.inference (codec_basic.py:670-718) ------------------------------------------
     @torch.no_grad()
     def inference(self, speech: torch.Tensor, need_recon: bool = True, bit_width: int = None,
-                  use_scale: bool = True) -> Dict[str, torch.Tensor]:
+                  use_scale: bool = True, _quantise_always: bool = False) -> Dict[str, torch.Tensor]:
         speech = self._as_bct(speech)
+        bypass = self.arch.bypass_quantizer and not _quantise_always
         n_q = self.arch.num_quantizers_for_bandwidth(bit_width)
         wav = speech[:, 0, :] if self.engine.channels == 1 else speech
         if self.arch.segment_length is not None:
             wav = wav.to(self.device, torch.float32)
-            return self._inference_segmented(wav, n_q, need_recon, use_scale)
-        if need_recon:
+            return self._inference_segmented(wav, n_q, need_recon, use_scale, bypass)
+        if bypass:
+            r = self._encode_or_bypass(wav, n_q, True)
+            recon = None
+            if need_recon:             # _decode_frame on the encoder output, trimmed like recon[:, :, :T] (:711)
+                T = wav.shape[-1]
+                recon = self.engine.decode_emb(r["quantized"], r["scale"] if use_scale else None,
+                                               out_len=min(T, self.engine.decoded_samples(r["quantized"].shape[1])))
+        elif need_recon:
             r = self.engine.encode_decode(wav, n_q, use_scale=use_scale)
             recon = r["recon"]
         else:
@@ -109,7 +128,8 @@ class EncodecMI355X:
     @torch.no_grad()
     def inference_encoding(self, speech: torch.Tensor, need_recon: bool = False, bit_width: int = None,
                            use_scale: bool = True) -> Dict[str, torch.Tensor]:
-        return self.inference(speech, need_recon=need_recon, bit_width=bit_width, use_scale=use_scale)
+        # (model_conf.bypass_quantizer does not reach this entry point in the reference: it quantises, :748-750)
+        return self.inference(speech, need_recon=need_recon, bit_width=bit_width, use_scale=use_scale, _quantise_always=True)
 
     # -- Encodec.inference_decoding (codec_basic.py:766-802) ---------------------------------
     @torch.no_grad()

@@ -151,6 +151,13 @@ SEG_CASES = [
 ]
 
 
+# model_conf.bypass_quantizer: (name, config, weight seed, audio kind, audio seed, B, T)
+BYPASS_CASES = [
+    ("tinybypass_b2_t900", "tinybypass", 7, "tones", 131, 2, 900),
+    ("tinybypassseg_b2_t2000", "tinybypassseg", 7, "noise", 132, 2, 2000),
+]
+
+
 def reference_config(cfg):
     """The two tweaks SURVEY.md §8c lists for running the reference on a GPU-less box."""
     cfg = json.loads(json.dumps(cfg))
@@ -270,6 +277,32 @@ def main():
             if C > 1:
                 manifest["cases"][name]["channels"] = C
             print(f"[golden] {name}: {len(idx)} frames {[tuple(i.shape) for i in idx]} oracle==reference OK")
+
+        # ---- model_conf.bypass_quantizer (codec_basic.py:148,700-705): Encodec.inference hands the ENCODER output on as code embeddings,
+        # zero indices [B, Tf], zero sub_quants, and decodes from it; inference_encoding (run_mod "encode") still quantises
+        for name, cfg_name, wseed, akind, aseed, B, T in BYPASS_CASES:
+            if only is not None and name not in only:
+                continue
+            s2t, cfg, sd = build_reference(cfg_name, wseed, 1.0, tmp)
+            x = torch.from_numpy(synthetic_audio(B, T, aseed, akind))
+            idx, embs, recon, subs = s2t(x.unsqueeze(1), bit_width=None, use_scale=True, run_mod="inference")
+            idx_e, embs_e, _, _ = s2t(x.unsqueeze(1), bit_width=None, run_mod="encode")
+            assert all(int(i.abs().max()) == 0 and i.dim() == 2 for i in idx) and idx_e[0].dim() == 3
+            orc = Oracle(cfg, {k: torch.from_numpy(v) for k, v in sd.items()})
+            o = orc.inference(x, bit_width=None, use_scale=True)
+            arrays = {}
+            for f in range(len(idx)):
+                assert torch.equal(o["code_indices"][f], idx[f]) and torch.equal(o["code_embeddings"][f][0], embs[f][0])
+                assert torch.equal(o["sub_quants"][f], subs[f])
+                arrays[f"emb_{f}"] = embs[f][0].numpy()
+                arrays[f"scale_{f}"] = embs[f][1].numpy()
+            assert torch.equal(o["recon_speech"], recon), f"{name}: oracle recon != reference"
+            arrays.update(recon=recon.numpy(), encode_indices_0=idx_e[0].numpy().astype(np.int16))
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), **arrays)
+            manifest["cases"][name] = dict(kind="bypass", config=cfg_name, weight_seed=wseed, codebook_decay=1.0, audio_kind=akind,
+                                           audio_seed=aseed, batch=B, samples=T, bit_width=None, n_q=int(idx_e[0].shape[0]),
+                                           frames=[int(e[0].shape[1]) for e in embs])
+            print(f"[golden] {name}: {len(idx)} frame(s), emb {tuple(embs[0][0].shape)} recon {tuple(recon.shape)} oracle==reference OK")
 
         # ---- `use_ddp: false` quantiser (core_vq.ResidualVectorQuantization, core_vq.py:324-396): the CostumeQuantizer wrapper
         # cannot construct it at this commit (vq.py:73 passes q0_ds_ratio to a ctor that does not take it), so the class is

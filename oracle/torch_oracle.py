@@ -304,7 +304,7 @@ class Oracle:
         for off in range(0, T, stride):
             frame = speech[:, :, off:off + seg]
             emb, scale = self.encode_frame(frame)
-            quant, idx, subs = self.rvq_forward(emb, self.n_q_for(bit_width))
+            quant, idx, subs = self._quantise(emb, bit_width)
             idxs.append(idx); embs.append((quant, scale if use_scale else None)); subs_all.append(subs)
             encs.append(emb); scales.append(scale)
             if need_recon:
@@ -316,6 +316,12 @@ class Oracle:
         return dict(code_indices=idxs, code_embeddings=embs, recon_speech=recon, sub_quants=subs_all,
                     encoder_out=encs, scale=scales)
 
+    def _quantise(self, emb, bit_width):
+        """the quantiser call of Encodec.inference, or model_conf.bypass_quantizer's stand-ins (codec_basic.py:700-705)"""
+        if self.cfg.get("model_conf", {}).get("bypass_quantizer", False):
+            return emb, torch.zeros(emb.shape[0], emb.shape[1], dtype=torch.long), torch.zeros_like(emb)
+        return self.rvq_forward(emb, self.n_q_for(bit_width))
+
     @torch.no_grad()
     def inference(self, speech: torch.Tensor, bit_width=None, use_scale=True, need_recon=True):
         """Encodec.inference codec_basic.py:670-718 (one frame when segment_dur is null)."""
@@ -324,7 +330,7 @@ class Oracle:
         if speech.dim() == 2:
             speech = speech.unsqueeze(1)
         emb, scale = self.encode_frame(speech)
-        quant, idx, subs = self.rvq_forward(emb, self.n_q_for(bit_width))
+        quant, idx, subs = self._quantise(emb, bit_width)
         recon = None
         if need_recon:
             recon = self.decoder(quant)

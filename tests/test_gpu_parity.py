@@ -13,7 +13,7 @@ from helpers import (audio, engine_for, golden, index_report, manifest, oracle_f
 
 pytestmark = pytest.mark.gpu
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg", "variants")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg", "variants", "bypass")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 FREQ = [n for n, c in MAN["cases"].items() if c.get("kind") == "freq" and not c["config"].endswith("ang")]
 FREQ_ANGLE = [n for n, c in MAN["cases"].items() if c.get("kind") == "freq" and c["config"].endswith("ang")]
@@ -107,6 +107,30 @@ def test_segmented_mode_against_reference_golden(name):
     # frames of one call are independent utterances: the first frame alone gives the same codes
     one = m.engine.encode(wav[..., :8000], c["n_q"])
     assert torch.equal(one["codes"], r["code_indices"][0])
+
+
+@pytest.mark.parametrize("name", [n for n, c in MAN["cases"].items() if c.get("kind") == "bypass"])
+def test_bypass_quantizer_against_reference_golden(name):
+    """model_conf.bypass_quantizer (codec_basic.py:148,700-705): Encodec.inference hands the encoder output on as the code embeddings with zero
+    indices [B, Tf] and zero sub_quants and decodes from it (also per frame in segmented mode); inference_encoding still quantises.  Golden =
+    the real reference."""
+    c = MAN["cases"][name]
+    m = engine_for(c["config"], c["weight_seed"])
+    assert m.arch.bypass_quantizer
+    wav = audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"])
+    g = golden(name)
+    r = m.inference(wav.unsqueeze(1), bit_width=None, use_scale=True)
+    assert len(r["code_indices"]) == len(c["frames"])
+    for f, Tf in enumerate(c["frames"]):
+        emb, scale = r["code_embeddings"][f]
+        assert r["code_indices"][f].shape == (c["batch"], Tf) and r["code_indices"][f].dtype == torch.long and int(r["code_indices"][f].abs().max()) == 0
+        assert r["sub_quants"][f].shape == emb.shape and float(r["sub_quants"][f].abs().max()) == 0.0
+        assert rms(emb, g[f"emb_{f}"]) < 2e-5
+        assert np.allclose(scale.cpu().numpy(), g[f"scale_{f}"], rtol=1e-5)
+    assert r["recon_speech"].shape == g["recon"].shape and rms(r["recon_speech"], g["recon"]) < WAV_RMS_TOL
+    e = m.inference_encoding(wav.unsqueeze(1), bit_width=None)
+    rep = index_report(e["code_indices"][0], g["encode_indices_0"].astype(np.int64))
+    assert rep["mismatched_indices"] == 0, rep
 
 
 def test_stereo_model_channel_contract():

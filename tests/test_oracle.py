@@ -7,7 +7,7 @@ import torch
 from helpers import audio, golden, index_report, manifest, oracle_for, rms
 
 MAN = manifest()
-E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg", "variants")]
+E2E = [n for n, c in MAN["cases"].items() if c.get("kind") not in ("rvq", "rvq_noddp", "segmented", "freq", "freqseg", "variants", "bypass")]
 SEG = [n for n, c in MAN["cases"].items() if c.get("kind") == "segmented"]
 SAME_BUILD = torch.__version__ == MAN["torch"]
 
@@ -127,6 +127,19 @@ def test_torch_oracle_segmented_mode_matches_reference_golden(name):
         assert np.allclose(o["code_embeddings"][f][1].numpy(), g[f"scale_{f}"], rtol=1e-6)
     if exact:
         assert np.array_equal(o["recon_speech"].numpy(), g["recon"])
+
+
+@pytest.mark.parametrize("name", [n for n, c in MAN["cases"].items() if c.get("kind") == "bypass"])
+def test_torch_oracle_bypass_quantizer_matches_reference_golden(name):
+    """model_conf.bypass_quantizer (codec_basic.py:700-705): encoder output as code embeddings, zero indices [B, Tf], decode from it."""
+    c = MAN["cases"][name]
+    orc = oracle_for(c["config"], c["weight_seed"])
+    g = golden(name)
+    o = orc.inference(audio(c["batch"], c["samples"], c["audio_seed"], c["audio_kind"]), bit_width=None, use_scale=True)
+    for f, Tf in enumerate(c["frames"]):
+        assert o["code_indices"][f].shape == (c["batch"], Tf) and int(o["code_indices"][f].abs().max()) == 0
+        assert rms(o["code_embeddings"][f][0], g[f"emb_{f}"]) < 1e-5
+    assert rms(o["recon_speech"], g["recon"]) < 1e-4
 
 
 @pytest.mark.parametrize("name", ["rvq_flat", "rvq_decay08"])
