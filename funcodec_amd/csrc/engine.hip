@@ -92,7 +92,7 @@ struct Ctx {
     int B = 0;
     hipStream_t st = nullptr;
     char* base = nullptr;
-    size_t cap = 0, off = 0;
+    size_t cap = 0, off = 256;       // the first buffer starts 256 bytes in: the grouped 3 x 3 conv reads one float in front of a row (freq_kernels.hip, FASTEDGE)
     bool dry = false;
     int err = 0;
     int launches = 0, conv_launches = 0;

@@ -268,6 +268,9 @@ struct GConvArgs {
 #ifndef FC_GCONV_WAVES
 #define FC_GCONV_WAVES 0
 #endif
+#ifndef FC_GCONV_FASTEDGE
+#define FC_GCONV_FASTEDGE 1
+#endif
 #ifndef FC_GCONV_ABL
 #define FC_GCONV_ABL 0        // profiling builds (results are garbage): 1 no ELU arithmetic, 2 a quarter of the FMAs
 #endif
@@ -300,8 +303,17 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
     }
     const int n0 = tile * 1024 + 4 * tid;        // first output column of this lane
     const int q0 = n0 * ST - p.padL;             // source index (before reflection) of its first input column
-    const bool vec_ok = q0 >= 0 && q0 + 4 * NV <= p.Tin;
-    const int qsafe = q0 < 0 ? 0 : (q0 + 4 * NV <= p.Tin ? q0 : (p.Tin >= 4 * NV ? p.Tin - 4 * NV : 0));
+    // FASTEDGE (3 x 3, stride 1, rows longer than the padding; round 4): NO clamped addresses and NO per-element gathers for the lanes at the
+    // row ends -- those gathers (address registers, ~100 divergent regions) cost 60 of the kernel's 232 registers.  Every lane loads its
+    // window where it lies: the floats before column 0 / behind column T - 1 are the neighbouring channel row's (the activation buffers are
+    // contiguous; the workspace starts 256 bytes in and ends with 4 KiB of slack), i.e. finite garbage, and the only two garbage columns a VALID
+    // output reads are replaced in registers by their reflections: column -1 by column 1 (the lane with q0 = -1: element 0 <- element 2) and
+    // column T by column T - 2 (the lane that owns output T - 1: element eT = T - q0 in 2 .. 5 <- element eT - 2); causal nets pad two
+    // columns on the left and none on the right (elements 0, 1 <- elements 4, 3).
+    constexpr bool FASTEDGE = !NEEDMASK && KF == 3 && KT == 3 && ST == 1 && FC_GCONV_FASTEDGE;
+    const bool vec_ok = FASTEDGE || (q0 >= 0 && q0 + 4 * NV <= p.Tin);
+    const int qsafe = FASTEDGE ? q0 : (q0 < 0 ? 0 : (q0 + 4 * NV <= p.Tin ? q0 : (p.Tin >= 4 * NV ? p.Tin - 4 * NV : 0)));
+    const int eT = p.Tin - q0;                   // FASTEDGE: element index of column T in this lane's window
     int esrc[NE]; unsigned emask = 0;
     {
         const int refl = 2 * (p.Leff - 1);
@@ -341,60 +353,81 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
         constexpr int NR = KF + (FO - 1) * (KF >= 4 ? KF / 2 : 1);
         // round 3: the NEXT input row's loads are requested before the current row is activated and multiplied (two register sets): as
         // one straight-line block per row the loads of row r + 1 were issued only after row r's ~150 VALU instructions had retired
-        f32x4 rbuf0[2][CPG][NV], rbuf1[2][DUAL ? CPG : 1][NV];
-        auto load_row = [&](int r, int slot) __attribute__((always_inline)) {
-            int rr = fo0 * sf + r;
-            rr = rr > row_max ? row_max : rr;
+        // FASTEDGE: the group's channels in passes of CP = 2 -- a REAL loop (straight-line over all 4 channels, without the gather regions
+        // as scheduling fences, hipcc interleaves everything and takes 254 registers = one wave per SIMD): per pass 4 rows x 2 channels,
+        // one row ahead, the pass's 36 weights; the accumulators carry over.
+        constexpr int CP = (FASTEDGE && CPG == 4) ? 2 : CPG;
+        f32x4 rbuf0[2][CP][NV], rbuf1[2][DUAL ? CP : 1][NV];
+#pragma unroll CP == CPG ? 4 : 1
+        for (int c0 = 0; c0 < CPG; c0 += CP) {
+            auto load_row = [&](int r, int slot) __attribute__((always_inline)) {
+                int rr = fo0 * sf + r;
+                rr = rr > row_max ? row_max : rr;
 #pragma unroll
-            for (int ci = 0; ci < CPG; ++ci) {   // straight-line loads of the whole input row
-                const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)ci * p.Tin + qsafe;
+                for (int ci = 0; ci < CP; ++ci) {   // straight-line loads of the whole input row
+                    const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)(c0 + ci) * p.Tin + qsafe;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    rbuf0[slot][ci][v] = *(const f32x4u*)(p.src0 + off + 4 * v);
-                    if (DUAL) rbuf1[slot][ci][v] = *(const f32x4u*)(p.src1 + off + 4 * v);
-                }
-            }
-        };
-        load_row(0, 0);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            int rr = fo0 * sf + r;
-            rr = rr > row_max ? row_max : rr;
-            if (r + 1 < NR) load_row(r + 1, (r + 1) & 1);
-            f32x4 (&r0)[CPG][NV] = rbuf0[r & 1];
-            f32x4 (&r1)[DUAL ? CPG : 1][NV] = rbuf1[r & 1];
-#pragma unroll
-            for (int ci = 0; ci < CPG; ++ci) {
-                const float2 A = a0 ? a0[ci] : make_float2(1.f, 0.f);
-                const float2 A1 = a1 ? a1[ci] : make_float2(1.f, 0.f);
-                float x[NE];
-#pragma unroll
-                for (int j = 0; j < NE; ++j) {
-                    float v0 = r0[ci][j >> 2][j & 3], v1 = DUAL ? r1[ci][j >> 2][j & 3] : 0.f;
-                    if (!vec_ok) {
-                        const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)ci * p.Tin + esrc[j];
-                        v0 = p.src0[off];
-                        if (DUAL) v1 = p.src1[off];
+                    for (int v = 0; v < NV; ++v) {
+                        rbuf0[slot][ci][v] = *(const f32x4u*)(p.src0 + off + 4 * v);
+                        if (DUAL) rbuf1[slot][ci][v] = *(const f32x4u*)(p.src1 + off + 4 * v);
                     }
-                    float v = fmaf(v0, A.x, A.y);
-                    if (DUAL) v = v + fmaf(v1, A1.x, A1.y);
-                    if (p.elu && !(FC_GCONV_ABL & 1)) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f); v = v > 0.f ? v : fmaf(e, p.alpha, -p.alpha); }
-                    x[j] = (!NEEDMASK || ((vmask >> j) & 1u)) ? v : 0.f;
                 }
+            };
+            load_row(0, 0);
 #pragma unroll
-                for (int f = 0; f < FO; ++f) {
-                    constexpr int SFC = KF >= 4 ? KF / 2 : 1;          // compile-time row stride between the FO windows (== p.sf, checked by the launcher)
-                    const int a = r - f * SFC;                         // frequency tap of input row r for output row f
-                    if (a < 0 || a >= KF) continue;
+            for (int r = 0; r < NR; ++r) {
+                int rr = fo0 * sf + r;
+                rr = rr > row_max ? row_max : rr;
+                if (r + 1 < NR) load_row(r + 1, (r + 1) & 1);
+                f32x4 (&r0)[CP][NV] = rbuf0[r & 1];
+                f32x4 (&r1)[DUAL ? CP : 1][NV] = rbuf1[r & 1];
 #pragma unroll
-                    for (int o = 0; o < OPG; ++o)
+                for (int ci = 0; ci < CP; ++ci) {
+                    const int cc = c0 + ci;          // channel inside the group
+                    const float2 A = a0 ? a0[cc] : make_float2(1.f, 0.f);
+                    const float2 A1 = a1 ? a1[cc] : make_float2(1.f, 0.f);
+                    float x[NE];
 #pragma unroll
-                        for (int kk = 0; kk < KT; ++kk) {
-                                    const float wv = wgp[((o * CPG + ci) * KF + a) * KT + kk];
-                            if (FC_GCONV_ABL & 2) { acc[f][o][0] += wv * x[kk]; continue; }       // profiling build: a quarter of the FMAs
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[f][o][j] = fmaf(wv, x[j * ST + kk], acc[f][o][j]);
+                    for (int j = 0; j < NE; ++j) {
+                        float v0 = r0[ci][j >> 2][j & 3], v1 = DUAL ? r1[ci][j >> 2][j & 3] : 0.f;
+                        if (!vec_ok) {               // padded edge: gather by index
+                            const size_t off = in_b + (size_t)rr * p.in_sF + (size_t)cc * p.Tin + esrc[j];
+                            v0 = p.src0[off];
+                            if (DUAL) v1 = p.src1[off];
                         }
+                        float v = fmaf(v0, A.x, A.y);
+                        if (DUAL) v = v + fmaf(v1, A1.x, A1.y);
+                        if (p.elu && !(FC_GCONV_ABL & 1)) { const float e = __builtin_amdgcn_exp2f(v * 1.44269504088896341f); v = v > 0.f ? v : fmaf(e, p.alpha, -p.alpha); }
+                        x[j] = (!NEEDMASK || ((vmask >> j) & 1u)) ? v : 0.f;
+                    }
+                    if (FASTEDGE) {                  // reflections of the columns outside the row that valid outputs read
+                        // left: column -k <- column k, i.e. element padL - k <- element padL + k (the lane with q0 = -padL; padL = 1, or 2 = causal)
+                        if (q0 < 0) {
+                            x[0] = p.padL == 1 ? x[2] : x[4];
+                            if (p.padL == 2) x[1] = x[3];
+                        }
+                        // right (non-causal only, one padded column): column T <- column T - 2 in the lane that owns output T - 1
+                        if (p.padL == 1) {
+#pragma unroll
+                            for (int e = 2; e < NE; ++e)
+                                if (eT == e) x[e] = x[e - 2];
+                        }
+                    }
+#pragma unroll
+                    for (int f = 0; f < FO; ++f) {
+                        constexpr int SFC = KF >= 4 ? KF / 2 : 1;          // compile-time row stride between the FO windows (== p.sf, checked by the launcher)
+                        const int a = r - f * SFC;                         // frequency tap of input row r for output row f
+                        if (a < 0 || a >= KF) continue;
+#pragma unroll
+                        for (int o = 0; o < OPG; ++o)
+#pragma unroll
+                            for (int kk = 0; kk < KT; ++kk) {
+                                const float wv = wgp[((o * CPG + cc) * KF + a) * KT + kk];
+                                if (FC_GCONV_ABL & 2) { acc[f][o][0] += wv * x[kk]; continue; }       // profiling build: a quarter of the FMAs
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) acc[f][o][j] = fmaf(wv, x[j * ST + kk], acc[f][o][j]);
+                            }
+                    }
                 }
             }
         }
