@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
     // output reads are replaced in registers by their reflections: column -1 by column 1 (the lane with q0 = -1: element 0 <- element 2) and
     // column T by column T - 2 (the lane that owns output T - 1: element eT = T - q0 in 2 .. 5 <- element eT - 2); causal nets pad two
     // columns on the left and none on the right (elements 0, 1 <- elements 4, 3).
-    constexpr bool FASTEDGE = !NEEDMASK && KF == 3 && KT == 3 && ST == 1 && FC_GCONV_FASTEDGE;
+    constexpr bool FASTEDGE = !NEEDMASK && ST == 1 && ((KF == 3 && KT == 3) || KT == 2) && FC_GCONV_FASTEDGE;
     const bool vec_ok = FASTEDGE || (q0 >= 0 && q0 + 4 * NV <= p.Tin);
     const int qsafe = FASTEDGE ? q0 : (q0 < 0 ? 0 : (q0 + 4 * NV <= p.Tin ? q0 : (p.Tin >= 4 * NV ? p.Tin - 4 * NV : 0)));
     const int eT = p.Tin - q0;                   // FASTEDGE: element index of column T in this lane's window
@@ -403,11 +403,12 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
                     if (FASTEDGE) {                  // reflections of the columns outside the row that valid outputs read
                         // left: column -k <- column k, i.e. element padL - k <- element padL + k (the lane with q0 = -padL; padL = 1, or 2 = causal)
                         if (q0 < 0) {
-                            x[0] = p.padL == 1 ? x[2] : x[4];
-                            if (p.padL == 2) x[1] = x[3];
+                            x[0] = p.padL == 1 ? x[2] : x[4 < NE ? 4 : 0];
+                            if (KT == 3 && p.padL == 2) x[1] = x[3];
                         }
-                        // right (non-causal only, one padded column): column T <- column T - 2 in the lane that owns output T - 1
-                        if (p.padL == 1) {
+                        // right (3 taps, non-causal only: one padded column): column T <- column T - 2 in the lane that owns output T - 1;
+                        // 2 taps (the strided 8-row layers' time axis): one padded column on the left, none on the right
+                        if (KT == 3 && p.padL == 1) {
 #pragma unroll
                             for (int e = 2; e < NE; ++e)
                                 if (eT == e) x[e] = x[e - 2];
@@ -708,7 +709,11 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     dim3 grid(cdiv(c.Tout, 1024), c.G, c.B * cdiv(c.Fo, fo_n)), block(256);
     const int cpg = c.C / c.G, opg = c.M / c.G;
     const bool dual = c.src1 != nullptr;
-    const bool nm = a.Leff != a.Tin;               // rows not longer than the padding: columns without a source must read as zeros
+    // rows not longer than the padding: columns without a source must read as zeros.  The same (gather) instantiation also takes every
+    // padding split the register-reflection form of the other one is not written for
+    const bool pad_fast = (c.kt == 3 && c.padL + c.padR == 2 && (c.padL == 1 || c.padL == 2)) || (c.kt == 2 && c.padL == 1 && c.padR == 0) || c.kt == 1 ||
+                          c.st != 1;
+    const bool nm = a.Leff != a.Tin || !pad_fast;
 #define FC_GCL(CP, OP, KF_, KT_, ST_, FO_)                                                                                    \
     do {                                                                                                                     \
         if (dual && nm) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, FO_, true>), grid, block, 0, st, a);         \
