@@ -215,7 +215,8 @@ def kernel_rooflines(prof, prof_steps):
                      "alg_gbs": round(gbs, 1) if gbs else None,
                      "bound": bound,
                      "f32_frac": round(tfl / PEAK_F32_TFLOPS, 4) if tfl else None,
-                     "hbm_frac": round(gbs / 1e3 / PEAK_HBM_TBS, 4) if gbs else None})
+                     # a fraction above 1 can only come from an algorithmic byte count that is not one (never reported)
+                     "hbm_frac": round(gbs / 1e3 / PEAK_HBM_TBS, 4) if gbs and gbs / 1e3 <= PEAK_HBM_TBS else None})
     convs = [k for k in kern if k["kernel"].startswith(CONV_CLASSES)]
     mfma_bound = [k for k in convs if k["bound"] != "hbm"]
     if mfma_bound:
@@ -251,8 +252,9 @@ def kernel_rooflines(prof, prof_steps):
                            "ms_per_step": top["ms_per_step"],
                            "share_of_kernel_time": round(top["ms_per_step"] / max(1e-9, sum(k["ms_per_step"] for k in kern)), 4),
                            "note": "top kernel class of the step by time.  lstm_persist_kernel: one launch = the whole 2-layer recurrence of a SLSTM "
-                                   "block; algorithmic FLOPs = 2 * B * 4H * 3H per wavefront step; it is bound by the per-step hidden-state exchange "
-                                   "(a grid-wide all-gather + barrier per step), not by the matrix pipe: frac is its distance from the fp32 MFMA roof"}
+                                   "block; algorithmic FLOPs = 2 * B * 4H * 3H per wavefront step; algorithmic bytes per SURVEY.md 8d = recurrent weights "
+                                   "read ONCE + x-projection in + y out (the PMC traffic above that is the per-step hidden-state exchange); it is bound by that "
+                                   "exchange (a grid-wide all-gather + barrier per step), not by the matrix pipe: frac is its distance from the fp32 MFMA roof"}
     for key in ("roofline", "roofline_conv"):
         if key in out:
             _sustained(out[key])

@@ -1013,7 +1013,10 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
     cx.lstm_flops += 2.0 * B * (double)T * 4 * H * H * (2 * L - 1);
     cx.launches += persist ? 2 : T + L;
     if (!cx.dry && !cx.err) {
-        ProfSpan sp(e, cx, e->profiling ? e->prof_class(persist ? kLstmPersistClass : kLstmWaveClass) : 0, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), 4.0 * T * 4.0 * H * H * (2 * L - 1));
+        // algorithmic bytes per SURVEY.md 8d: the recurrent weights read ONCE (they stay resident in registers) + the x-projection in + y out;
+        // the per-step launches re-stream the weights, which is traffic, not algorithm
+        const double lstm_bytes = 4.0 * (4.0 * H * H * (2 * L - 1) + (double)T * B * 4.0 * H + (double)B * H * T);
+        ProfSpan sp(e, cx, e->profiling ? e->prof_class(persist ? kLstmPersistClass : kLstmWaveClass) : 0, 2.0 * B * (double)T * 4 * H * H * (2 * L - 1), lstm_bytes);
         hipError_t er = fc::launch_zero_fill(state, persist ? fc::lstm_persist_clear_floats(B, H) : (size_t)3 * L * B * H, cx.st);
         const float* w[FC_LSTM_MAX_LAYERS] = {nullptr};
         const float* bias[FC_LSTM_MAX_LAYERS] = {nullptr};

@@ -912,10 +912,30 @@ def test_freq_codec_mag_angle_against_reference_golden(name):
     noise = float(c["stft_self_noise"])
     own = rms(r_own["enc_out"], g["encoder_out"])
     assert own < 3.0 * noise, (own, noise)
+    extra = {}
+    if name + "_variants" in MAN["cases"]:
+        # COMMITTED FACT (oracle/make_golden.py): the real reference on this recording with its STFT evaluated exactly (fp64) -- its own feature
+        # tensor and codes.  The wraps are a property of the DOMAIN on speech too: every angle bin the engine wraps against the fixture must be a
+        # bin whose angle is +-pi within rounding (the fixture's |angle| > 3), exactly the class of bins the reference's own exact STFT wraps;
+        # thread counts change nothing on the reference's side.
+        v = golden(name + "_variants")
+        f64 = torch.from_numpy(v["features_stft64"])
+        gfc = gf.cpu()
+        d64 = (f64[:, 1] - gfc[:, 1]).abs()
+        ref_wrapped = d64 > 3.0
+        eng_wrapped = (d > 3.0).cpu()
+        assert int(ref_wrapped.sum()) == MAN["cases"][name + "_variants"]["summary"]["stft64"]["angle_bins_wrapped"]
+        assert bool((gfc[:, 1].abs()[eng_wrapped] > 3.0).all()) and bool((gfc[:, 1].abs()[ref_wrapped] > 3.0).all())
+        for tag in ("threads1", "threads3"):
+            assert np.array_equal(v["indices_" + tag].astype(np.int64), ref)
+        ref64_frames = int((v["indices_stft64"].astype(np.int64) != ref).any(0).sum())
+        extra = dict(reference_fp64_stft_wrapped_bins=int(ref_wrapped.sum()), wrapped_by_both=int((ref_wrapped & eng_wrapped).sum()),
+                     reference_fp64_stft_frames_with_other_codes=ref64_frames,
+                     reference_fp64_stft_encoder_out_rms=MAN["cases"][name + "_variants"]["summary"]["stft64"]["encoder_out_rms_diff"])
     record_report(name, angle_bins=int(d.numel()), angle_bins_wrapped_by_the_engine=wrapped,
                   reference_fp64_stft=c["angle_conditioning"], encoder_out_rms_vs_fixture_own_stft=own, stft_self_noise=noise,
                   frames_with_other_codes_own_stft=int((r_own["codes"].cpu().numpy() != ref).any(0).sum()),
-                  indices_identical_from_reference_features=rep["mismatched_indices"] == 0)
+                  indices_identical_from_reference_features=rep["mismatched_indices"] == 0, **extra)
 
 
 @pytest.mark.parametrize("name", [n for n, c in MAN["cases"].items() if c.get("kind") == "freqseg"])
@@ -1009,6 +1029,40 @@ def test_freq_codec_batch_independence_and_determinism():
         one = m.engine.encode_decode(big[i:i + 1], 32)
         assert torch.equal(one["codes"][:, 0], c["codes"][:, i]) and torch.equal(one["recon"][0], c["recon"][i])
     m.engine.check_status()
+
+
+def test_freq_codec_gr1_benchmark_configuration_in_a_32_utterance_call():
+    """The configuration bench.py's FreqCodec side measurement times (`freqmpgr1`, weight seed 0, engine calls of 32): the grouped direct
+    kernels at 257 frequency rows, the H = 512 persistent LSTM with its two batch-tile groups and the two-row-set quantiser (N = 32 x 151 rows
+    > 16 per CU) are only live in such a call.  Rows 0, 15, 16, 31 of the 32-call equal the single-utterance calls bit for bit, and rows 0 / 31
+    match the CPU oracle (pinned to the real reference on this very configuration: goldens freqmpgr1_b1_t16000 / freqmpgr1_b2_t48000)."""
+    from helpers import freq_engine_for, freq_oracle_for
+    m, orc = freq_engine_for("freqmpgr1", 0), freq_oracle_for("freqmpgr1", 0)
+    wav = audio(32, 48000, 1234, "noise")
+    old = m.engine.micro_batch
+    m.engine.micro_batch = 32
+    try:
+        a = m.engine.encode_decode(wav.cuda(), 32, use_scale=True)
+        b = m.engine.encode_decode(wav.cuda(), 32, use_scale=True)
+    finally:
+        m.engine.micro_batch = old
+    m.engine.check_status()
+    assert a["codes"].shape == (32, 32, 151)
+    assert torch.equal(a["codes"], b["codes"]) and torch.equal(a["recon"], b["recon"])
+    for i in (0, 15, 16, 31):
+        one = m.engine.encode_decode(wav[i:i + 1].cuda(), 32, use_scale=True)
+        assert torch.equal(one["codes"][:, 0], a["codes"][:, i]), i
+        assert torch.equal(one["recon"][0], a["recon"][i]) and torch.equal(one["quantized"][0], a["quantized"][i]), i
+    rows = [0, 31]
+    o = orc.inference(wav[rows], bit_width=None, use_scale=True)
+    got = a["codes"][:, rows].cpu()
+    rep = index_report(got, o["code_indices"][0])
+    if rep["frames_bad"]:
+        _assert_flips_are_near_ties(orc.embed, o["encoder_out"], o["code_indices"][0], got, max_frames=1)
+    else:
+        ref_rms = float(o["recon_speech"].double().pow(2).mean().sqrt())
+        assert rms(a["recon"][rows], o["recon_speech"]) < 1e-3 * ref_rms
+        assert rms(a["quantized"][rows], o["code_embeddings"][0][0]) == 0.0
 
 
 def test_freq_codec_speech2token_dropin(tmp_path):
