@@ -731,7 +731,36 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     eng.check_status()
+    diag = None
     if world > 1:
+        # ---- self-diagnosing N > 1 line: every rank's own wall time for the K steps, and a separate gather-only loop --
+        # efficiency then reads as load balance (rank spread) vs the collective (gather_ms), not as one opaque number
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank_ms = [float(x.item()) / args.steps * 1e3 for x in per_rank]
+        local_codes = codes[:, lo:hi].contiguous()
+        for _ in range(2):
+            gather_codes(local_codes, dist, shard_sizes=shard_sizes)
+        fence()
+        tg = time.perf_counter()
+        g_reps = max(3, args.steps)
+        for _ in range(g_reps):
+            gather_codes(local_codes, dist, shard_sizes=shard_sizes)
+        fence()
+        tg = torch.tensor([(time.perf_counter() - tg) / g_reps], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        try:
+            ver = torch.cuda.nccl.version() if not rehearsal else None      # on ROCm builds this is RCCL's version triple
+            ver = ".".join(str(v) for v in ver) if ver else None
+        except Exception:                                                    # noqa: BLE001 -- a version string must never fail the bench
+            ver = None
+        diag = {"rank_ms_per_step": [round(x, 3) for x in per_rank_ms], "rank_ms_per_step_min": round(min(per_rank_ms), 3),
+                "rank_ms_per_step_max": round(max(per_rank_ms), 3),
+                "gather_ms": round(float(tg.item()) * 1e3, 3), "gather_bytes_per_rank": int(local_codes.numel() * 8),
+                "gather_note": "one all_gather_into_tensor of this rank's int64 codes per step, timed alone (barrier + sync on both sides, max over "
+                               "ranks); inside the timed step it runs behind the last micro-batch's kernels on the same stream",
+                "backend": dist.get_backend(), "rccl_version": ver}
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -809,6 +838,7 @@ def main():
             if "roofline" in out:
                 out["roofline"]["whole_step"] = out["whole_step"]
         if world > 1:
+            out["multi_gpu"] = diag
             out["config"]["scaling_base"] = ("efficiency is to be computed against secondary.config_c_shard_b128.value of the --gpus 1 line (same "
                                              "per-rank shape: 128 x 10 s in micro-batches of 32), NOT against the N = 1 contract value (Config B, "
                                              "16 utterances in one call)")

@@ -41,7 +41,7 @@ class Speech2Token:
             self,
             config_file: Union[Path, str] = None,
             model_file: Union[Path, str] = None,
-            device: str = "cuda",
+            device: str = "cpu",          # the reference's default (codec_inference.py:53-63); this engine then refuses loudly, see below
             batch_size: int = 1,
             dtype: str = "float32",
             streaming: bool = False,
@@ -54,8 +54,11 @@ class Speech2Token:
         # The engine computes in fp32 whatever `dtype` says (index exactness).  The reference converts the MODEL with
         # model.to(dtype) (:78) and feeds the caller's tensors unchanged; here float16 / float64 means: inputs of that dtype are
         # accepted and the floating-point outputs are returned in it (fp32 arithmetic in between).
-        if device == "cpu":
-            raise RuntimeError("funcodec_amd.Speech2Token runs on MI355X only; use the reference for device='cpu'")
+        # Same signature and default as the reference -- so `Speech2Token(cfg, pth)` does NOT silently pick a GPU: it fails the same way an
+        # explicit device="cpu" does, with the fix in the message.
+        if str(device).startswith("cpu"):
+            raise RuntimeError("funcodec_amd.Speech2Token runs on MI355X only: pass device='cuda' (or 'cuda:<n>'); the default 'cpu' is the "
+                               "reference's signature (funcodec/bin/codec_inference.py:56) -- use the reference itself for CPU inference")
         model, model_args = build_model_from_file(config_file, model_file, device)
         self.model = model
         self.model_args = model_args
@@ -112,6 +115,15 @@ class Speech2Token:
 
     @staticmethod
     def from_pretrained(model_tag: Optional[str] = None, **kwargs: Optional[Any]):
+        """Like the reference (codec_inference.py:136-150: "model_tag ... Currently, not used"): the instance is built from **kwargs
+        (config_file / model_file / device ...).  A non-None tag cannot select a model here either -- there is no hub access -- and that is
+        said instead of silently dropped."""
+        if model_tag is not None:
+            logging.warning("Speech2Token.from_pretrained: model_tag=%r is not used (the reference ignores it as well, codec_inference.py:144); "
+                            "the model comes from config_file / model_file", model_tag)
+            if not (kwargs.get("config_file") and kwargs.get("model_file")):
+                raise ValueError(f"Speech2Token.from_pretrained(model_tag={model_tag!r}) needs config_file= and model_file=: model tags are "
+                                 "not resolved (no hub access), the tag alone selects nothing")
         return Speech2Token(**kwargs)
 
 

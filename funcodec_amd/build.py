@@ -19,7 +19,7 @@ HEADERS = ["kernels.h", "conv_kernel.h", "laura_kernels.h", os.path.join("..", "
 
 
 def sources():
-    return ["kernels.hip", "engine.hip", "freq_kernels.hip", "laura.hip", "laura_kernels.hip", "laura_persist.hip"] + sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "conv_tile_*.hip")))
+    return ["kernels.hip", "engine.hip", "freq_kernels.hip", "laura.hip", "laura_kernels.hip", "laura_persist.hip"] + sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "conv_tile*_*.hip")))
 
 
 def _hipcc() -> str:

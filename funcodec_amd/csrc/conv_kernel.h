@@ -59,6 +59,10 @@ struct ConvArgs {
     unsigned magic_slabW;   // floor(2^32 / slabW) + 1
     const int* koff;        // [koff_n] B-operand LDS float offset per k-step (padded, multiple of 4)
     int koff_n;
+    int xq_Tp;              // > 0: src0 is a channel-quad-interleaved, padded materialisation xq[b][Cin/4][xq_Tp][4] (combine_xq_kernel;
+                            // column t of the tensor sits at xq column padL + t, the padding values are already in place): MODE 5 DMA staging
+    int quad;               // quad-k operand layout (CC % 4 == 0): A [quad][hi][BM][4], B [g4][column][4 channels]
+    int nq2;                // quads per chunk, rounded up to an even count
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
     // two-level batch addressing (2-D nets in frequency-major layout [B][F][C][T]: a frequency row of an utterance is one
     // "virtual utterance" of the 1-D conv): blockIdx.z = breal*Fo + fo.  1-D layers: Fo = 1, in_sB0 = Cin*Tin, affC = Cin.
@@ -106,6 +110,20 @@ __device__ __forceinline__ void dma_weights(const float* __restrict__ gsrc, floa
 }
 
 
+// One LDS-DMA piece (64 lanes x 16 bytes -> 1 KiB of LDS at the wave-uniform byte address `lds_byte`) whose 64 source addresses are a
+// wave-uniform 64-bit base (SGPR pair) + a per-lane 32-bit byte offset: NO vector ALU instruction is needed to form the addresses.  That is
+// the point (round 5): fp32 MFMAs occupy the SIMD's vector issue, and a co-resident wave's VALU instruction waits for a gap in the matrix
+// wave's MFMA stream -- the builtin form computes a 64-bit lane address per piece (v_lshl_add_u64) and the staging wave of a DMA-only item
+// still took a whole item to get its ~10 pieces issued.  M0 is compiler-reserved: saved and restored inside the statement.  hipcc does
+// not count this load: the caller waits with dma_wait_all() before the barrier that publishes the data.
+__device__ __forceinline__ void dma_piece_sbase(const void* sbase, unsigned voff, unsigned lds_byte) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_byte_addr(const float* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+
 // MODE 0: plain single source (already activated input, no prologue math)
 // MODE 1/2: single source with GroupNorm affine (optional /div), without / with ELU
 // MODE 3/4: two summed sources with GroupNorm affines, without / with ELU
@@ -132,12 +150,25 @@ static __device__ unsigned long long g_timeline[2][24][8];   // one copy per tra
 #else
 #define FC_STAMP(role_, f_, slot_) do {} while (0)
 #endif
-template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW>
+// QK: quad-k operand layout (round 5).  Both operands are stored so that a lane's values of FOUR consecutive k-steps are one 16-byte piece:
+//   Ws[quad][hi][BM][4]          a chunk's k indices as HALF-QUADS h = (tap kk, channel quad g4) in tap-major order; quad q = half-quads 2 q
+//                                (MFMA lanes 0-31) and 2 q + 1 (lanes 32-63); element s = weight of channel 4 g4 + s at tap kk
+//   Xs[g4][slab column][4]       element s = channel 4 g4 + s of that column; a tap is a column offset, a stride phase a column block; the
+//                                lane halves read their half-quad's (plane, column) offset from table[2 q + hi]
+// so the matrix waves issue ONE ds_read_b128 per operand tile per 4 k-steps (16 MFMAs of a 2 x 2 register tile) instead of one ds_read_b32 per
+// tile per k-step: tests/micro/conv_loop_feed_b128.hip measures 0.95 - 0.98 of the fp32 MFMA peak for this feed against 0.81 (one matrix wave
+// per SIMD) / 0.89 (two) for the round-4 form.  k-step s of a quad multiplies channel s of its two half-quads: the accumulation order inside
+// a chunk is (quad, s), fixed per layer.  NU then counts QUAD slots (4 channels x one column) per staging
+// thread (element staging) or rounds of 256 (4 channels x 4 columns) units (row staging).
+template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW, bool QK = false>
 __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
     static_assert(WM * WN == 4, "4 matrix waves per workgroup");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr bool PLAIN = MODE == 0;                 // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU
-    constexpr bool DUAL = MODE >= 3;
+    // MODE: 0 plain | 1 affine | 2 affine+ELU | 3 dual | 4 dual+ELU | 5 plain, slab staged by DMA from a quad-interleaved padded input
+    constexpr bool PLAIN = MODE == 0 || MODE == 5;
+    constexpr bool DMA5 = MODE == 5;
+    static_assert(!DMA5 || QK, "DMA slab staging needs the quad layout");
+    constexpr bool DUAL = MODE == 3 || MODE == 4;
     constexpr bool ELU = MODE == 2 || MODE == 4;
     // which role streams the weight chunks: the staging waves when they have no prologue math (PLAIN), else the matrix
     // waves, one DMA piece per loop trip (measured: each choice loses 5-8 % on the other kind of layer)
@@ -218,7 +249,244 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             dma_weights(wt_tile, smem, p.Wbuf, rtid, p.ablate);
             if (resident && p.nchunk == 2) dma_weights(wt_tile + p.Wbuf, smem + p.Wbuf, p.Wbuf, rtid, p.ablate);
         }
-        if constexpr (ROW) {
+        if constexpr (DMA5) {
+            // ---------------------------------------------------------------------------------------------
+            // MODE 5 (round 5): the slab arrives by DMA, like the weights.  The timelines of round 5 showed what bounds
+            // this kernel: fp32 MFMAs occupy the SIMD's vector issue, and every VALU instruction of the co-resident staging wave waits for a
+            // gap in the matrix wave's MFMA stream -- the staging waves of the register-staged forms took a whole item (~9 000 cycles) to get
+            // ~100 instructions issued, and the matrix waves then waited for them at the barrier.  Here the input was materialised (it is, for
+            // every layer with >= 3 M tiles) as xq[b][channel quad][padded column][4 channels], so a B-operand plane row is contiguous in
+            // memory: a staging wave issues NU 16-byte-per-lane DMA pieces per item (1 KiB each, no VGPR data, no prologue, no LDS store, no
+            // edge cases: the padding is part of the materialisation) and goes back to the barrier.
+            // piece d = (j * 4 + wave) * 64 + lane of the slab image [g4][rowStride columns]; its source column: stride phases are column
+            // blocks of PL (col = ph * PL + q <-> input column q * stride + ph)
+            // ---------------------------------------------------------------------------------------------
+            const int pieces = (p.CC >> 2) * p.rowStride;
+            unsigned off[NU];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const int d = ((j * 4 + wid) << 6) + lane;
+                off[j] = 0u;
+                if (d < pieces) {
+                    const int g4 = d / p.rowStride, col = d - g4 * p.rowStride;
+                    const int ph = col / p.PL, q = col - ph * p.PL;
+                    off[j] = 16u * (unsigned)(g4 * p.xq_Tp + q * p.stride + ph);
+                }
+            }
+            const char* xq_b = (const char*)p.src0 + (size_t)breal * (size_t)(p.Cin >> 2) * (size_t)p.xq_Tp * 16;
+            const size_t chunk_bytes = (size_t)(p.CC >> 2) * (size_t)p.xq_Tp * 16;
+            const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+            const unsigned w_voff = 16u * (unsigned)rtid;         // weights: piece i of a chunk = 4 KiB, this wave's KiB of it at wave * 1 KiB
+            const unsigned smem_b = lds_byte_addr(smem), xs0_b = lds_byte_addr(Xs0);
+            const int wpieces = p.Wbuf >> 10;
+            int ld_tile = t_begin, ld_chunk = 0;
+            // the staging waves issue nothing but scalar and memory instructions from here on; they must still win the issue arbitration
+            // against the matrix waves whenever they have something to issue (a DMA requested late is a barrier wait for four matrix waves)
+            __builtin_amdgcn_s_setprio(3);
+            auto dma_w = [&](const float* gsrc, int buf) __attribute__((always_inline)) {
+                if (p.ablate & 16) return;
+                const char* g = (const char*)gsrc;
+                unsigned l = smem_b + (unsigned)buf * (unsigned)p.Wbuf * 4u + (unsigned)wid_s * 1024u;
+                for (int i = 0; i < wpieces; ++i, g += 4096, l += 4096u) dma_piece_sbase(g, w_voff, l);
+            };
+            auto dma_slab = [&](int buf) __attribute__((always_inline)) {
+                const char* base = xq_b + (size_t)ld_chunk * chunk_bytes + (size_t)ld_tile * (size_t)(BN * p.stride) * 16;
+                if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
+                if (p.ablate & 4) return;
+                const unsigned l = xs0_b + (unsigned)buf * (unsigned)XSF * 4u + (unsigned)wid_s * 1024u;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) dma_piece_sbase(base, off[j], l + (unsigned)j * 4096u);
+            };
+            dma_slab(0);                                  // item 0 (its weights were requested above, by the builtin form hipcc counts)
+            dma_wait_all();
+            __syncthreads();                              // B0
+            int st_tile = t_begin, st_chunk = 0;
+            for (int f = 0; f < nitems; ++f) {
+                FC_STAMP(1, f, 0);
+                if (f + 1 < nitems) {
+                    if (!resident) {
+                        const int nc = st_chunk + 1 == p.nchunk ? 0 : st_chunk + 1;
+                        dma_w(wt_tile + (size_t)nc * p.Wbuf, (f + 1) & 1);
+                    }
+                    dma_slab((f + 1) & 1);
+                }
+                FC_STAMP(1, f, 1);
+                dma_wait_all();                           // hipcc does not count the asm pieces: the barrier below publishes them
+                FC_STAMP(1, f, 2);
+                __syncthreads();                          // B(f+1)
+                FC_STAMP(1, f, 3);
+                if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
+                FC_STAMP(1, f, 4);
+            }
+            __syncthreads();                              // final (kept symmetric with the matrix role)
+            return;
+        }
+        if constexpr (ROW && QK) {
+            // ---------------------------------------------------------------------------------------------
+            // Row staging, quad-k layout (stride-1 layers).  A unit = 4 consecutive channels x 4 consecutive columns: FOUR 16-byte global
+            // loads (one per channel) and FOUR 16-byte LDS stores (one per column: the 4 channels of that column are one B-operand piece);
+            // the 4 x 4 transposition is free, it only names registers.  BN/4 threads cover the main columns of a channel quad, a round =
+            // 256 units = 256/(BN/4) channel quads; NU rounds per item (compile time).  Chunks with fewer units than one round leave whole
+            // waves without a main unit.  Tail columns ((k - 1) * dilation per row): one (channel quad, column) unit per thread.
+            // ---------------------------------------------------------------------------------------------
+            typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+            constexpr int LPR = BN / 4, GPR = 256 / LPR, NR = NU;
+            const int nq4 = p.CC >> 2;
+            const bool has_main = rtid / LPR < nq4;        // wave-uniform (LPR >= 32); false only when the chunk has < 256 units (NR == 1)
+            const int g0 = has_main ? rtid / LPR : 0, c4 = rtid % LPR;
+            const unsigned slot0 = 16u * (unsigned)(g0 * p.rowStride + 4 * c4);
+            const unsigned lds_round = 16u * (unsigned)(GPR * p.rowStride);
+            const size_t src_round = (size_t)(4 * GPR) * p.Tin;
+            const int km1 = p.slabW - BN;
+            const bool has_tail = rtid < nq4 * km1;
+            const int t_g = has_tail ? rtid / km1 : 0, t_j = has_tail ? rtid - t_g * km1 : 0;
+            const unsigned t_slot = 16u * (unsigned)(t_g * p.rowStride + BN + t_j);
+            unsigned src_off = 0, eoff[4] = {0, 0, 0, 0}, emask = 0, t_off = 0;
+            bool ld_edge = false, t_ok = true;
+            bool r_edge = false, r_tok = true; unsigned r_emask = 0;
+            f32x4 v0[NR][4], v1[DUAL ? NR : 1][4];
+            float tv0[4] = {0.f, 0.f, 0.f, 0.f}, tv1[4] = {0.f, 0.f, 0.f, 0.f};
+            int ld_tile = t_begin, ld_chunk = 0, wr_chunk = 0;
+            const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
+            auto resolve = [&](int g, bool& ok) __attribute__((always_inline)) {
+                ok = g >= -p.padL && g < hi_lim;
+                int src = g < 0 ? -g : g;
+                src = src >= p.Leff ? refl - src : src;
+                if (p.pad_zero) { src = g; ok = ok && g >= 0; }
+                ok = ok && src < p.Tin;
+                return ok ? src : 0;
+            };
+            auto setup_tile = [&](int tbase) __attribute__((always_inline)) {
+                ld_edge = !(tbase >= 0 && tbase + p.slabW <= p.Tin);
+                if (!ld_edge) {
+                    src_off = 4u * (unsigned)(4 * g0 * p.Tin + tbase + 4 * c4);
+                    t_off = has_tail ? 4u * (unsigned)(4 * t_g * p.Tin + tbase + BN + t_j) : src_off;
+                    t_ok = true;
+                } else {
+                    emask = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bool ok;
+                        const int src = resolve(tbase + 4 * c4 + j, ok);
+                        eoff[j] = 4u * (unsigned)(4 * g0 * p.Tin + src);
+                        emask |= (ok ? 1u : 0u) << j;
+                    }
+                    const int src = resolve(has_tail ? tbase + BN + t_j : tbase + 4 * c4, t_ok);
+                    t_off = 4u * (unsigned)(4 * (has_tail ? t_g : g0) * p.Tin + src);
+                }
+            };
+            auto load_slab = [&]() __attribute__((always_inline)) {
+                const int tbase = ld_tile * BN - p.padL;
+                if (ld_chunk == 0) setup_tile(tbase);
+                const size_t cbase = (size_t)(ld_chunk * p.CC) * p.Tin;
+                if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
+                r_edge = ld_edge; r_emask = emask; r_tok = t_ok;
+                if (p.ablate & 4) return;
+                const float* r0 = s0b + cbase;
+                const float* r1 = s1b + cbase;
+                if (!ld_edge) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            v0[r][s4] = *(const f32x4u*)((const char*)(r0 + r * src_round + (size_t)s4 * p.Tin) + src_off);
+                            if (DUAL) v1[r][s4] = *(const f32x4u*)((const char*)(r1 + r * src_round + (size_t)s4 * p.Tin) + src_off);
+                        }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                v0[r][s4][j] = *(const float*)((const char*)(r0 + r * src_round + (size_t)s4 * p.Tin) + eoff[j]);
+                                if (DUAL) v1[r][s4][j] = *(const float*)((const char*)(r1 + r * src_round + (size_t)s4 * p.Tin) + eoff[j]);
+                            }
+                }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    tv0[s4] = *(const float*)((const char*)(r0 + (size_t)s4 * p.Tin) + t_off);
+                    if (DUAL) tv1[s4] = *(const float*)((const char*)(r1 + (size_t)s4 * p.Tin) + t_off);
+                }
+            };
+            auto prologue = [&](float v, float w, float2 a, float2 a1) __attribute__((always_inline)) {
+                if (PLAIN) return v;
+                v = fmaf(v, a.x, a.y);
+                if (DUAL) v = v + fmaf(w, a1.x, a1.y);
+                if (ELU) v = elu_f(v, p.alpha);
+                return v;
+            };
+            // the 4 table entries (scale, shift) of a channel quad: 32 contiguous bytes
+            auto tab4 = [&](const float2* t, int c, float2 (&a)[4]) __attribute__((always_inline)) {
+                const float4 lo = *(const float4*)(t + c), hi4 = *(const float4*)(t + c + 2);
+                a[0] = make_float2(lo.x, lo.y); a[1] = make_float2(lo.z, lo.w);
+                a[2] = make_float2(hi4.x, hi4.y); a[3] = make_float2(hi4.z, hi4.w);
+            };
+            auto write_slab = [&](char* Xd) __attribute__((always_inline)) {
+                const int c0 = wr_chunk * p.CC;
+                if (++wr_chunk == p.nchunk) wr_chunk = 0;
+                float2 a[PLAIN ? 1 : NR][4], a1[DUAL ? NR : 1][4], ta[4], ta1[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { ta[s4] = make_float2(1.f, 0.f); ta1[s4] = make_float2(1.f, 0.f); }
+                if (!PLAIN) {                             // all table reads ahead of the stores (possible aliasing)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        tab4(tab0, c0 + 4 * (g0 + r * GPR), a[r]);
+                        if (DUAL) tab4(tab1, c0 + 4 * (g0 + r * GPR), a1[r]);
+                    }
+                    tab4(tab0, c0 + 4 * t_g, ta);
+                    if (DUAL) tab4(tab1, c0 + 4 * t_g, ta1);
+                }
+                if (has_main) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 o;
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                o[s4] = prologue(v0[r][s4][j], DUAL ? v1[r][s4][j] : 0.f, PLAIN ? ta[s4] : a[r][s4], DUAL ? a1[r][s4] : ta1[s4]);
+                                if (r_edge) o[s4] = ((r_emask >> j) & 1u) ? o[s4] : 0.f;
+                            }
+                            *(f32x4*)(Xd + slot0 + r * lds_round + 16 * j) = o;
+                        }
+                }
+                if (has_tail) {
+                    f32x4 o;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        o[s4] = prologue(tv0[s4], tv1[s4], ta[s4], ta1[s4]);
+                        o[s4] = r_tok ? o[s4] : 0.f;
+                    }
+                    *(f32x4*)(Xd + t_slot) = o;
+                }
+            };
+            load_slab();
+            write_slab((char*)Xs0);
+            if (nitems > 1) load_slab();
+            __syncthreads();                              // B0
+            int st_tile = t_begin, st_chunk = 0;
+            for (int f = 0; f < nitems; ++f) {
+                FC_STAMP(1, f, 0);
+                if (STAGING_DMA && f + 1 < nitems && !resident) {
+                    const int nc = st_chunk + 1 == p.nchunk ? 0 : st_chunk + 1;
+                    dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
+                }
+                if (f + 1 < nitems) {
+                    write_slab((char*)(Xs0 + ((f + 1) & 1) * XSF));
+                    FC_STAMP(1, f, 1);
+                    if (f + 2 < nitems) load_slab();
+                    FC_STAMP(1, f, 2);
+                }
+                __syncthreads();                          // B(f+1)
+                FC_STAMP(1, f, 3);
+                if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
+                FC_STAMP(1, f, 4);
+            }
+            __syncthreads();                              // final (kept symmetric with the matrix role)
+            return;
+        }
+        if constexpr (ROW && !QK) {
             // ---------------------------------------------------------------------------------------------
             // Row staging (stride-1 layers).  A slab row = one input channel, BN main columns + k-1 tail columns.
             // BN/4 lanes cover the main columns of a row with ONE 16-byte global load and ONE 16-byte LDS store each
@@ -382,6 +650,194 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 FC_STAMP(1, f, 4);
             }
             __syncthreads();                              // final (kept symmetric with the matrix role)
+            return;
+        }
+        if constexpr (QK) {
+            // ---------------------------------------------------------------------------------------------
+            // Element staging, quad-k layout (strided layers, PLAIN stride-1 layers): a slot = (channel quad, slab column): FOUR dword loads
+            // (the 4 channels: same lane offset from 4 wave-uniform row bases) and ONE 16-byte LDS store into the column's B-operand piece
+            // (stride-phase-split like the round-4 slab: [c8][hi][tau % stride][tau / stride][4]).  NU = slots per thread (compile time).
+            // ---------------------------------------------------------------------------------------------
+            const int totalq = (p.CC >> 2) * p.slabW;
+            const float divv = (MODE == 1 && p.div0) ? p.div0[breal] : 1.f;
+            unsigned base0[NU], slot[NU], cl32[PLAIN ? 1 : NU];
+            constexpr int NSET = DEEP ? 2 : 1;
+            float v0[NSET][NU][4], v1[NSET][DUAL ? NU : 1][4];
+            unsigned inmask = 0, vmask[NSET] = {};
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int e = rtid + 256 * u;
+                base0[u] = 0u; slot[u] = (unsigned)(XSF - 4) * 4u;
+                if (!PLAIN) cl32[u] = 0u;
+                if (e < totalq) {
+                    const int g4 = (int)__umulhi((unsigned)e, p.magic_slabW);
+                    const int tau = e - g4 * p.slabW;
+                    int ph, q;
+                    switch (p.stride) {
+                        case 1: ph = 0; q = tau; break;
+                        case 2: q = tau >> 1; ph = tau & 1; break;
+                        case 4: q = tau >> 2; ph = tau & 3; break;
+                        case 8: q = tau >> 3; ph = tau & 7; break;
+                        default: q = tau / p.stride; ph = tau - q * p.stride; break;
+                    }
+                    base0[u] = 4u * (unsigned)(4 * g4 * p.Tin + tau);
+                    slot[u] = 16u * (unsigned)(g4 * p.rowStride + ph * p.PL + q);
+                    if (!PLAIN) cl32[u] = (unsigned)g4 * 32u;
+                    inmask |= 1u << u;
+                }
+            }
+            bool base_static = true, ld_interior = true;
+            unsigned tile_mask = 0;
+            bool all_valid[NSET] = {};
+            int ld_tile = t_begin, ld_chunk = 0, wr_chunk = 0;
+            auto setup_tile = [&](int tbase) __attribute__((always_inline)) {
+                ld_interior = tbase >= 0 && tbase + p.slabW <= p.Tin;
+                tile_mask = inmask;
+                if (ld_interior && base_static) return;
+                const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    unsigned ee = (unsigned)(rtid + 256 * u);
+                    asm volatile("" : "+v"(ee));
+                    const int g4 = (int)__umulhi(ee, p.magic_slabW);
+                    const int tau = (int)ee - g4 * p.slabW;
+                    if (ld_interior) {
+                        base0[u] = ((inmask >> u) & 1u) ? 4u * (unsigned)(4 * g4 * p.Tin + tau) : 0u;
+                    } else {
+                        const int g = tbase + tau;
+                        bool ok = ((inmask >> u) & 1u) && g >= -p.padL && g < hi_lim;
+                        int src = g < 0 ? -g : g;
+                        src = src >= p.Leff ? refl - src : src;
+                        if (p.pad_zero) { src = g; ok = ok && g >= 0; }
+                        ok = ok && src < p.Tin;
+                        base0[u] = ok ? 4u * (unsigned)(4 * g4 * p.Tin + src) : 0u;
+                        tile_mask &= ~((ok ? 0u : 1u) << u);
+                    }
+                }
+                base_static = ld_interior;
+            };
+            // channels of a slot that exist (the last chunk of a layer whose channel count is no multiple of the chunk): 0..4
+            int nvalid[NSET][NU];
+            auto load_slab = [&](auto set_tag) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_tag)::value;
+                const int tbase = ld_tile * BN * p.stride - p.padL;
+                if (ld_chunk == 0) setup_tile(tbase);
+                const int c0 = ld_chunk * p.CC;
+                if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
+                vmask[S] = tile_mask;
+                if (p.ablate & 4) return;
+                all_valid[S] = ld_interior;
+                const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + (ld_interior ? tbase : 0));
+                if (p.cin_tail && c0 + p.CC > p.Cin) {      // last chunk runs past the real channels (uniform, rare)
+                    all_valid[S] = false;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        unsigned ee = (unsigned)(rtid + 256 * u);
+                        asm volatile("" : "+v"(ee));
+                        const int left = p.Cin - (c0 + 4 * (int)__umulhi(ee, p.magic_slabW));
+                        nvalid[S][u] = left < 0 ? 0 : (left > 4 ? 4 : left);
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const unsigned off = s4 < nvalid[S][u] ? base0[u] + ubase : 0u;
+                            v0[S][u][s4] = *(const float*)((const char*)(s0b + (s4 < nvalid[S][u] ? (size_t)s4 * p.Tin : 0)) + off);
+                            if (DUAL) v1[S][u][s4] = *(const float*)((const char*)(s1b + (s4 < nvalid[S][u] ? (size_t)s4 * p.Tin : 0)) + off);
+                        }
+                    }
+                    return;
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    nvalid[S][u] = 4;
+                    const unsigned off = base0[u] + ubase;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        v0[S][u][s4] = *(const float*)((const char*)(s0b + (size_t)s4 * p.Tin) + off);
+                        if (DUAL) v1[S][u][s4] = *(const float*)((const char*)(s1b + (size_t)s4 * p.Tin) + off);
+                    }
+                }
+            };
+            auto write_slab_t = [&](auto set_tag, char* Xd, auto use_div, auto masked) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_tag)::value;
+                const int c0 = wr_chunk * p.CC;
+                if (++wr_chunk == p.nchunk) wr_chunk = 0;
+                const char* t0 = (const char*)(tab0 + c0);
+                const char* t1 = (const char*)(tab1 + c0);
+                float4 a0[PLAIN ? 1 : NU][2], a1[DUAL ? NU : 1][2];      // (scale, shift) of the slot's 4 channels: 32 contiguous bytes
+                if (!PLAIN) {
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        a0[u][0] = *(const float4*)(t0 + cl32[u]); a0[u][1] = *(const float4*)(t0 + cl32[u] + 16);
+                        if (DUAL) { a1[u][0] = *(const float4*)(t1 + cl32[u]); a1[u][1] = *(const float4*)(t1 + cl32[u] + 16); }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    f32x4 o;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        float v = v0[S][u][s4];
+                        if (!PLAIN) {
+                            const float sc = s4 == 0 ? a0[u][0].x : s4 == 1 ? a0[u][0].z : s4 == 2 ? a0[u][1].x : a0[u][1].z;
+                            const float sh = s4 == 0 ? a0[u][0].y : s4 == 1 ? a0[u][0].w : s4 == 2 ? a0[u][1].y : a0[u][1].w;
+                            if (decltype(use_div)::value) v = v / divv;
+                            v = fmaf(v, sc, sh);
+                            if (DUAL) {
+                                const float sc1 = s4 == 0 ? a1[u][0].x : s4 == 1 ? a1[u][0].z : s4 == 2 ? a1[u][1].x : a1[u][1].z;
+                                const float sh1 = s4 == 0 ? a1[u][0].y : s4 == 1 ? a1[u][0].w : s4 == 2 ? a1[u][1].y : a1[u][1].w;
+                                v = v + fmaf(v1[S][u][s4], sc1, sh1);
+                            }
+                            if (ELU) v = elu_f(v, p.alpha);
+                        }
+                        if (decltype(masked)::value) v = (((vmask[S] >> u) & 1u) && s4 < nvalid[S][u]) ? v : 0.f;
+                        o[s4] = v;
+                    }
+                    *(f32x4*)(Xd + slot[u]) = o;
+                }
+            };
+            auto write_slab = [&](auto set_tag, char* Xd) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_tag)::value;
+                if (MODE == 1 && p.div0) write_slab_t(set_tag, Xd, std::true_type(), std::true_type());
+                else if (all_valid[S]) write_slab_t(set_tag, Xd, std::false_type(), std::false_type());
+                else write_slab_t(set_tag, Xd, std::false_type(), std::true_type());
+            };
+            using Set0 = std::integral_constant<int, 0>;
+            using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
+            int st_tile = t_begin, st_chunk = 0;
+            auto step = [&](int f, auto wr_set) __attribute__((always_inline)) {
+                FC_STAMP(1, f, 0);
+                if (STAGING_DMA && f + 1 < nitems && !resident) {
+                    const int nc = st_chunk + 1 == p.nchunk ? 0 : st_chunk + 1;
+                    dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
+                }
+                if (f + 1 < nitems) {
+                    write_slab(wr_set, (char*)(Xs0 + ((f + 1) & 1) * XSF));
+                    FC_STAMP(1, f, 1);
+                    if (f + 1 + NSET < nitems) load_slab(wr_set);
+                    FC_STAMP(1, f, 2);
+                }
+                __syncthreads();
+                FC_STAMP(1, f, 3);
+                if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
+                FC_STAMP(1, f, 4);
+            };
+            load_slab(Set0());
+            write_slab(Set0(), (char*)Xs0);
+            if (DEEP) {
+                if (nitems > 1) load_slab(Set1());
+                if (nitems > 2) load_slab(Set0());
+            } else {
+                if (nitems > 1) load_slab(Set0());
+            }
+            __syncthreads();                              // B0
+            if (DEEP) {
+                for (int f = 0; f < nitems; f += 2) {
+                    step(f, Set1());
+                    if (f + 1 < nitems) step(f + 1, Set0());
+                }
+            } else {
+                for (int f = 0; f < nitems; ++f) step(f, Set0());
+            }
+            __syncthreads();                              // final
             return;
         }
         const int total = p.CC * p.slabW;             // <= 256 * NU
@@ -695,6 +1151,54 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
         };
+        if constexpr (QK) {
+          if (!(p.ablate & 1)) {
+            // quad-k feed: per quad (4 k-steps) ONE 16-byte LDS read per operand tile, 4 x TM x TN MFMAs; the reads of quad q + 1 are issued
+            // ahead of the MFMAs of quad q (fenced, as below).  The quad count is even (a zero-weight pad quad with table offset 0 if needed);
+            // the table has entries for the two quads the pipeline reads ahead.
+            const f32x4* WsA = (const f32x4*)(smem + (resident ? chunk : (f & 1)) * p.Wbuf) + (hi * BM + wm * (TM * 32) + l31);
+            const char* XbB = (const char*)(Xs0 + (f & 1) * XSF) + 16 * (wn * (TN * 32) + l31);
+            const int* kq = kofs_i + hi;                  // this lane half's entry of a quad: table[2 q + hi]
+            auto load_quad = [&](int q, int bofs, f32x4 (&a)[TM], f32x4 (&bb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = WsA[q * 2 * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bb[j] = *(const f32x4*)(XbB + 4 * bofs + j * (32 * 16));
+            };
+            auto mfma_quad = [&](const f32x4 (&a)[TM], const f32x4 (&bb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s4], bb[j][s4], acc[i][j], 0, 0, 0);
+            };
+            f32x4 qa0[TM], qb0[TN], qa1[TM], qb1[TN];
+            load_quad(0, kq[0], qa0, qb0);
+            int ko = kq[2];
+            for (int q = 0; q < p.nq2; q += 2) {
+                load_quad(q + 1, ko, qa1, qb1);
+                ko = kq[2 * q + 4];
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_quad(qa0, qb0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (wleft > 0) {
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)wdst, 16, 0, 0);
+                    wsrc += 1024; wdst += 1024; wleft -= 1024;
+                }
+                load_quad(q + 2, ko, qa0, qb0);
+                ko = kq[2 * q + 6];
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_quad(qa1, qb1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (wleft > 0) {
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)wdst, 16, 0, 0);
+                    wsrc += 1024; wdst += 1024; wleft -= 1024;
+                }
+            }
+          }
+        } else
         if (!(p.ablate & 1)) {
             // the packed weight image is zero-padded to a multiple of 4 k-steps (conv_wbuf_floats) and the offset
             // table to two groups more, so there is no tail: padded k-steps multiply zeros into the accumulators
@@ -737,12 +1241,12 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
 
 // entries of the k-step offset table: the k-steps of a chunk rounded up to whole groups of 4, plus two zero groups the
 // pipelined main loop may read ahead
-template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW>
+template <int BM, int BN, int WM, int WN, int MODE, int NU, bool ROW, bool QK = false>
 static hipError_t launch_conv_k(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     // the opt-in to > 64 KiB of dynamic LDS is per (kernel, device): one bit per device, set idempotently (two threads
     // racing here both set the attribute, which is harmless)
     static std::atomic<unsigned long long> attr_done{0ull};
-    auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE, NU, ROW>;
+    auto kfn = conv_mfma_kernel<BM, BN, WM, WN, MODE, NU, ROW, QK>;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
@@ -764,6 +1268,19 @@ static int conv_nu_for(int total, int mode) {
     if (mode == 0 && need <= 11) return 11;
     if (mode == 0 && need <= 16) return 16;
     return need <= NU_BIG ? NU_BIG : 0;
+}
+// quad layout: slots of (channel quad, column) units per staging thread: 2 .. 5 (two-source prologues: <= 3)
+static int conv_nuq_for(int totalq, int mode) {
+    const int need = (totalq + 255) / 256;
+    if (need <= 2) return 2;
+    if (need <= 3) return 3;
+    if (mode >= 3) return 0;
+    return need <= 4 ? 4 : (need <= 5 ? 5 : 0);
+}
+// quad layout, row staging: rounds of 256 (4 channels x 4 columns) units per item (1 also covers chunks with fewer units than one round)
+static int conv_rowq_rounds(int CC, int BN) {
+    const int units = (CC / 4) * (BN / 4);
+    return units <= 256 ? 1 : units / 256;
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>
@@ -790,6 +1307,38 @@ static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t 
     return hipErrorInvalidValue;
 }
 
+// quad-layout instantiations (their own translation units: conv_tileq_*.hip)
+template <int BM, int BN, int WM, int WN, int MODE>
+static hipError_t launch_conv_mq(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    if constexpr (MODE == 5) {      // DMA-staged slab: NU = 16-byte pieces per lane of a staging wave (256 per round)
+        const int nj = ((a.CC / 4) * a.rowStride + 255) / 256;
+        if (nj == 1) return launch_conv_k<BM, BN, WM, WN, 5, 1, false, true>(a, grid, lds, st);
+        if (nj == 2) return launch_conv_k<BM, BN, WM, WN, 5, 2, false, true>(a, grid, lds, st);
+        if (nj == 3) return launch_conv_k<BM, BN, WM, WN, 5, 3, false, true>(a, grid, lds, st);
+        if (nj == 4) return launch_conv_k<BM, BN, WM, WN, 5, 4, false, true>(a, grid, lds, st);
+        if (nj == 5) return launch_conv_k<BM, BN, WM, WN, 5, 5, false, true>(a, grid, lds, st);
+        if (nj == 6) return launch_conv_k<BM, BN, WM, WN, 5, 6, false, true>(a, grid, lds, st);
+        return hipErrorInvalidValue;
+    } else {
+    if (a.row) {
+        const int nr = conv_rowq_rounds(a.CC, BN);
+        if (nr == 1) return launch_conv_k<BM, BN, WM, WN, MODE, 1, true, true>(a, grid, lds, st);
+        if constexpr (MODE < 3) {
+            if (nr == 2) return launch_conv_k<BM, BN, WM, WN, MODE, 2, true, true>(a, grid, lds, st);
+        }
+        return hipErrorInvalidValue;
+    }
+    const int nu = conv_nuq_for((a.CC / 4) * a.slabW, MODE);
+    if (nu == 2) return launch_conv_k<BM, BN, WM, WN, MODE, 2, false, true>(a, grid, lds, st);
+    if (nu == 3) return launch_conv_k<BM, BN, WM, WN, MODE, 3, false, true>(a, grid, lds, st);
+    if constexpr (MODE < 3) {
+        if (nu == 4) return launch_conv_k<BM, BN, WM, WN, MODE, 4, false, true>(a, grid, lds, st);
+        if (nu == 5) return launch_conv_k<BM, BN, WM, WN, MODE, 5, false, true>(a, grid, lds, st);
+    }
+    return hipErrorInvalidValue;
+    }
+}
+
 // one explicit instantiation per tile shape, each in its own translation unit (conv_tile_*.hip) so that they compile in parallel
 template <int BM, int BN, int WM, int WN>
 hipError_t launch_conv_tile(const ConvLaunch& c, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
@@ -799,6 +1348,14 @@ hipError_t launch_conv_tile(const ConvLaunch& c, const ConvArgs& a, dim3 grid, s
     if (c.s0.aff || c.s0.div || c.elu) return c.elu ? launch_conv_m<BM, BN, WM, WN, 2>(a, total, grid, lds, st)
                                                     : launch_conv_m<BM, BN, WM, WN, 1>(a, total, grid, lds, st);
     return launch_conv_m<BM, BN, WM, WN, 0>(a, total, grid, lds, st);
+}
+template <int BM, int BN, int WM, int WN>
+hipError_t launch_conv_tile_q(const ConvLaunch& c, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    if (a.xq_Tp > 0) return launch_conv_mq<BM, BN, WM, WN, 5>(a, grid, lds, st);
+    if (c.s1.ptr) return c.elu ? launch_conv_mq<BM, BN, WM, WN, 4>(a, grid, lds, st) : launch_conv_mq<BM, BN, WM, WN, 3>(a, grid, lds, st);
+    if (c.s0.aff || c.s0.div || c.elu) return c.elu ? launch_conv_mq<BM, BN, WM, WN, 2>(a, grid, lds, st)
+                                                    : launch_conv_mq<BM, BN, WM, WN, 1>(a, grid, lds, st);
+    return launch_conv_mq<BM, BN, WM, WN, 0>(a, grid, lds, st);
 }
 
 // which template instantiation launch_conv() will pick (profiling labels)

@@ -624,10 +624,10 @@ int pack_gemm(fc_engine* e, ConvLayer& L, const std::vector<float>& wg /*[M][cin
                 for (int cl = 0; cl < L.CC; ++cl) {
                     const int ci = ch * L.CC + cl;
                     if (ci >= L.cin) continue;
-                    float* dst = &packed[(size_t)(mt * L.nchunk + ch) * wbuf + ((size_t)kk * L.CC + cl) * L.BM];
+                    float* img = &packed[(size_t)(mt * L.nchunk + ch) * wbuf];
                     for (int mm = 0; mm < L.BM; ++mm) {
                         const int m = mt * L.BM + mm;
-                        if (m < L.M) dst[mm] = wg[((size_t)m * L.cin + ci) * L.gk + kk];
+                        if (m < L.M) img[fc::conv_pack_index(L.gk, L.CC, L.BM, kk, cl, mm)] = wg[((size_t)m * L.cin + ci) * L.gk + kk];
                     }
                 }
     std::vector<float> bpad(L.Mpad, 0.f);
@@ -905,23 +905,34 @@ ConvGeom conv_geom(const ConvLayer& L, int T) {
     return g;
 }
 
+static bool out_override_blocks_xq(const ConvLayer& L) { return L.kf != 1 || L.valid || L.cout <= 4; }   // 2-D / STFT GEMMs / few-output FMA layers
 Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, int elu, int Tin,
              float* out_override = nullptr, long long sB = 0, long long sM = 0, long long sT = 0) {
     const ConvGeom g = conv_geom(L, Tin);
     // Layers with several M tiles would re-apply the fused prologue (GroupNorm affine, residual add, ELU) once per
     // M tile; for those (deep, short tensors) it is cheaper to materialise the activated input once and stream it.
     const bool has_prologue = (s0.used & 2) || s1.used || elu;
+    int xq_Tp = 0;
     if ((L.Mpad / L.BM >= 3 || L.force_plain) && has_prologue) {
-        float* tmp = cx.alloc<float>((size_t)cx.B * L.cin * Tin);
+        // the conv kernel's quad layout stages such an input by DMA when it is materialised with 4 channels interleaved and its padding in
+        // place (kernels.hip combine_xq_kernel / conv_kernel.h MODE 5); else the plain [B][C][T] tensor and the register-staged PLAIN form
+        const bool xq = !s0.div && !out_override_blocks_xq(L) && fc::conv_xq_ok(L.cin, L.CC, L.gk, L.gstride, L.dil, L.BM, L.BN, L.row ? 1 : 0);
+        const int padL_x = L.transposed ? 1 : g.padL, padR_x = L.transposed ? 1 : g.padR;
+        const int Tp = padL_x + Tin + padR_x;
+        float* tmp = xq ? cx.alloc<float>(fc::conv_xq_floats(cx.B, L.cin, Tp, L.BN, L.gstride, L.gk, L.dil))
+                        : cx.alloc<float>((size_t)cx.B * L.cin * Tin);
         cx.launches++;
         if (!cx.dry && !cx.err) {
-            hipError_t er0 = fc::launch_combine(s0, s1, elu, e->arch.elu_alpha, nullptr, cx.B, L.cin, Tin, Tin, tmp,
-                                                (long long)L.cin * Tin, Tin, 1, cx.st);
+            hipError_t er0 = xq ? fc::launch_combine_xq(s0, s1, elu, e->arch.elu_alpha, cx.B, L.cin, Tin, padL_x, padR_x,
+                                                        (L.transposed || L.zpadL >= 0) ? 1 : 0, tmp, cx.st)
+                                : fc::launch_combine(s0, s1, elu, e->arch.elu_alpha, nullptr, cx.B, L.cin, Tin, Tin, tmp,
+                                                     (long long)L.cin * Tin, Tin, 1, cx.st);
             if (er0 != hipSuccess) { cx.err = 1; g_err = std::string("combine launch failed: ") + hipGetErrorString(er0); }
         }
         s0 = fc::Src(); s0.ptr = tmp; s0.used = 1;
         s1 = fc::Src();
         elu = 0;
+        if (xq) xq_Tp = Tp;
     }
     fc::ConvLaunch c;
     c.s0 = s0; c.s1 = s1; c.elu = elu; c.alpha = e->arch.elu_alpha;
@@ -930,6 +941,7 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
     c.k = L.gk; c.stride = L.gstride; c.dil = L.dil; c.padL = g.padL; c.padR = g.padR;
     c.BM = L.BM; c.BN = L.BN; c.CC = L.CC; c.nchunk = L.nchunk; c.row = L.row ? 1 : 0;
     c.w_plain = L.w_plain; c.bias_host0 = L.bias0;
+    c.xq_Tp = xq_Tp;
     Act out;
     out.C = L.cout; out.T = g.Tout;
     if (L.transposed) {
@@ -969,9 +981,9 @@ Act run_conv(fc_engine* e, Ctx& cx, const ConvLayer& L, fc::Src s0, fc::Src s1, 
             int mode = 0, nu = 0;
             int row = 0;
             fc::conv_variant(c, &mode, &nu, &row);
-            char nm[64];
-            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1,
-                     L.BM >= 128 ? 2 : 4, mode, nu, row ? "true" : "false");
+            char nm[80];
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1,
+                     L.BM >= 128 ? 2 : 4, mode, nu, (row & 1) ? "true" : "false", (row & 2) ? "true" : "false");
             if (fc::conv_cout1_ok(c))
                 fc::conv_fewout_name(c, nm, sizeof(nm));
             cls = e->prof_class(nm);
@@ -1278,9 +1290,9 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         if (e->profiling) {
             int mode = 0, nu = 0, row = 0;
             fc::conv_variant(c, &mode, &nu, &row);
-            char nm[64];
-            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
-                     row ? "true" : "false");
+            char nm[80];
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
+                     (row & 1) ? "true" : "false", (row & 2) ? "true" : "false");
             if (fc::conv_cout1_ok(c))
                 fc::conv_fewout_name(c, nm, sizeof(nm));
             cls = e->prof_class(nm);
@@ -1387,9 +1399,9 @@ Act2 run_convtr2d(fc_engine* e, Ctx& cx, const ConvLayer& S, const std::vector<C
         if (e->profiling) {
             int mode = 0, nu = 0, row = 0;
             fc::conv_variant(c, &mode, &nu, &row);
-            char nm[64];
-            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
-                     row ? "true" : "false");
+            char nm[80];
+            snprintf(nm, sizeof(nm), "conv_mfma_kernel<%d, %d, %d, %d, %d, %d, %s, %s>", L.BM, L.BN, L.BM >= 128 ? 2 : 1, L.BM >= 128 ? 2 : 4, mode, nu,
+                     (row & 1) ? "true" : "false", (row & 2) ? "true" : "false");
             if (fc::conv_cout1_ok(c))
                 fc::conv_fewout_name(c, nm, sizeof(nm));
             cls = e->prof_class(nm);

@@ -34,6 +34,8 @@ struct ConvLaunch {
     double* partials = nullptr;   // [B][nblk][2] (sum, sumsq) or null
     int BM = 128, BN = 128, CC = 2, nchunk = 1;   // tiling chosen at pack time
     int row = 0;                  // stride-1 row staging (conv_row_ok() at pack time)
+    int xq_Tp = 0;                // > 0: s0.ptr is the channel-quad-interleaved padded materialisation of launch_combine_xq() with this many
+                                  // columns per row (padL + Tin + padR): the slab is staged by DMA (conv_kernel.h MODE 5); no s1, no affine, no ELU
     // 2-D nets in frequency-major layout (kernels of conv_kernel.h, "two-level batch addressing"); defaults = 1-D layer
     int Fo = 1;                   // virtual utterances per real utterance (B = real utterances x Fo)
     int affC = 0;                 // channels of the affine tables (0: = Cin)
@@ -50,6 +52,8 @@ bool conv_fewout_rows(const ConvLaunch& c);                 // ... its LDS form 
 void conv_fewout_name(const ConvLaunch& c, char* buf, size_t n); // the kernel symbol launch_conv picks for a few-output layer (profile class name)
 size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
+bool conv_quad(int CC);                                     // this chunking uses the quad-k operand layout (kernels.hip)
+size_t conv_pack_index(int k, int CC, int BM, int kk, int cl, int mm);   // float index of W[row mm][chunk channel cl][tap kk] in a chunk image
 size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row);
 bool conv_row_ok(int k, int stride, int dil, int CC, int BM, int BN, int Cin, bool dual);   // row staging usable with this chunking?
 bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dual);
@@ -110,6 +114,16 @@ hipError_t launch_istft_finish(const float* ypoly, const float* win2, int B, int
 // Reduce stat partials -> mean/rstd -> per-(b,c) GroupNorm affine table aff[b][c] = (rstd*gamma, beta-mean*rstd*gamma)
 hipError_t launch_gn_finalize(const double* partials, int nblk, double count, const float* gamma,
                               const float* beta, int C, float eps, int B, float* aff, hipStream_t st);
+
+// xq[b][c / 4][padL + t][c % 4] = pad( [elu]( f0(s0) + f1(s1) ) )[t]  for t in [-padL, Tin + padR): the activated input of a conv layer
+// materialised WITH its padding (reflect as pad1d conv.py:82-99 incl. the zero-extension of short inputs, or zeros) and with 4 channels
+// interleaved, i.e. in the order the quad-layout conv kernel's B-operand planes hold it: a plane row is contiguous memory and the conv
+// kernel stages it by DMA.  C % 4 == 0.  conv_xq_ok(): this layer / launch can take that path; conv_xq_floats(): buffer size incl. the
+// slack the last tile's DMA reads past the last row.
+bool conv_xq_ok(int Cin, int CC, int k, int stride, int dil, int BM, int BN, int row);
+size_t conv_xq_floats(int B, int Cin, int Tp, int BN, int stride, int k, int dil);
+hipError_t launch_combine_xq(const Src& s0, const Src& s1, int elu, float alpha, int B, int C, int Tin, int padL, int padR, int pad_zero,
+                             float* xq, hipStream_t st);
 
 // out[b][c][t] (strides) = [elu]( f0(s0) + f1(s1) ) * mul[b]     for t < Tcopy
 hipError_t launch_combine(const Src& s0, const Src& s1, int elu, float alpha, const float* mul,

@@ -16,12 +16,41 @@ FC_CONV_TILE(64, 256, 1, 4)
 FC_CONV_TILE(32, 256, 1, 4)
 FC_CONV_TILE(32, 128, 1, 4)
 #undef FC_CONV_TILE
+// ... and their quad-layout twins (conv_tileq_*.hip)
+#define FC_CONV_TILE_Q(BM, BN, WM, WN) \
+    extern template hipError_t launch_conv_tile_q<BM, BN, WM, WN>(const ConvLaunch&, const ConvArgs&, dim3, size_t, hipStream_t);
+FC_CONV_TILE_Q(128, 128, 2, 2)
+FC_CONV_TILE_Q(64, 256, 1, 4)
+FC_CONV_TILE_Q(32, 256, 1, 4)
+FC_CONV_TILE_Q(32, 128, 1, 4)
+#undef FC_CONV_TILE_Q
 
-static int conv_koff_len(int k, int CC) { return (((k * CC / 2) + 3) & ~3) + 8; }
+// QUAD-K operand layout (round 5, tests/micro/conv_loop_feed_b128.hip: 0.95 - 0.98 of the fp32 MFMA peak from the LDS feed against 0.81 /
+// 0.89 for one ds_read_b32 per operand tile per k-step): chunks of a multiple of 8 channels keep both operands so that a lane's values
+// of FOUR consecutive k-steps are one 16-byte piece.  FC_QUAD=0 restores the round-4 layout (A / B aid).
+bool conv_quad(int CC) {
+    static const int quad_env = getenv("FC_QUAD") ? atoi(getenv("FC_QUAD")) : 1;
+    return quad_env != 0 && CC >= 4 && CC % 4 == 0;
+}
+// A chunk's k indices are grouped into HALF-QUADS (tap kk, channel quad g4) in tap-major order h = kk * CC/4 + g4; quad q = half-quads 2q
+// (lanes 0-31 of the MFMA operands) and 2q + 1 (lanes 32-63).  Quads per chunk, rounded up to an even count (the matrix loop runs two
+// quads per trip; pad half-quads have zero weights and table offset 0)
+static int conv_nquads(int k, int CC) { return (((k * (CC / 4) + 1) / 2) + 1) & ~1; }
+static int conv_koff_len(int k, int CC) { return conv_quad(CC) ? ((2 * conv_nquads(k, CC) + 3) & ~3) + 8 : (((k * CC / 2) + 3) & ~3) + 8; }
+// float index of W[m = mm of the tile][chunk channel cl][tap kk] inside a packed chunk image
+//   round-4 layout: [kk][cl][BM]                      (k-step = two consecutive channels)
+//   quad layout:    [quad = h / 2][hi = h & 1][BM][s = cl & 3],  h = kk * CC/4 + cl/4     (k-step s of a quad = channel s of its two half-quads)
+size_t conv_pack_index(int k, int CC, int BM, int kk, int cl, int mm) {
+    (void)k;
+    if (!conv_quad(CC)) return ((size_t)kk * CC + cl) * BM + mm;
+    const int h = kk * (CC / 4) + cl / 4, s4 = cl & 3;
+    return (((size_t)(h >> 1) * 2 + (h & 1)) * BM + mm) * 4 + s4;
+}
 
 // copy of the timeline stamps of a profiling build (zeros otherwise): [role][item][slot]
 hipError_t debug_timeline_128(unsigned long long* dst);   // conv_tile_128x128.hip (the profiling build stamps that tile shape)
-hipError_t debug_timeline(unsigned long long* dst) { return debug_timeline_128(dst); }
+hipError_t debug_timeline_128q(unsigned long long* dst);  // conv_tileq_128x128.hip
+hipError_t debug_timeline(unsigned long long* dst) { return conv_quad(4) ? debug_timeline_128q(dst) : debug_timeline_128(dst); }
 
 static ConvArgs make_args(const ConvLaunch& c) {
     ConvArgs a;
@@ -54,9 +83,16 @@ static ConvArgs make_args(const ConvLaunch& c) {
     // floats per slab buffer: row staging = the image; element staging = whole 256-element slots (the last float is the dummy
     // slot of lanes without an element)
     a.xsf = c.row ? c.CC * a.rowStride + 4 : ceil_div(c.CC * a.rowStride, 256) * 256 + 4;
+    a.xq_Tp = c.xq_Tp;
+    if (conv_quad(c.CC) && !c.s1.ptr && !c.s0.aff && !c.s0.div && !c.elu)
+        a.xsf = ceil_div(c.CC * a.rowStride, 1024) * 1024 + 4;      // plain quad layers: whole 256-piece DMA rounds (conv_lds_bytes_for, ntab = 0)
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.koff = c.koff;
     a.koff_n = conv_koff_len(c.k, c.CC);
+    a.quad = conv_quad(c.CC) ? 1 : 0;
+    a.nq2 = conv_nquads(c.k, c.CC);
+    // quad element staging: units of (4 channels, slab column)
+    a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.cin_tail = (c.Cin % c.CC) != 0;
     static const int ablate = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
     a.ablate = ablate;
@@ -69,6 +105,17 @@ std::vector<int> conv_koff_table(int k, int stride, int dil, int CC, int BN, int
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     int PL = ceil_div(slabW, stride), rowStride = PL * stride;
     if (row) { rowStride = (slabW + 3) & ~3; PL = rowStride; }
+    if (conv_quad(CC)) {
+        // entry 2 q + hi = FLOAT offset of half-quad h = 2 q + hi: its channel plane (planes are [g4][rowStride columns][4 channels]) and the
+        // column of its tap
+        const int n4 = CC / 4;
+        std::vector<int> t(conv_koff_len(k, CC), 0);
+        for (int h = 0; h < k * n4; ++h) {
+            const int kk = h / n4, g4 = h % n4, pos = kk * dil;
+            t[h] = (g4 * rowStride + (pos % stride) * PL + pos / stride) * 4;
+        }
+        return t;
+    }
     const int nks = k * CC / 2, half_cc = CC / 2;
     std::vector<int> t(conv_koff_len(k, CC), 0);
     for (int ks = 0; ks < nks; ++ks) {
@@ -79,7 +126,10 @@ std::vector<int> conv_koff_table(int k, int stride, int dil, int CC, int BN, int
 }
 
 // K of a chunk is zero-padded to a multiple of 4 k-steps (8 k values): the main loop has no tail
-int conv_wbuf_floats(int k, int CC, int BM) { return ((((k * CC + 7) & ~7) * BM + 1023) / 1024) * 1024; }
+int conv_wbuf_floats(int k, int CC, int BM) {
+    if (conv_quad(CC)) return ((conv_nquads(k, CC) * 8 * BM + 1023) / 1024) * 1024;
+    return ((((k * CC + 7) & ~7) * BM + 1023) / 1024) * 1024;
+}
 
 bool conv_cout1_ok(const ConvLaunch& c);
 // outputs per workgroup of the few-output FMA kernels: the LDS form (1024) on short rows / 2-D layers, the streaming form (992) else
@@ -103,6 +153,15 @@ int conv_nblk(const ConvLaunch& c) {
 // rounds of one source (4 of two) in registers.
 bool conv_row_ok(int k, int stride, int dil, int CC, int BM, int BN, int Cin, bool dual) {
     if (stride != 1 || (BN != 128 && BN != 256)) return false;
+    if (conv_quad(CC)) {
+        // quad layout: units of (4 channels x 4 columns), 256 per round: one or two whole rounds (two-source prologues: one -- a unit holds
+        // 16 values per source, more rounds spill) or less than one; one tail unit (4 channels x 1 column) per thread at most
+        if (Cin % CC != 0) return false;
+        const int units = (CC / 4) * (BN / 4);
+        if (units > 256 && units % 256 != 0) return false;
+        if (units / 256 > (dual ? 1 : 2)) return false;
+        return (CC / 4) * (k - 1) * dil <= 256 && (size_t)conv_wbuf_floats(k, CC, BM) <= 8192;
+    }
     const int rpr = 4 * (64 / (BN / 4));
     if (CC % rpr != 0 || Cin % CC != 0) return false;
     if (CC / rpr > (dual ? 4 : 8)) return false;
@@ -113,7 +172,8 @@ size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, in
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int rowStride = row ? ((slabW + 3) & ~3) : ceil_div(slabW, stride) * stride;
     const int img = CC * rowStride;
-    const int xs = row ? img + 4 : ceil_div(img, 256) * 256 + 4;   // make_args(): xsf
+    int xs = row ? img + 4 : ceil_div(img, 256) * 256 + 4;   // make_args(): xsf
+    if (conv_quad(CC) && ntab == 0) xs = ceil_div(img, 1024) * 1024 + 4;
     const size_t koff_bytes = (size_t)conv_koff_len(k, CC) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
            (size_t)BM * sizeof(float) + 2 * 256 * 8;
@@ -125,6 +185,7 @@ int conv_wgs_per_cu(int) { return 2; }
 bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dual) {
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int img = CC * ceil_div(slabW, stride) * stride;
+    if (conv_quad(CC)) return (CC / 4) * slabW <= (dual ? 3 : 5) * 256;    // quad slots of 4 channels: 3 two-source, 5 otherwise
     if (dual) return img <= NU_DUAL * 256;             // two-source prologue: at most NU_DUAL slots (two values + two table entries each)
     return img <= SLAB_PER_THREAD * 256;
 }
@@ -140,7 +201,14 @@ void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row) {
     if (c.s1.ptr) *mode = c.elu ? 4 : 3;
     else if (c.s0.aff || c.s0.div || c.elu) *mode = c.elu ? 2 : 1;
     else *mode = 0;
-    if (a.row) {
+    if (a.quad && a.xq_Tp > 0) {
+        *mode = 5; *nu = ((a.CC / 4) * a.rowStride + 255) / 256; *row = 2;
+        return;
+    }
+    if (a.quad) {
+        *nu = a.row ? conv_rowq_rounds(a.CC, c.BN) : conv_nuq_for((a.CC / 4) * a.slabW, *mode);
+        *row |= 2;                                         // bit 1: quad layout (profile label)
+    } else if (a.row) {
         const int nr = a.CC / (4 * (64 / (c.BN / 4)));
         *nu = (nr == 2 || nr == 4 || (nr == 8 && *mode < 3)) ? nr : 1;
     } else {
@@ -152,12 +220,19 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     if (conv_cout1_ok(c)) return launch_conv_cout1(c, st);
     const ConvArgs a = make_args(c);
-    const size_t lds = conv_lds_bytes(c);
+    static const int lds_extra = getenv("FC_LDS_EXTRA") ? atoi(getenv("FC_LDS_EXTRA")) : 0;      // bring-up aid
+    const size_t lds = conv_lds_bytes(c) + (size_t)lds_extra;
     if (lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
     // the staging waves address a chunk's rows with 32-bit byte offsets from a per-chunk base
     if ((unsigned long long)c.CC * (unsigned long long)c.Tin * 4ull >= (1ull << 32)) return hipErrorInvalidValue;
-    if (c.row) {
+    if (c.xq_Tp > 0) {
+        if (!a.quad || c.s1.ptr || c.s0.aff || c.s0.div || c.elu || (c.Fo > 1) || c.Cin % c.CC != 0 ||
+            !conv_xq_ok(c.Cin, c.CC, c.k, c.stride, c.dil, c.BM, c.BN, c.row) || c.xq_Tp != c.padL + c.Tin + c.padR)
+            return hipErrorInvalidValue;
+    } else if (c.row) {
         if (!conv_row_ok(c.k, c.stride, c.dil, c.CC, c.BM, c.BN, c.Cin, c.s1.ptr != nullptr) || c.s0.div) return hipErrorInvalidValue;
+    } else if (a.quad) {
+        if (!conv_slab_fits(c.k, c.stride, c.dil, c.CC, c.BN, c.BM, c.s1.ptr != nullptr)) return hipErrorInvalidValue;
     } else if (c.CC * (ceil_div((c.BN - 1) * c.stride + (c.k - 1) * c.dil + 1, c.stride) * c.stride) > SLAB_PER_THREAD * 256) {
         return hipErrorInvalidValue;
     }
@@ -169,6 +244,13 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
     dim3 grid(G, mtiles, c.B);
+    if (a.quad) {
+        if (c.BM == 128 && c.BN == 128) return launch_conv_tile_q<128, 128, 2, 2>(c, a, grid, lds, st);
+        if (c.BM == 64 && c.BN == 256) return launch_conv_tile_q<64, 256, 1, 4>(c, a, grid, lds, st);
+        if (c.BM == 32 && c.BN == 256) return launch_conv_tile_q<32, 256, 1, 4>(c, a, grid, lds, st);
+        if (c.BM == 32 && c.BN == 128) return launch_conv_tile_q<32, 128, 1, 4>(c, a, grid, lds, st);
+        return hipErrorInvalidValue;
+    }
     if (c.BM == 128 && c.BN == 128) return launch_conv_tile<128, 128, 2, 2>(c, a, grid, lds, st);
     if (c.BM == 64 && c.BN == 256) return launch_conv_tile<64, 256, 1, 4>(c, a, grid, lds, st);
     if (c.BM == 32 && c.BN == 256) return launch_conv_tile<32, 256, 1, 4>(c, a, grid, lds, st);
@@ -1205,6 +1287,95 @@ hipError_t launch_combine(const Src& s0, const Src& s1, int elu, float alpha, co
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(combine_kernel, dim3(gx, C, B), dim3(256), 0, st, s0, s1, elu, alpha, mul, C, Tsrc, Tcopy, out,
                        o_sB, o_sC, o_sT);
+    return hipGetLastError();
+}
+
+// Materialisation for the DMA-staged conv form (conv_kernel.h MODE 5): 4 channels interleaved, padding in place.  One thread = 4 channels x 4
+// padded columns: four 16-byte loads (interior) or 16 resolved dword loads (the few columns around the row ends), four 16-byte stores = 64
+// contiguous bytes.
+__global__ __launch_bounds__(256) void combine_xq_kernel(Src s0, Src s1, int elu, float alpha, int C, int Tin, int padL, int padR, int pad_zero,
+                                                         int Leff, float* __restrict__ xq) {
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int b = blockIdx.z, g4 = blockIdx.y, Tp = padL + Tin + padR;
+    const size_t row0 = (size_t)b * C + 4 * g4;
+    float2 a0[4], a1[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        a0[s4] = s0.aff ? ((const float2*)s0.aff)[row0 + s4] : make_float2(1.f, 0.f);
+        a1[s4] = (s1.ptr && s1.aff) ? ((const float2*)s1.aff)[row0 + s4] : make_float2(1.f, 0.f);
+    }
+    const float* r0 = s0.ptr + row0 * Tin;
+    const float* r1 = s1.ptr ? s1.ptr + row0 * Tin : r0;
+    f32x4* orow = (f32x4*)xq + ((size_t)b * (C >> 2) + g4) * (size_t)Tp;
+    const int hi_lim = Tin + padR, refl = 2 * (Leff - 1);
+    auto act = [&](float v, float w, int s4) __attribute__((always_inline)) {
+        if (s0.aff) v = fmaf(v, a0[s4].x, a0[s4].y);
+        if (s1.ptr) v = v + (s1.aff ? fmaf(w, a1[s4].x, a1[s4].y) : w);
+        if (elu) v = elu_f(v, alpha);
+        return v;
+    };
+    const int T4 = (Tp + 3) >> 2;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < T4; q += gridDim.x * 256) {
+        const int g = 4 * q - padL;                  // tensor column of padded column 4 q
+        f32x4 x0[4], x1[4];
+        bool ok[4] = {true, true, true, true};
+        if (g >= 0 && g + 3 < Tin) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                x0[s4] = *(const f32x4u*)(r0 + (size_t)s4 * Tin + g);
+                x1[s4] = s1.ptr ? (f32x4)(*(const f32x4u*)(r1 + (size_t)s4 * Tin + g)) : x0[s4];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gj = g + j;
+                bool o = gj >= -padL && gj < hi_lim;
+                int src = gj < 0 ? -gj : gj;
+                src = src >= Leff ? refl - src : src;
+                if (pad_zero) { src = gj; o = o && gj >= 0; }
+                o = o && src >= 0 && src < Tin;          // zero padding / zero-extension of short inputs (conv.py:89-93)
+                src = o ? src : 0;
+                ok[j] = o;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    x0[s4][j] = r0[(size_t)s4 * Tin + src];
+                    x1[s4][j] = s1.ptr ? r1[(size_t)s4 * Tin + src] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (4 * q + j >= Tp) break;
+            f32x4 y;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) y[s4] = ok[j] ? act(x0[s4][j], x1[s4][j], s4) : 0.f;
+            orow[4 * q + j] = y;
+        }
+    }
+}
+
+bool conv_xq_ok(int Cin, int CC, int k, int stride, int dil, int BM, int BN, int row) {
+    static const int xq_env = getenv("FC_XQ") ? atoi(getenv("FC_XQ")) : 1;          // FC_XQ=0: register staging everywhere (A / B aid)
+    if (!xq_env || !conv_quad(CC) || Cin % 4 != 0 || Cin % CC != 0) return false;
+    const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
+    const int rowStride = row ? ((slabW + 3) & ~3) : ceil_div(slabW, stride) * stride;
+    (void)BM;
+    return ceil_div((CC / 4) * rowStride, 256) <= 6;
+}
+size_t conv_xq_floats(int B, int Cin, int Tp, int BN, int stride, int k, int dil) {
+    // the DMA of the last N tile reads a whole slab (and the pad lanes of its last round read row 0 of the chunk): slack of one slab + one
+    // round of pieces behind the last row
+    return ((size_t)B * (Cin / 4) * (size_t)Tp + (size_t)BN * stride + (size_t)k * dil + 64 + 256) * 4;
+}
+hipError_t launch_combine_xq(const Src& s0, const Src& s1, int elu, float alpha, int B, int C, int Tin, int padL, int padR, int pad_zero,
+                             float* xq, hipStream_t st) {
+    if (C % 4 != 0 || B <= 0 || Tin <= 0 || s0.div) return hipErrorInvalidValue;
+    const int Tp = padL + Tin + padR;
+    const int maxpad = padL > padR ? padL : padR;
+    const int Leff = Tin > maxpad ? Tin : maxpad + 1;
+    int gx = ceil_div(ceil_div(Tp, 4), 256);
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(combine_xq_kernel, dim3(gx, C / 4, B), dim3(256), 0, st, s0, s1, elu, alpha, C, Tin, padL, padR, pad_zero, Leff, xq);
     return hipGetLastError();
 }
 

@@ -218,10 +218,10 @@ int pack_full(fc_laura* e, Lin& L, const std::vector<float>& W, const std::vecto
             for (int cl = 0; cl < L.CC; ++cl) {
                 const int ci = ch * L.CC + cl;
                 if (ci >= L.cin) continue;
-                float* dst = &packed[(size_t)(mt * L.nchunk + ch) * wbuf + (size_t)cl * L.BM];
+                float* img = &packed[(size_t)(mt * L.nchunk + ch) * wbuf];
                 for (int mm = 0; mm < L.BM; ++mm) {
                     const int m = mt * L.BM + mm;
-                    if (m < L.cout) dst[mm] = W[(size_t)m * L.cin + ci];
+                    if (m < L.cout) img[fc::conv_pack_index(1, L.CC, L.BM, 0, cl, mm)] = W[(size_t)m * L.cin + ci];
                 }
             }
     std::vector<float> bpad(L.Mpad, 0.f);

@@ -77,8 +77,13 @@ def test_the_whole_n_rank_flow_of_bench_main_runs_on_cpu_with_a_stand_in_engine(
     assert out["config"]["ranks_seen"] == 2 and out["config"]["global_utterances"] == 10 and out["config"]["micro_batch"] == 2
     assert "config_c_shard_b128" in out["config"]["scaling_base"]
     assert out["gather_ok"] is True and "REHEARSAL" in out["metric"] and out["value"] == 0.0
+    # the self-diagnosing fields of an N > 1 line: per-rank step times, the gather timed alone, the collective library
+    mg = out["multi_gpu"]
+    assert len(mg["rank_ms_per_step"]) == 2 and mg["rank_ms_per_step_min"] <= mg["rank_ms_per_step_max"]
+    assert abs(mg["rank_ms_per_step_max"] - max(mg["rank_ms_per_step"])) < 1e-9 and mg["rank_ms_per_step_max"] <= out["ms_per_step"] * 1.5 + 1.0
+    assert mg["gather_ms"] > 0 and mg["gather_bytes_per_rank"] == 5 * 32 * 10 * 8 and mg["backend"] == "gloo" and "rccl_version" in mg
     # and the single-rank flow (no launcher, no gather)
     r1 = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--no-secondary", "--no-cpu-baseline"], env_extra=env)
     assert r1.returncode == 0, r1.stderr[-3000:]
     o1 = _json_lines(r1.stdout)[0]
-    assert o1["n_gpus"] == 1 and o1["gather_ok"] is True and o1["config"]["ranks_seen"] == 1
+    assert o1["n_gpus"] == 1 and o1["gather_ok"] is True and o1["config"]["ranks_seen"] == 1 and "multi_gpu" not in o1
