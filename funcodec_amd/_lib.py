@@ -105,6 +105,7 @@ SYMBOLS = {
     "fc_laura_linear": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_size_t, _P]),
     "fc_laura_debug_probe": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int]),
     "fc_laura_set_persistent_step": (C.c_int, [_P, C.c_int]),
+    "fc_laura_persistent_step_fallbacks": (C.c_int, [_P]),
 }
 
 _lib = None

@@ -323,25 +323,29 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         }
         if constexpr (ROW && QK) {
             // ---------------------------------------------------------------------------------------------
-            // Row staging, quad-k layout (stride-1 layers).  A unit = 4 consecutive channels x 4 consecutive columns: FOUR 16-byte global
-            // loads (one per channel) and FOUR 16-byte LDS stores (one per column: the 4 channels of that column are one B-operand piece);
-            // the 4 x 4 transposition is free, it only names registers.  BN/4 threads cover the main columns of a channel quad, a round =
-            // 256 units = 256/(BN/4) channel quads; NU rounds per item (compile time).  Chunks with fewer units than one round leave whole
-            // waves without a main unit.  Tail columns ((k - 1) * dilation per row): one (channel quad, column) unit per thread.
+            // Row staging, quad-k layout (stride-1 layers).  A unit = 4 consecutive channels x CW consecutive columns (CW = 4): FOUR 16-byte
+            // global loads (one per channel) and FOUR 16-byte LDS stores (one per column: the 4 channels of that column are one B-operand
+            // piece); the 4 x 4 transposition is free, it only names registers.  BN/CW threads cover the main columns of a channel quad, a
+            // round = 256 units = 256/(BN/CW) channel quads; NU rounds per item (compile time).  Chunks with fewer than 256 such units take
+            // NARROWER units (NU = 12: CW = 2, NU = 11: CW = 1; one round) so that all four staging waves share the work -- a staging wave's
+            // instructions are issued in the gaps of the co-resident matrix wave's MFMA stream, the item lasts as long as the busiest one.
+            // Tail columns ((k - 1) * dilation per row): one (channel quad, column) unit per thread.
             // ---------------------------------------------------------------------------------------------
             typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-            constexpr int LPR = BN / 4, GPR = 256 / LPR, NR = NU;
+            typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+            constexpr int CW = NU == 12 ? 2 : (NU == 11 ? 1 : 4), NR = NU >= 11 ? 1 : NU;
+            constexpr int LPR = BN / CW, GPR = 256 / LPR;
             const int nq4 = p.CC >> 2;
             const bool has_main = rtid / LPR < nq4;        // wave-uniform (LPR >= 32); false only when the chunk has < 256 units (NR == 1)
             const int g0 = has_main ? rtid / LPR : 0, c4 = rtid % LPR;
-            const unsigned slot0 = 16u * (unsigned)(g0 * p.rowStride + 4 * c4);
+            const unsigned slot0 = 16u * (unsigned)(g0 * p.rowStride + CW * c4);
             const unsigned lds_round = 16u * (unsigned)(GPR * p.rowStride);
             const size_t src_round = (size_t)(4 * GPR) * p.Tin;
             const int km1 = p.slabW - BN;
             const bool has_tail = rtid < nq4 * km1;
             const int t_g = has_tail ? rtid / km1 : 0, t_j = has_tail ? rtid - t_g * km1 : 0;
             const unsigned t_slot = 16u * (unsigned)(t_g * p.rowStride + BN + t_j);
-            unsigned src_off = 0, eoff[4] = {0, 0, 0, 0}, emask = 0, t_off = 0;
+            unsigned src_off = 0, eoff[CW], emask = 0, t_off = 0;
             bool ld_edge = false, t_ok = true;
             bool r_edge = false, r_tok = true; unsigned r_emask = 0;
             f32x4 v0[NR][4], v1[DUAL ? NR : 1][4];
@@ -359,19 +363,19 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             auto setup_tile = [&](int tbase) __attribute__((always_inline)) {
                 ld_edge = !(tbase >= 0 && tbase + p.slabW <= p.Tin);
                 if (!ld_edge) {
-                    src_off = 4u * (unsigned)(4 * g0 * p.Tin + tbase + 4 * c4);
+                    src_off = 4u * (unsigned)(4 * g0 * p.Tin + tbase + CW * c4);
                     t_off = has_tail ? 4u * (unsigned)(4 * t_g * p.Tin + tbase + BN + t_j) : src_off;
                     t_ok = true;
                 } else {
                     emask = 0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < CW; ++j) {
                         bool ok;
-                        const int src = resolve(tbase + 4 * c4 + j, ok);
+                        const int src = resolve(tbase + CW * c4 + j, ok);
                         eoff[j] = 4u * (unsigned)(4 * g0 * p.Tin + src);
                         emask |= (ok ? 1u : 0u) << j;
                     }
-                    const int src = resolve(has_tail ? tbase + BN + t_j : tbase + 4 * c4, t_ok);
+                    const int src = resolve(has_tail ? tbase + BN + t_j : tbase + CW * c4, t_ok);
                     t_off = 4u * (unsigned)(4 * (has_tail ? t_g : g0) * p.Tin + src);
                 }
             };
@@ -389,8 +393,19 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                     for (int r = 0; r < NR; ++r)
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {
-                            v0[r][s4] = *(const f32x4u*)((const char*)(r0 + r * src_round + (size_t)s4 * p.Tin) + src_off);
-                            if (DUAL) v1[r][s4] = *(const f32x4u*)((const char*)(r1 + r * src_round + (size_t)s4 * p.Tin) + src_off);
+                            const char* a0p = (const char*)(r0 + r * src_round + (size_t)s4 * p.Tin) + src_off;
+                            const char* a1p = (const char*)(r1 + r * src_round + (size_t)s4 * p.Tin) + src_off;
+                            if constexpr (CW == 4) {
+                                v0[r][s4] = *(const f32x4u*)a0p;
+                                if (DUAL) v1[r][s4] = *(const f32x4u*)a1p;
+                            } else if constexpr (CW == 2) {
+                                const f32x2u t0 = *(const f32x2u*)a0p;
+                                v0[r][s4][0] = t0[0]; v0[r][s4][1] = t0[1];
+                                if (DUAL) { const f32x2u t1 = *(const f32x2u*)a1p; v1[r][s4][0] = t1[0]; v1[r][s4][1] = t1[1]; }
+                            } else {
+                                v0[r][s4][0] = *(const float*)a0p;
+                                if (DUAL) v1[r][s4][0] = *(const float*)a1p;
+                            }
                         }
                 } else {
 #pragma unroll
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
+                            for (int j = 0; j < CW; ++j) {
                                 v0[r][s4][j] = *(const float*)((const char*)(r0 + r * src_round + (size_t)s4 * p.Tin) + eoff[j]);
                                 if (DUAL) v1[r][s4][j] = *(const float*)((const char*)(r1 + r * src_round + (size_t)s4 * p.Tin) + eoff[j]);
                             }
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < CW; ++j) {
                             f32x4 o;
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
@@ -1280,6 +1295,8 @@ static int conv_nuq_for(int totalq, int mode) {
 // quad layout, row staging: rounds of 256 (4 channels x 4 columns) units per item (1 also covers chunks with fewer units than one round)
 static int conv_rowq_rounds(int CC, int BN) {
     const int units = (CC / 4) * (BN / 4);
+    if (units * 4 <= 256) return 11;          // units of 4 channels x 1 column
+    if (units * 2 <= 256) return 12;          // ... x 2 columns: all four staging waves share the chunk
     return units <= 256 ? 1 : units / 256;
 }
 
@@ -1323,6 +1340,8 @@ static hipError_t launch_conv_mq(const ConvArgs& a, dim3 grid, size_t lds, hipSt
     if (a.row) {
         const int nr = conv_rowq_rounds(a.CC, BN);
         if (nr == 1) return launch_conv_k<BM, BN, WM, WN, MODE, 1, true, true>(a, grid, lds, st);
+        if (nr == 12) return launch_conv_k<BM, BN, WM, WN, MODE, 12, true, true>(a, grid, lds, st);
+        if (nr == 11) return launch_conv_k<BM, BN, WM, WN, MODE, 11, true, true>(a, grid, lds, st);
         if constexpr (MODE < 3) {
             if (nr == 2) return launch_conv_k<BM, BN, WM, WN, MODE, 2, true, true>(a, grid, lds, st);
         }

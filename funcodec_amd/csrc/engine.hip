@@ -95,6 +95,7 @@ struct Ctx {
     size_t cap = 0, off = 256;       // the first buffer starts 256 bytes in: the grouped 3 x 3 conv reads one float in front of a row (freq_kernels.hip, FASTEDGE)
     bool dry = false;
     int err = 0;
+    static constexpr size_t kTailSlack = 4096;
     int launches = 0, conv_launches = 0;
     double conv_flops = 0, conv_bytes = 0, lstm_flops = 0, rvq_flops = 0, other_bytes = 0;
     template <typename T>
@@ -102,7 +103,9 @@ struct Ctx {
         off = (off + 255) & ~(size_t)255;
         T* p = dry ? nullptr : (T*)(base + off);
         off += n * sizeof(T);
-        if (!dry && off > cap) { err = 1; g_err = "workspace too small"; return nullptr; }
+        // every buffer ends at least kTailSlack bytes before the end of the workspace: kernels with unclamped row-end loads (the grouped
+        // 3 x 3 / 8 x 2 convs, freq_kernels.hip FASTEDGE) and the DMA-staged conv (over-read of the last N tile) rely on it
+        if (!dry && off + kTailSlack > cap) { err = 1; g_err = "workspace too small (sizes from fc_engine_workspace_bytes include 4 KiB of tail slack)"; return nullptr; }
         return p;
     }
 };
@@ -1206,6 +1209,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         c.out = cx.dry ? nullptr : o.buf + (long long)out_halo * orow;
         c.B = B; c.C = C; c.M = L.cout; c.G = L.groups; c.Tin = x0.T; c.Tout = g.Tout; c.Fo = Fo; c.kf = kf; c.kt = L.k; c.sf = sf; c.st = L.stride;
         c.padL = g.padL; c.padR = g.padR; c.elu = elu; c.alpha = e->arch.elu_alpha;
+        c.guard_lo = cx.base; c.guard_hi = cx.base ? cx.base + cx.cap : nullptr;      // both sources are buffers of THIS workspace (Ctx::alloc)
         c.in_sB = (long long)(x0.F + 2 * x0.halo) * rowsz; c.in_sF = rowsz;
         c.out_sB = (long long)(Fo + 2 * out_halo) * orow; c.out_sF = orow;
         const bool fuse_halo = halo_fuse_on() && fc::gconv2d_fuses_halo(kf, L.k, L.stride, Fo, out_halo);

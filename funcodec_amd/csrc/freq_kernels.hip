@@ -713,7 +713,15 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     // padding split the register-reflection form of the other one is not written for
     const bool pad_fast = (c.kt == 3 && c.padL + c.padR == 2 && (c.padL == 1 || c.padL == 2)) || (c.kt == 2 && c.padL == 1 && c.padR == 0) || c.kt == 1 ||
                           c.st != 1;
-    const bool nm = a.Leff != a.Tin || !pad_fast;
+    // unclamped row-end loads only inside a range the caller vouches for (the contract used to be a convention)
+    auto guarded = [&](const float* src) {
+        if (!src) return true;
+        if (!c.guard_lo || !c.guard_hi) return false;
+        const char* lo = (const char*)src;
+        const char* hi = lo + ((size_t)c.B * (size_t)c.in_sB) * sizeof(float);
+        return lo - 16 >= c.guard_lo && hi + 64 <= c.guard_hi;
+    };
+    const bool nm = a.Leff != a.Tin || !pad_fast || !guarded(c.src0) || !guarded(c.src1);
 #define FC_GCL(CP, OP, KF_, KT_, ST_, FO_)                                                                                    \
     do {                                                                                                                     \
         if (dual && nm) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, true, FO_, true>), grid, block, 0, st, a);         \

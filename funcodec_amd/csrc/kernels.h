@@ -87,6 +87,11 @@ struct GConvLaunch {
     int B = 0, C = 0, M = 0, G = 1, Tin = 0, Tout = 0, Fo = 0, kf = 1, kt = 1, sf = 1, st = 1, padL = 0, padR = 0, elu = 0;
     float alpha = 1.f;
     long long in_sB = 0, in_sF = 0, out_sB = 0, out_sF = 0;
+    // The register-reflection (FASTEDGE) instantiations load every lane's window where it lies: up to 8 bytes in front of a source row and 16
+    // bytes past its end.  Only a caller that GUARANTEES readable memory there may opt in: [guard_lo, guard_hi) is the readable byte range both
+    // sources lie in (the engine: its workspace, whose first buffer starts 256 bytes in and which ends with 4 KiB of slack, enforced by
+    // Ctx::alloc).  Null (the default): every source column is clamped / gathered (the NEEDMASK instantiation), no out-of-row read.
+    const char *guard_lo = nullptr, *guard_hi = nullptr;
     int out_halo = 0;      // > 0: the kernel also writes the reflected halo rows of its output (row -i = row i, row Fo-1+i = row Fo-1-i) --
                            // only honoured when gconv2d_fuses_halo() says so, else the caller runs launch_halo_rows
 };

@@ -220,8 +220,7 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st);
 hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     if (conv_cout1_ok(c)) return launch_conv_cout1(c, st);
     const ConvArgs a = make_args(c);
-    static const int lds_extra = getenv("FC_LDS_EXTRA") ? atoi(getenv("FC_LDS_EXTRA")) : 0;      // bring-up aid
-    const size_t lds = conv_lds_bytes(c) + (size_t)lds_extra;
+    const size_t lds = conv_lds_bytes(c);
     if (lds > 160 * 1024 || (c.CC & 1)) return hipErrorInvalidValue;
     // the staging waves address a chunk's rows with 32-bit byte offsets from a per-chunk base
     if ((unsigned long long)c.CC * (unsigned long long)c.Tin * 4ull >= (1ull << 32)) return hipErrorInvalidValue;

@@ -106,6 +106,7 @@ struct fc_laura {
     lk::StepLayer* step_layers = nullptr;   // device table of the LM's blocks for the persistent decoding step (laura_persist.hip)
     int persist_grid = 0;              // workgroups of the persistent step launch, 0 = not available on this device / for this model
     bool persist_on = !(getenv("FC_LAURA_PERSIST") && atoi(getenv("FC_LAURA_PERSIST")) == 0);   // fc_laura_set_persistent_step
+    int persist_fallbacks = 0;         // calls that timed out at a hand-off of the persistent step and were re-run on the kernel chain
     std::map<std::string, Lin*> lin_by_name;
     std::vector<void*> dev_allocs;
     int vocab() const { return arch.predict_nq * (arch.codebook_size + 1); }
@@ -615,18 +616,16 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
         cx.check(step_gemv(e->lm_decoder, xs, B, S.ag, S.ab, 1e-12f, 0, 0, lg, V, st), "decoder GEMV");
         cx.check(lk::launch_sample(sm, st), "sampling");
     };
+    bool timed_out = false;
     auto all_done = [&]() -> bool {       // all utterances finished? (one small read-back)
-        if (hipMemcpyAsync(&host_done, n_done, sizeof(int), hipMemcpyDeviceToHost, cx.st) != hipSuccess ||
-            hipStreamSynchronize(cx.st) != hipSuccess) { cx.err = 1; fail("decode_codec: status read-back failed"); return true; }
-        if (persist) {      // stop replaying steps once a hand-off has timed out
-            unsigned perr = 0;
-            if (hipMemcpy(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess || perr) {
-                cx.err = 1;
-                e->persist_on = false;
-                fail("decode_codec: the persistent decoding step timed out at a hand-off; this engine now uses the kernel chain "
-                     "(fc_laura_set_persistent_step(e, 1) re-enables it)");
-                return true;
-            }
+        unsigned perr = 0;             // both words in the same stream-ordered read-back: one synchronisation, no null-stream copy
+        hipError_t ea = hipMemcpyAsync(&host_done, n_done, sizeof(int), hipMemcpyDeviceToHost, cx.st);
+        if (ea == hipSuccess && persist) ea = hipMemcpyAsync(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost, cx.st);
+        if (ea != hipSuccess || hipStreamSynchronize(cx.st) != hipSuccess) { cx.err = 1; fail("decode_codec: status read-back failed"); return true; }
+        if (perr) {                    // stop replaying steps once a hand-off has timed out; the caller re-runs the call on the kernel chain
+            cx.err = 1;
+            timed_out = true;
+            return true;
         }
         return host_done >= B;
     };
@@ -652,6 +651,11 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
         if ((s & 15) == 15 && s + 1 < max_length && all_done()) break;
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (timed_out) {
+        (void)hipStreamSynchronize(cx.st);
+        e->persist_on = false;
+        return 2;
+    }
     if (cx.err) return 1;
     if (persist && ptrace) {
         std::vector<unsigned long long> tr((size_t)256 * 64 * 8);
@@ -664,9 +668,8 @@ int do_decode(fc_laura* e, Ctx& cx, const float* text_outs, const int32_t* text_
         HIP_TRY(hipMemcpyAsync(&perr, psync + sync_words - 64, sizeof(unsigned), hipMemcpyDeviceToHost, cx.st));
         HIP_TRY(hipStreamSynchronize(cx.st));
         if (perr) {
-            e->persist_on = false;         // like the persistent LSTM: never a silent result, and the engine stays usable on the kernel chain
-            return fail("decode_codec: the persistent decoding step timed out at a hand-off; this engine now uses the kernel chain "
-                        "(fc_laura_set_persistent_step(e, 1) re-enables it)");
+            e->persist_on = false;         // never a silent result: the caller (fc_laura_decode_codec) re-runs this call on the kernel chain
+            return 2;
         }
     }
     std::vector<int> gen(B);
@@ -905,9 +908,23 @@ int fc_laura_decode_codec(fc_laura* e, const float* text_outs, const int32_t* te
     for (int b = 0; b < B; ++b) prefix = std::max(prefix, text_lens[b] + 2 + (continual ? cont_lens[b] : 0));
     if (prefix + max_length > e->R) return fail("prefix + max_length exceeds max_positions");
     Ctx cx = make_ctx(B, workspace, workspace_bytes, stream);
-    return do_decode(e, cx, text_outs, text_lens, L, continual, cont_lens, Cmax < 0 ? 0 : Cmax, max_length, sampling_mode, sampling_k,
-                     sampling_p, seed, forced, tokens, out_lens, step_logp, prefix);
+    int rc = do_decode(e, cx, text_outs, text_lens, L, continual, cont_lens, Cmax < 0 ? 0 : Cmax, max_length, sampling_mode, sampling_k,
+                       sampling_p, seed, forced, tokens, out_lens, step_logp, prefix);
+    if (rc == 2) {
+        // A hand-off of the persistent decoding step timed out (its workgroups were not all resident: another stream or process held CUs --
+        // the launch is not cooperative; or a lost store).  Bounded spins, the launch has ended, nothing of its output is used: THIS call is
+        // run again from the start on the kernel chain (a generation is a function of its seed, so the result is the one the chain gives),
+        // later calls stay on the chain until fc_laura_set_persistent_step(e, 1).  The event is counted, not hidden.
+        e->persist_fallbacks++;
+        Ctx cx2 = make_ctx(B, workspace, workspace_bytes, stream);
+        rc = do_decode(e, cx2, text_outs, text_lens, L, continual, cont_lens, Cmax < 0 ? 0 : Cmax, max_length, sampling_mode, sampling_k,
+                       sampling_p, seed, forced, tokens, out_lens, step_logp, prefix);
+        if (rc == 2) return fail("decode_codec: the decoding step timed out on the kernel chain as well");
+    }
+    return rc;
 }
+
+int fc_laura_persistent_step_fallbacks(const fc_laura* e) { return e ? e->persist_fallbacks : -1; }
 
 int fc_laura_codec_emb(fc_laura* e, const float* text_outs, const int32_t* text_lens, int B, int L, const int64_t* codec, int nq_cols,
                        const int32_t* codec_lens, int Cmax, float* emb, void* workspace, size_t workspace_bytes, void* stream) {

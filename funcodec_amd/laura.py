@@ -113,6 +113,13 @@ class LauraEngine:
             logging.info("funcodec_amd: skipped %d LauraTTS checkpoint tensors outside the generation path (e.g. %s)", len(skipped), skipped[0])
         self._check(self.lib.fc_laura_finalize(self._h))
 
+    _fallbacks_seen = 0
+
+    @property
+    def persistent_step_fallbacks(self) -> int:
+        """Calls of this engine whose persistent decoding step timed out and which were re-run on the kernel chain."""
+        return int(self.lib.fc_laura_persistent_step_fallbacks(self._h))
+
     def set_persistent_step(self, on: bool) -> bool:
         """Decoding step as one persistent launch (default) or as the chain of one kernel per Linear / attention; returns whether the
         persistent form is in effect (False also when this model / device cannot run it)."""
@@ -256,6 +263,12 @@ class LauraEngine:
                                                    _ptr(ws), ws.numel(), C.c_void_p(run.cuda_stream)))
         if run is not cur:
             cur.wait_stream(run)
+        nfb = int(self.lib.fc_laura_persistent_step_fallbacks(self._h))
+        if nfb != self._fallbacks_seen:            # the call succeeded on the kernel chain after a hand-off timeout: said, not hidden
+            self._fallbacks_seen = nfb
+            import warnings
+            warnings.warn("decode_codec: the persistent decoding step timed out at a hand-off (CUs held by another stream / process?); this call "
+                          "was re-run on the kernel chain and later calls use it until set_persistent_step(True)", RuntimeWarning)
         lens = [int(v) for v in out_lens]
         return (tokens, lens, logp) if return_logp else (tokens, lens)
 

@@ -115,7 +115,10 @@ int    fc_engine_frames(const fc_engine* e, int n_samples);
 /* samples the decoder emits for n_frames frames: n_frames * hop for the time-domain codec; stft_hop * (frames * time ratios - 1) for
  * the STFT-domain codec (torch.istft with center=True).  Upper bound of `out_len` of the decode entry points. */
 int    fc_engine_decoded_samples(const fc_engine* e, int n_frames);
-/* bytes of caller-provided device scratch needed by any call with batch B and T samples (or Tf*hop). */
+/* bytes of caller-provided device scratch needed by any call with batch B and T samples (or Tf*hop).  The figure INCLUDES 4 KiB of tail
+ * slack that every entry point requires behind its last internal buffer (kernels with unclamped row-end loads and the DMA-staged conv
+ * read a few bytes past a buffer's end): a workspace that ends exactly at the last buffer is refused ("workspace too small"), never
+ * over-read.  The workspace pointer itself must be 256-byte aligned device memory. */
 size_t fc_engine_workspace_bytes(const fc_engine* e, int B, int T);
 
 /* ---- the hot path -------------------------------------------------------------------------------- */
@@ -352,6 +355,11 @@ int fc_laura_debug_probe(void* dev_dst, size_t cap_bytes, int stack, int layer, 
  * on = 0: the chain of one kernel per Linear / attention (csrc/laura_kernels.hip).  Same arithmetic, results agree to fp32 rounding.
  * Returns 1 if the persistent form is in effect afterwards, 0 if the chain is (switched off, or the model / device cannot run it), -1 on a null handle. */
 int fc_laura_set_persistent_step(fc_laura* e, int on);
+/* The persistent launch needs all its workgroups resident; it is not a cooperative launch, so CUs held by another stream or process can make
+ * a hand-off time out (bounded spins, no hang).  fc_laura_decode_codec then runs THAT call again on the kernel chain and succeeds with the
+ * chain's result (a generation is a function of its seed), and the engine stays on the chain until fc_laura_set_persistent_step(e, 1).
+ * This counter says how many calls of this engine went that way (0 normally; -1 on a null handle): a fallback is reported, never silent. */
+int fc_laura_persistent_step_fallbacks(const fc_laura* e);
 
 #ifdef __cplusplus
 }

@@ -97,13 +97,39 @@ def test_segmented_mode_against_reference_golden(name):
     g = golden(name)
     r = m.inference(wav if wav.dim() == 3 else wav.unsqueeze(1), bit_width=c["bit_width"], use_scale=True)
     assert len(r["code_indices"]) == len(c["frames"]) and len(r["sub_quants"]) == len(c["frames"])
+    tied = []                                          # (segment, utterance) pairs with a proven fp32 tie
     for f, idx in enumerate(r["code_indices"]):
         assert idx.shape == (c["n_q"], c["batch"], c["frames"][f])
-        rep = index_report(idx, g[f"indices_{f}"].astype(np.int64))
-        assert rep["mismatched_indices"] == 0, (f, rep)
+        ref_idx = g[f"indices_{f}"].astype(np.int64)
+        rep = index_report(idx, ref_idx)
+        if rep["mismatched_indices"]:
+            # bit-exact, or every differing frame is a PROVEN fp32 tie of the reference's own distances (as in the unsegmented tests; at most
+            # one frame per segment).  The fixture stores no encoder output per segment: the CPU oracle (pinned bit-for-bit to the reference
+            # on this very fixture by oracle/make_golden.py) supplies it, the engine's own comes from encoding the segment alone.
+            cfg_, arch_, sd_ = state_for(c["config"], c["weight_seed"], c["codebook_decay"])
+            orc = oracle_for(c["config"], c["weight_seed"], c["codebook_decay"])
+            o = orc.inference(wav if wav.dim() == 3 else wav, bit_width=c["bit_width"], use_scale=True)
+            assert torch.equal(o["code_indices"][f], torch.from_numpy(ref_idx))
+            seg = wav[..., f * m.arch.segment_stride: f * m.arch.segment_stride + m.arch.segment_length]
+            own = m.engine.encode(seg, c["n_q"], want_enc_out=True)
+            assert torch.equal(own["codes"], idx)
+            _assert_flips_are_near_ties(sd_["quantizer.rq.model.embed"], o["encoder_out"][f], ref_idx, idx, got_enc=own["enc_out"], max_frames=1)
+            bad_b = (idx.cpu().numpy() != ref_idx).any(0).any(-1)
+            tied += [(f, int(b)) for b in np.nonzero(bad_b)[0]]
         assert np.allclose(r["code_embeddings"][f][1].cpu().numpy(), g[f"scale_{f}"], rtol=1e-5)
     assert r["recon_speech"].shape == (c["batch"], c.get("channels", 1), c["samples"])
-    assert rms(r["recon_speech"], g["recon"]) < WAV_RMS_TOL
+    if not tied:
+        assert rms(r["recon_speech"], g["recon"]) < WAV_RMS_TOL
+    else:
+        # a tied frame changes its whole segment of that utterance (GroupNorm statistics span the segment): every sample outside the tied
+        # segments' extent must still match
+        keep = torch.ones(c["batch"], c["samples"], dtype=torch.bool)
+        for f, b in tied:
+            keep[b, f * m.arch.segment_stride: f * m.arch.segment_stride + m.arch.segment_length] = False
+        got, ref = r["recon_speech"].cpu(), torch.from_numpy(g["recon"])
+        for b in range(c["batch"]):
+            assert keep[b].any()
+            assert rms(got[b][:, keep[b]], ref[b][:, keep[b]]) < WAV_RMS_TOL, b
     # frames of one call are independent utterances: the first frame alone gives the same codes
     one = m.engine.encode(wav[..., :8000], c["n_q"])
     assert torch.equal(one["codes"], r["code_indices"][0])
