@@ -88,6 +88,25 @@ __device__ __forceinline__ float elu_f(float v, float alpha) {
     return v > 0.f ? v : fmaf(e, alpha, -alpha);
 }
 
+// Buffer loads for the register-staged quad paths (round 5): `buffer_load_dword v, v_off, s[rsrc], s_off offen` forms its address from a scalar
+// descriptor, a scalar offset and ONE 32-bit lane offset -- no vector instruction.  The global_load form hipcc picks for `base + lane offset`
+// computes a 64-bit lane address per load (v_lshl_add_u64: 114 of them in the staging loop of the two-source strided layers), and a staging
+// wave's vector instructions are what it cannot get issued next to the matrix waves' MFMA stream.
+typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stage_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);   // raw buffer, range check effectively off
+}
+__device__ __forceinline__ float buf_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+typedef float f32x2_ld __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_ld buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x2_ld, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+}
+
 // Element staging: NU = register slots (slab elements) per staging thread per chunk, a compile-time constant so that the staging
 // code is straight-line (a run-time slot count put a scalar branch between every load: measured 15 % slower).  The strided
 // layers' slabs are 4.03 / 8.06 / 10.1 / 16.0 / 16.1 x 256 elements, so the instantiations are 5, 9, 11, 16 and 18 slots (two
@@ -386,25 +405,25 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
                 r_edge = ld_edge; r_emask = emask; r_tok = t_ok;
                 if (p.ablate & 4) return;
-                const float* r0 = s0b + cbase;
-                const float* r1 = s1b + cbase;
+                // the chunk's rows through buffer descriptors: scalar base + scalar (round, channel) offset + the lane's 32-bit offset
+                const __amdgpu_buffer_rsrc_t q0 = stage_rsrc(s0b + cbase), q1 = stage_rsrc(s1b + cbase);
+                const int ch_b = 4 * p.Tin, rd_b = 4 * (int)src_round;       // bytes between channels / rounds (< 2^31: launch_conv checks CC * Tin)
                 if (!ld_edge) {
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {
-                            const char* a0p = (const char*)(r0 + r * src_round + (size_t)s4 * p.Tin) + src_off;
-                            const char* a1p = (const char*)(r1 + r * src_round + (size_t)s4 * p.Tin) + src_off;
+                            const int so = r * rd_b + s4 * ch_b;
                             if constexpr (CW == 4) {
-                                v0[r][s4] = *(const f32x4u*)a0p;
-                                if (DUAL) v1[r][s4] = *(const f32x4u*)a1p;
+                                v0[r][s4] = buf_ld4(q0, src_off, so);
+                                if (DUAL) v1[r][s4] = buf_ld4(q1, src_off, so);
                             } else if constexpr (CW == 2) {
-                                const f32x2u t0 = *(const f32x2u*)a0p;
+                                const f32x2_ld t0 = buf_ld2(q0, src_off, so);
                                 v0[r][s4][0] = t0[0]; v0[r][s4][1] = t0[1];
-                                if (DUAL) { const f32x2u t1 = *(const f32x2u*)a1p; v1[r][s4][0] = t1[0]; v1[r][s4][1] = t1[1]; }
+                                if (DUAL) { const f32x2_ld t1 = buf_ld2(q1, src_off, so); v1[r][s4][0] = t1[0]; v1[r][s4][1] = t1[1]; }
                             } else {
-                                v0[r][s4][0] = *(const float*)a0p;
-                                if (DUAL) v1[r][s4][0] = *(const float*)a1p;
+                                v0[r][s4][0] = buf_ld1(q0, src_off, so);
+                                if (DUAL) v1[r][s4][0] = buf_ld1(q1, src_off, so);
                             }
                         }
                 } else {
@@ -414,14 +433,14 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                             for (int j = 0; j < CW; ++j) {
-                                v0[r][s4][j] = *(const float*)((const char*)(r0 + r * src_round + (size_t)s4 * p.Tin) + eoff[j]);
-                                if (DUAL) v1[r][s4][j] = *(const float*)((const char*)(r1 + r * src_round + (size_t)s4 * p.Tin) + eoff[j]);
+                                v0[r][s4][j] = buf_ld1(q0, eoff[j], r * rd_b + s4 * ch_b);
+                                if (DUAL) v1[r][s4][j] = buf_ld1(q1, eoff[j], r * rd_b + s4 * ch_b);
                             }
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    tv0[s4] = *(const float*)((const char*)(r0 + (size_t)s4 * p.Tin) + t_off);
-                    if (DUAL) tv1[s4] = *(const float*)((const char*)(r1 + (size_t)s4 * p.Tin) + t_off);
+                    tv0[s4] = buf_ld1(q0, t_off, s4 * ch_b);
+                    if (DUAL) tv1[s4] = buf_ld1(q1, t_off, s4 * ch_b);
                 }
             };
             auto prologue = [&](float v, float w, float2 a, float2 a1) __attribute__((always_inline)) {
@@ -742,7 +761,14 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 vmask[S] = tile_mask;
                 if (p.ablate & 4) return;
                 all_valid[S] = ld_interior;
-                const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + (ld_interior ? tbase : 0));
+                // the chunk (and, for interior tiles, the tile origin) goes into the buffer descriptors' scalar base, the channel of a slot's
+                // four loads into the scalar offset: the lane contributes its static 32-bit descriptor only
+                const size_t org = (size_t)c0 * p.Tin;
+                const float* o0 = s0b + org;
+                const float* o1 = s1b + org;
+                if (ld_interior) { o0 += tbase; o1 += tbase; }            // tbase >= 0 here
+                const __amdgpu_buffer_rsrc_t q0 = stage_rsrc(o0), q1 = stage_rsrc(o1);
+                const int ch_b = 4 * p.Tin;
                 if (p.cin_tail && c0 + p.CC > p.Cin) {      // last chunk runs past the real channels (uniform, rare)
                     all_valid[S] = false;
 #pragma unroll
@@ -753,9 +779,10 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         nvalid[S][u] = left < 0 ? 0 : (left > 4 ? 4 : left);
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {
-                            const unsigned off = s4 < nvalid[S][u] ? base0[u] + ubase : 0u;
-                            v0[S][u][s4] = *(const float*)((const char*)(s0b + (s4 < nvalid[S][u] ? (size_t)s4 * p.Tin : 0)) + off);
-                            if (DUAL) v1[S][u][s4] = *(const float*)((const char*)(s1b + (s4 < nvalid[S][u] ? (size_t)s4 * p.Tin : 0)) + off);
+                            const bool okc = s4 < nvalid[S][u];
+                            const unsigned off = okc ? base0[u] + (unsigned)(s4 * ch_b) : 0u;
+                            v0[S][u][s4] = buf_ld1(q0, off, 0);
+                            if (DUAL) v1[S][u][s4] = buf_ld1(q1, off, 0);
                         }
                     }
                     return;
@@ -763,11 +790,10 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
                     nvalid[S][u] = 4;
-                    const unsigned off = base0[u] + ubase;
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        v0[S][u][s4] = *(const float*)((const char*)(s0b + (size_t)s4 * p.Tin) + off);
-                        if (DUAL) v1[S][u][s4] = *(const float*)((const char*)(s1b + (size_t)s4 * p.Tin) + off);
+                        v0[S][u][s4] = buf_ld1(q0, base0[u], s4 * ch_b);
+                        if (DUAL) v1[S][u][s4] = buf_ld1(q1, base0[u], s4 * ch_b);
                     }
                 }
             };
