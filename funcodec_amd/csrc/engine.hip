@@ -1916,8 +1916,15 @@ int fc_engine_work(const fc_engine* ce, int B, int T, int n_q, fc_work* out) {
     return 0;
 }
 
+namespace {
+// fc_debug_freq_features is ONE SHOT: whatever the next fc_encode / fc_encode_decode call of this thread does -- a time-domain model, an early
+// error, success -- the hook (a raw device pointer the caller may free afterwards) is disarmed when that call returns
+struct FeatHookDisarm { ~FeatHookDisarm() { g_feat_hook = FeatHook(); } };
+}  // namespace
+
 int fc_encode(fc_engine* e, const float* wav, int B, int T, int n_q, int64_t* codes, float* quantized, float* sub_quants,
               float* scale, float* enc_out, void* workspace, size_t workspace_bytes, void* stream) {
+    FeatHookDisarm disarm_feature_hook;
     if (check_ready(e)) return 1;
     if (!wav || !codes || B <= 0 || T <= 0) return fail("bad argument");
     if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");
@@ -1959,6 +1966,7 @@ int fc_decode_codes(fc_engine* e, const int64_t* codes, int B, int Tf, int n_q, 
 
 int fc_encode_decode(fc_engine* e, const float* wav, int B, int T, int n_q, int use_scale, int64_t* codes, float* quantized,
                      float* sub_quants, float* scale, float* recon, void* workspace, size_t workspace_bytes, void* stream) {
+    FeatHookDisarm disarm_feature_hook;
     if (check_ready(e)) return 1;
     if (!wav || !codes || !recon || B <= 0 || T <= 0) return fail("bad argument");
     if (n_q < 1 || n_q > e->arch.num_quantizers) return fail("n_q out of range");

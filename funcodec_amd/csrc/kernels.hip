@@ -1815,12 +1815,23 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
     // codebook fragments of a stage are loaded once for both, 32 rows per MFMA pass -- take 413 us per 32 rows per CU against 2 x 489:
     // 846 vs 974 us at 8 000 rows, 1 613 vs 1 943 at 16 000.  FC_RVQ_TWO=0 / 1 forces one form (A / B runs).
     static const int two_env = getenv("FC_RVQ_TWO") ? atoi(getenv("FC_RVQ_TWO")) : -1;
-    static int n_cus = 0;
-    if (!n_cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-    }
+    // CU count of the CURRENT device, looked up per call from a table filled once per device (thread-safe: function-local static of a
+    // type with a constructor; ADVICE r4: the round-4 form cached whichever device was current at the first call, unsynchronised)
+    struct CuTable {
+        int n[64];
+        CuTable() {
+            int nd = 0;
+            if (hipGetDeviceCount(&nd) != hipSuccess) nd = 0;
+            for (int d = 0; d < 64; ++d) {
+                hipDeviceProp_t prop;
+                n[d] = (d < nd && hipGetDeviceProperties(&prop, d) == hipSuccess) ? prop.multiProcessorCount : 256;
+            }
+        }
+    };
+    static const CuTable cu_table;
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    const int n_cus = cu_table.n[cur_dev & 63];
     const bool two = !src0 && D <= 128 && (two_env >= 0 ? (two_env != 0 && N >= 2048) : N > 16 * n_cus);
     dim3 grid(ceil_div(N, two ? 32 : 16)), block(512);
 #define FC_RVQ_CASE(DD)                                                                                            \

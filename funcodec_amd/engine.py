@@ -325,6 +325,9 @@ class CodecEngine:
         if buf is not None and (buf.device != self.device or buf.dtype != torch.float32 or not buf.is_contiguous()):
             raise EngineError("debug_freq_features: a contiguous float32 tensor on the engine's device")
         self._check(self.lib.fc_debug_freq_features(_ptr(buf), 0 if buf is None else buf.numel() * 4, int(mode)))
+        # the library keeps a RAW device pointer until the next encode call of this thread returns: keep the tensor alive at least that long
+        # (the reference is replaced by the next hook and dropped with the engine)
+        self._feat_hook_ref = buf if mode else None
 
     def check_status(self, sync: bool = True) -> None:
         """Raise if a kernel of an earlier call recorded a failure (persistent-LSTM barrier timeout, out-of-range code
