@@ -83,6 +83,7 @@ SYMBOLS = {
     "fc_engine_profile": (C.c_int, [_P, C.c_int]),
     "fc_engine_profile_read": (C.c_int, [_P, C.POINTER(FcProf)]),
     "fc_debug_timeline": (C.c_int, [_P]),
+    "fc_debug_conv_layout": (C.c_int, [C.c_int] * 7 + [_P, _P, C.c_size_t, _P, C.c_size_t]),
     "fc_debug_freq_features": (C.c_int, [_P, C.c_size_t, C.c_int]),
     "fc_codec_json_bound": (C.c_size_t, [C.c_int, C.c_int]),
     "fc_format_codec_json": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -2140,6 +2140,29 @@ int fc_debug_freq_features(void* dev_buf, size_t cap_bytes, int mode) {
     return 0;
 }
 
+// Host-side description of the conv kernel's operand layout for one chunk shape (kernels.hip: conv_pack_index / conv_koff_table); no GPU work.
+int fc_debug_conv_layout(int k, int stride, int dil, int CC, int BM, int BN, int row, int* info /* [6] */, int* pack_index, size_t pack_cap,
+                         int* koff, size_t koff_cap) {
+    if (k < 1 || stride < 1 || dil < 1 || CC < 1 || BM < 1 || BN < 1 || !info) return fail("fc_debug_conv_layout: bad shape");
+    const std::vector<int> t = fc::conv_koff_table(k, stride, dil, CC, BN, row ? 1 : 0);
+    const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
+    int PL = (slabW + stride - 1) / stride, rowStride = PL * stride;
+    if (row) { rowStride = (slabW + 3) & ~3; PL = rowStride; }
+    info[0] = fc::conv_quad(CC) ? 1 : 0; info[1] = fc::conv_wbuf_floats(k, CC, BM); info[2] = (int)t.size();
+    info[3] = rowStride; info[4] = PL; info[5] = slabW;
+    if (pack_index) {
+        if (pack_cap < (size_t)k * CC * BM) return fail("fc_debug_conv_layout: pack_index buffer too small");
+        for (int kk = 0; kk < k; ++kk)
+            for (int cl = 0; cl < CC; ++cl)
+                for (int mm = 0; mm < BM; ++mm) pack_index[((size_t)kk * CC + cl) * BM + mm] = (int)fc::conv_pack_index(k, CC, BM, kk, cl, mm);
+    }
+    if (koff) {
+        if (koff_cap < t.size()) return fail("fc_debug_conv_layout: koff buffer too small");
+        for (size_t i = 0; i < t.size(); ++i) koff[i] = t[i];
+    }
+    return 0;
+}
+
 int fc_debug_timeline(unsigned long long* dst) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(fc::debug_timeline(dst));

@@ -237,6 +237,15 @@ int fc_engine_profile_read(fc_engine* e, fc_prof* out /* [FC_PROF_CLASSES] */);
  * Only builds made with FC_TIMELINE=1 record anything (all zeros otherwise); a tuning aid, not part of the path. */
 int fc_debug_timeline(unsigned long long* dst /* [2*24*8] */);
 
+/* Host-side description of the implicit-GEMM conv kernel's operand layout for one chunk shape (k taps, CC channels per chunk, BM x BN tile);
+ * no GPU work -- what the CPU tests check the weight packing and the B-operand offset table against.
+ *   info[0] 1 = quad-k layout   info[1] floats per packed weight chunk   info[2] entries of the offset table   info[3] slab row stride
+ *   info[4] columns per stride phase (PL)   info[5] slab width in input columns
+ *   pack_index (optional) [k][CC][BM]: float index of W[row][chunk channel][tap] inside the packed chunk image
+ *   koff (optional): the B-operand offset table (floats), one entry per half-quad (quad layout) or per k-step (round-4 layout) */
+int fc_debug_conv_layout(int k, int stride, int dil, int CC, int BM, int BN, int row, int* info /* [6] */, int* pack_index, size_t pack_cap,
+                         int* koff, size_t koff_cap);
+
 /* Test hook for the STFT-domain codec (model_type 1): the NEXT fc_encode / fc_encode_decode call of this thread hands its feature tensor
  * (the 2-D encoder's input, codec_freq.py:356-379) to `dev_buf` (mode 1) or takes it from there (mode 2), in the reference's layout
  * [B][input_channels][n_fft / 2 + 1][1 + T / stft_hop] fp32; mode 0 disarms.  One shot.  Why it exists: torch.angle of a bin whose

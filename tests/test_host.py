@@ -278,3 +278,52 @@ def test_fc_arch_layout_is_the_same_in_header_binding_and_integration_doc():
     doc_fields = re.findall(r'\("([a-z_0-9]+)",\s*C\.', doc_struct)
     assert c_fields == py_fields == doc_fields, (c_fields, py_fields, doc_fields)
     assert f"abi_version={_lib.FC_ABI_VERSION}" in doc and f"#define FC_ABI_VERSION {_lib.FC_ABI_VERSION}" in hdr
+
+
+@pytest.mark.parametrize("k,stride,dil,CC,BM,BN,row", [
+    (3, 1, 1, 32, 128, 128, 1), (3, 1, 9, 16, 128, 128, 0), (7, 1, 1, 32, 64, 256, 1), (1, 1, 1, 64, 128, 128, 1),
+    (4, 2, 1, 32, 128, 128, 0), (10, 5, 1, 16, 128, 128, 0), (16, 8, 1, 8, 32, 256, 0), (2, 1, 1, 12, 32, 128, 0),
+])
+def test_conv_operand_layout_is_self_consistent(k, stride, dil, CC, BM, BN, row):
+    """Round-5 quad-k operand layout, host side only: the weight packing (conv_pack_index) and the B-operand offset
+    table (conv_koff_table) are written by different functions and met only inside the kernel's matrix loop.  This replays that loop's
+    address arithmetic in numpy -- quad q = half-quads 2q (MFMA lanes 0-31) and 2q + 1 (lanes 32-63); A piece = image[((2q + hi) BM + row) 4 + s],
+    B piece = slab[table[2q + hi] + 4 column + s] -- on a slab laid out as the staging paths write it ([channel quad][position][4 channels];
+    strided convs phase-split: position of slab column p = (p % stride) PL + p // stride) and compares with the convolution itself."""
+    lib = _lib.load()
+    info = (ctypes.c_int * 6)()
+    pack = np.zeros(k * CC * BM, np.int32)
+    koff = np.zeros(4096, np.int32)
+    rc = lib.fc_debug_conv_layout(k, stride, dil, CC, BM, BN, row, info, pack.ctypes.data, pack.size, koff.ctypes.data, koff.size)
+    assert rc == 0
+    quad, wbuf, nkoff, row_stride, PL, slabW = list(info)
+    assert quad == 1 and slabW == (BN - 1) * stride + (k - 1) * dil + 1
+    pack = pack.reshape(k, CC, BM)
+    assert len(np.unique(pack)) == pack.size and pack.min() >= 0 and pack.max() < wbuf          # an injection into the chunk image
+    rng = np.random.default_rng(k * 1000 + CC)
+    W = rng.standard_normal((BM, CC, k))
+    x = rng.standard_normal((CC, slabW))
+    image = np.zeros(wbuf)
+    image[pack.transpose(2, 1, 0).reshape(-1)] = W.reshape(-1)                                   # W[m][cl][kk] -> pack[kk][cl][m]
+    p = np.arange(slabW)
+    pos = p if row else (p % stride) * PL + p // stride
+    slab = np.zeros((CC // 4) * row_stride * 4 + 4 * BN + 64)
+    for c in range(CC):
+        slab[((c // 4) * row_stride + pos) * 4 + (c & 3)] = x[c]
+    n_half = k * (CC // 4)
+    nq = (wbuf // (8 * BM))                                                                      # quads the image has room for (pads are zero)
+    out = np.zeros((BM, BN))
+    cols = np.arange(BN)
+    for h in range(min(2 * nq, nkoff)):
+        q, hi = divmod(h, 2)
+        if h >= n_half:
+            assert not image[((2 * q + hi) * BM) * 4:((2 * q + hi + 1) * BM) * 4].any()          # pad half-quads multiply zeros
+            continue
+        for s in range(4):
+            a = image[((2 * q + hi) * BM + np.arange(BM)) * 4 + s]
+            b = slab[koff[h] + 4 * cols + s]
+            out += np.outer(a, b)
+    want = np.zeros((BM, BN))
+    for kk in range(k):
+        want += W[:, :, kk] @ x[:, cols * stride + kk * dil]
+    np.testing.assert_allclose(out, want, rtol=0, atol=1e-9)
