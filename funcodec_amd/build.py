@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     timeline = bool(os.environ.get("FC_TIMELINE"))
     # profiling build (phase timestamps inside the conv kernel, fc_debug_timeline): a SEPARATE file, selected with FC_LIB=<path>
     out = LIB_PATH.replace(".so", "_timeline.so") if timeline else LIB_PATH
-    defines = ["-DFC_TIMELINE"] if timeline else []
+    defines = ["-DFC_TIMELINE", "-DFC_AB_KNOBS"] if timeline else []     # the timeline build is a tuning build: its A / B switches are live
     defines += ["-D" + f for f in os.environ.get("FC_BUILD_DEFINES", "").split()]      # tuning aid: experimental -D switches
     if os.environ.get("FC_BUILD_OUT"):
         out = os.environ["FC_BUILD_OUT"]

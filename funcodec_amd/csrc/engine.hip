@@ -575,7 +575,7 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     // LDS budget of one workgroup.  Layers at the bottleneck frame rate with M <= 1024 have at most one workgroup per CU at the
     // benchmark shape anyway (M/128 x 2 N tiles x 16 utterances <= 256): they take the whole CU's LDS, i.e. twice as deep K
     // chunks -> half as many per-item barriers / pipeline refills for the same MFMA work (FC_SMALLN_LDS=80 restores round 1)
-    static const int smalln_lds = getenv("FC_SMALLN_LDS") ? atoi(getenv("FC_SMALLN_LDS")) : 160;
+    static const int smalln_lds = fc::ab_knob("FC_SMALLN_LDS", 160);
     const size_t lds_budget = (size_t)((L.small_n && L.M <= 1024) ? smalln_lds : 160 / fc::conv_wgs_per_cu(L.BM)) * 1024;
     int cin_p2 = 2;
     while (cin_p2 < L.cin) cin_p2 *= 2;
@@ -711,7 +711,7 @@ std::vector<float> folded_conv_weight(fc_engine* e, const ConvLayer& L) {
 // Thin residual blocks (C = 32 / 64): shortcut + block.1 run as ONE launch (kernels.hip 1c).  Weight images exactly as they sit
 // in LDS: wsc[c][m] = W_sc[m][c][0];  wb1[kk*C + c][h] = W_b1[h][c][kk].
 int pack_reshead(fc_engine* e, fc_engine::ResBlock& R) {
-    static const int enable = getenv("FC_RESHEAD") ? atoi(getenv("FC_RESHEAD")) : 1;
+    static const int enable = fc::ab_knob("FC_RESHEAD", 1);
     const int C = R.shortcut.cin, hid = R.block1.cout, K = R.block1.k;
     R.fused_head = enable && R.shortcut.cout == C && R.block1.cin == C && fc::reshead_ok(C, hid, R.shortcut.k, K, R.block1.dil, R.block1.stride) &&
                    R.shortcut.has_norm == R.block1.has_norm;
@@ -748,7 +748,7 @@ int pack_conv2d(fc_engine* e, ConvLayer& L) {
         }
     if (pack_gemm(e, L, wg, Bv)) return 1;
     // FC_GCONV=0: grouped layers stay on the block-diagonal dense GEMM (A/B aid)
-    static const int gconv_env = getenv("FC_GCONV") ? atoi(getenv("FC_GCONV")) : 1;
+    static const int gconv_env = fc::ab_knob("FC_GCONV", 1);
     if (gconv_env && L.groups > 1 && L.dil == 1 && fc::gconv2d_ok(cpg, opg, kf, kt, L.stride) && upload(e, W, &L.w_group)) return 1;
     if (L.cout <= 4 && L.stride == 1 && L.sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && upload(e, wg, &L.w_plain)) return 1;      // [cout][kf * C][kt]: FMA kernel, no MFMA tile
     if (L.has_norm) {
@@ -786,7 +786,7 @@ int pack_convtr2d(fc_engine* e, const ConvLayer& S, std::vector<ConvLayer>& phas
         if (pack_gemm(e, L, wg, bg)) return 1;
     }
     ConvLayer& L0 = phases[0];
-    static const int gconv_env = getenv("FC_GCONV") ? atoi(getenv("FC_GCONV")) : 1;
+    static const int gconv_env = fc::ab_knob("FC_GCONV", 1);
     if (gconv_env && S.groups > 1 && fc::gconvtr2d_ok(cpg, opg, r)) {          // direct kernel: torch-layout weights + plain bias
         if (upload(e, W, &L0.w_group) || upload(e, Bv, &L0.w_plain)) return 1;
     }
@@ -1154,7 +1154,7 @@ Act run_decoder(fc_engine* e, Ctx& cx, const float* z_bdt, int Tf) {
 // FreqCodec: the direct kernels and the materialisation passes write the reflected / zero halo rows of their outputs themselves (round 4;
 // FC_HALO_FUSE=0: a halo_rows launch behind every producer, as before -- A / B aid)
 static bool halo_fuse_on() {
-    static const int v = getenv("FC_HALO_FUSE") ? atoi(getenv("FC_HALO_FUSE")) : 1;
+    static const int v = fc::ab_knob("FC_HALO_FUSE", 1);
     return v != 0;
 }
 
@@ -1180,7 +1180,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
     if (L.w_group) {     // grouped conv with 2 / 4 channels per group: direct FMA kernel, prologue fused, no GEMM
         // the strided 8-row layers read every input sample from 2 output rows x ~1.25 lanes with a two-source prologue (11 VALU per read):
         // activate once instead (FC_GCONV_MAT=0: in-kernel prologue)
-        static const int gmat = getenv("FC_GCONV_MAT") ? atoi(getenv("FC_GCONV_MAT")) : 1;
+        static const int gmat = fc::ab_knob("FC_GCONV_MAT", 1);
         if (gmat && kf >= 4 && dual) {
             Act2 m;
             m.C = C; m.F = x0.F; m.T = x0.T; m.halo = x0.halo;
@@ -1241,7 +1241,7 @@ Act2 run_conv2d(fc_engine* e, Ctx& cx, const ConvLayer& L, Act2 x0, const Act2* 
         return o;
     }
     // the few-output FMA kernel re-stages every input row for each of the kf output rows that read it: activate once instead
-    static const int few_mat = getenv("FC_FEWOUT_MAT") ? atoi(getenv("FC_FEWOUT_MAT")) : 1;
+    static const int few_mat = fc::ab_knob("FC_FEWOUT_MAT", 1);
     const bool few_out = few_mat && L.cout <= 4 && L.stride == 1 && sf == 1 && (L.k == 3 || L.k == 5 || L.k == 7) && kf > 1;   // = pack_conv2d's w_plain rule
     if ((L.Mpad / L.BM >= 3 || few_out || L.force_plain) && (x0.normed || dual || elu)) {
         Act2 m;

@@ -652,7 +652,7 @@ static bool gconv2d_lds3(int kf, int kt, int st) {
     // only other workgroups can overlap, and 163 registers + 42 KB of LDS leave 3 of them per CU -- while the direct form has no barrier
     // and every wave streams on its own.  What would beat it is a persistent tile loop with a double-buffered patch; FC_GCONV_LDS3=1
     // selects this kernel for A / B runs.
-    static const int env = getenv("FC_GCONV_LDS3") ? atoi(getenv("FC_GCONV_LDS3")) : 0;
+    static const int env = ab_knob("FC_GCONV_LDS3", 0);
     return env && kf == 3 && kt == 3 && st == 1;
 }
 
@@ -665,7 +665,7 @@ bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st) {
 // output frequency rows per lane: 2 for the 3 x 3 layers (4 input rows instead of 6: 6.9 -> 5.6 ms on freqmpgr1); the strided 8-row layers
 // measured slower with 2 (12 rows x two sources in flight: 4.4 -> 5.6 ms), 1 x 1 layers share nothing
 static int gconv2d_fo(int kf, int Fo) {
-    static const int fo3 = getenv("FC_GCONV_FO3") ? atoi(getenv("FC_GCONV_FO3")) : 2;     // A / B aid: 1 .. 4 rows per lane for the 3 x 3 layers
+    static const int fo3 = ab_knob("FC_GCONV_FO3", 2);     // A / B aid: 1 .. 4 rows per lane for the 3 x 3 layers
     if (kf != 3 || Fo <= 1) return 1;
     const int f = fo3 < 1 ? 1 : (fo3 > 4 ? 4 : fo3);
     return f < Fo ? f : Fo;
@@ -941,7 +941,7 @@ hipError_t launch_gconvtr2d(const float* z, const float* w, const float* bias, f
     a.C = C; a.cout = cout; a.Fin = Fin; a.Tin = Tin; a.fr = fr; a.f_l = f_l; a.Fout = Fout; a.trimL = trimL; a.Tout = Tout; a.out_sB = out_sB;
     a.out_halo = (out_halo > 0 && Fout > out_halo) ? out_halo : 0;
     if ((Fin + 1) * fr > 65535 || B > 65535) return hipErrorInvalidValue;
-    static const int cs_env = getenv("FC_GCONVTR_CS") ? atoi(getenv("FC_GCONVTR_CS")) : 0;       // A / B aid
+    static const int cs_env = ab_knob("FC_GCONVTR_CS", 0);       // A / B aid
     a.nx = cdiv((Tin + 1) * tr, 1024);
     a.cs = 1;
     while (a.cs * 2 <= fr && a.cs * 2 <= cout && (long long)a.nx * (Fin + 1) * B * a.cs < 6144) a.cs *= 2;   // >= 4 workgroups per slot, or all there are

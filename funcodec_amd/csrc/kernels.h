@@ -2,10 +2,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <vector>
 
 namespace fc {
+
+// Tuning / ablation switches (A / B aids of tools/*.sh) are read from the environment only in builds made with
+// FC_BUILD_DEFINES=FC_AB_KNOBS (and in FC_TIMELINE builds); the shipped library takes the measured-best default of each, so that no
+// untested kernel variant can be selected in production.
+inline int ab_knob(const char* name, int dflt) {
+#ifdef FC_AB_KNOBS
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // One input of a fused prologue:  v = src[b][c][t];  optional /div[b];  optional per-(b,c) affine
 // (GroupNorm apply: v*aff[b][c][0] + aff[b][c][1]).

@@ -29,7 +29,7 @@ FC_CONV_TILE_Q(32, 128, 1, 4)
 // 0.89 for one ds_read_b32 per operand tile per k-step): chunks of a multiple of 8 channels keep both operands so that a lane's values
 // of FOUR consecutive k-steps are one 16-byte piece.  FC_QUAD=0 restores the round-4 layout (A / B aid).
 bool conv_quad(int CC) {
-    static const int quad_env = getenv("FC_QUAD") ? atoi(getenv("FC_QUAD")) : 1;
+    static const int quad_env = ab_knob("FC_QUAD", 1);
     return quad_env != 0 && CC >= 4 && CC % 4 == 0;
 }
 // A chunk's k indices are grouped into HALF-QUADS (tap kk, channel quad g4) in tap-major order h = kk * CC/4 + g4; quad q = half-quads 2q
@@ -94,7 +94,7 @@ static ConvArgs make_args(const ConvLaunch& c) {
     // quad element staging: units of (4 channels, slab column)
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.cin_tail = (c.Cin % c.CC) != 0;
-    static const int ablate = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
+    static const int ablate = ab_knob("FC_ABLATE", 0);
     a.ablate = ablate;
     return a;
 }
@@ -136,8 +136,8 @@ bool conv_cout1_ok(const ConvLaunch& c);
 static int conv_fewout_tile(const ConvLaunch& c) { return (c.Fo > 1 || c.Tout < 8192) ? 1024 : 992; }
 bool conv_fewout_rows(const ConvLaunch& c) { return conv_fewout_tile(c) == 1024; }
 static bool conv_fewout_plain(const ConvLaunch& c) {        // rows form, one materialised source, no prologue arithmetic: all-DMA staging
-    static const int plain_env = getenv("FC_FEWOUT_PLAIN") ? atoi(getenv("FC_FEWOUT_PLAIN")) : 1;     // 0: the general rows kernel (A / B aid)
-    static const int ablate_env = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
+    static const int plain_env = ab_knob("FC_FEWOUT_PLAIN", 1);     // 0: the general rows kernel (A / B aid)
+    static const int ablate_env = ab_knob("FC_ABLATE", 0);
     return conv_fewout_rows(c) && plain_env && !c.s0.aff && !c.s1.ptr && !c.elu && !ablate_env;
 }
 void conv_fewout_name(const ConvLaunch& c, char* buf, size_t n) {
@@ -745,7 +745,7 @@ static hipError_t launch_conv_cout1(const ConvLaunch& c, hipStream_t st) {
     a.out_sB = c.out_sB; a.out_sF = c.out_sF; a.out_sM = c.out_sM;
     const int tile_n = conv_fewout_tile(c);
     a.part_sB0 = c.part_sB0 ? c.part_sB0 : (long long)a.Fo * ceil_div(c.Tout, tile_n);
-    static const int ablate_env = getenv("FC_ABLATE") ? atoi(getenv("FC_ABLATE")) : 0;
+    static const int ablate_env = ab_knob("FC_ABLATE", 0);
     a.ablate = ablate_env;
     const int maxpad = c.padL > c.padR ? c.padL : c.padR;
     a.Leff = c.Tin > maxpad ? c.Tin : maxpad + 1;
@@ -1157,7 +1157,7 @@ hipError_t launch_reshead(const ResHeadLaunch& c, hipStream_t st) {
     a.alpha = c.alpha;
     const size_t lds = reshead_lds_bytes(c.C, c.k);
     const int per_cu = (int)((160 * 1024) / lds) > 3 ? 3 : (int)((160 * 1024) / lds);
-    static const int target_env = getenv("FC_RH_WGS") ? atoi(getenv("FC_RH_WGS")) : 0;
+    static const int target_env = ab_knob("FC_RH_WGS", 0);
     const int target = target_env ? target_env : 256 * (per_cu < 1 ? 1 : per_cu);
     int G = target / c.B;
     if (G < 1) G = 1;
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(256) void combine_xq_kernel(Src s0, Src s1, int elu
 }
 
 bool conv_xq_ok(int Cin, int CC, int k, int stride, int dil, int BM, int BN, int row) {
-    static const int xq_env = getenv("FC_XQ") ? atoi(getenv("FC_XQ")) : 1;          // FC_XQ=0: register staging everywhere (A / B aid)
+    static const int xq_env = ab_knob("FC_XQ", 1);          // FC_XQ=0: register staging everywhere (A / B aid)
     if (!xq_env || !conv_quad(CC) || Cin % 4 != 0 || Cin % CC != 0) return false;
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int rowStride = row ? ((slabW + 3) & ~3) : ceil_div(slabW, stride) * stride;
@@ -1809,12 +1809,12 @@ hipError_t launch_rvq_encode(const float* x, int N, int D, int K, int nq, const 
         return hipGetLastError();
     }
     // two row sets per workgroup once there are enough rows to keep ~half the CUs busy that way (L2 traffic halves)
-    static const int ablate = getenv("FC_ABLATE_RVQ") ? atoi(getenv("FC_ABLATE_RVQ")) : 0;
+    static const int ablate = ab_knob("FC_ABLATE_RVQ", 0);
     // Round 4 (tools/rvq_scaling.py): the kernel's time is linear in the workgroups per CU (one 8-wave workgroup per CU, 183 registers).
     // Up to 16 rows per CU the 16-row form is the fastest (497 vs 807 us at 4 000 rows); beyond that two row sets per workgroup -- the
     // codebook fragments of a stage are loaded once for both, 32 rows per MFMA pass -- take 413 us per 32 rows per CU against 2 x 489:
     // 846 vs 974 us at 8 000 rows, 1 613 vs 1 943 at 16 000.  FC_RVQ_TWO=0 / 1 forces one form (A / B runs).
-    static const int two_env = getenv("FC_RVQ_TWO") ? atoi(getenv("FC_RVQ_TWO")) : -1;
+    static const int two_env = ab_knob("FC_RVQ_TWO", -1);
     // CU count of the CURRENT device, looked up per call from a table filled once per device (thread-safe: function-local static of a
     // type with a constructor; ADVICE r4: the round-4 form cached whichever device was current at the first call, unsynchronised)
     struct CuTable {
@@ -1902,6 +1902,10 @@ __device__ __forceinline__ float tanh_f(float v) {
     const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * v);
     return fmaf(2.f, __builtin_amdgcn_rcpf(1.f + e), -1.f);
 }
+// c' = f * c + i * g with ONE explicit rounding order -- fma(f, c, round(i * g)) -- in every LSTM kernel: left to hipcc's contraction the
+// same expression became v_mul + v_fmac in one kernel and v_pk_mul + v_add in another (one ulp apart; the persistent and the per-step
+// forms are tested for bit equality)
+__device__ __forceinline__ float lstm_cell(float gf, float c, float gi, float gg) { return __fmaf_rn(gf, c, __fmul_rn(gi, gg)); }
 
 // -------------------------------------------------------------------------------------------------
 // Layer-wavefront LSTM step: launch s advances layer l by its timestep t = s - l for ALL layers at once
@@ -1999,7 +2003,7 @@ __global__ __launch_bounds__(256) void lstm_wave_kernel(const LstmWaveArgs p) {
                 const float gf = sigmoid_f(sgate[1] + xp[1]);
                 const float gg = tanh_f(sgate[2] + xp[2]);
                 const float go = sigmoid_f(sgate[3] + xp[3]);
-                const float cn = gf * cprev + gi * gg;
+                const float cn = lstm_cell(gf, cprev, gi, gg);
                 const float hn = go * tanh_f(cn);
                 cl[ci] = cn;
                 h_out[ci] = hn;
@@ -2201,7 +2205,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
                     const float gf = sigmoid_f(sg[1] + add[1]);
                     const float gg = tanh_f(sg[2] + add[2]);
                     const float go = sigmoid_f(sg[3] + add[3]);
-                    const float cn = gf * cst[nb] + gi * gg;
+                    const float cn = lstm_cell(gf, cst[nb], gi, gg);
                     const float hn = go * tanh_f(cn);
                     cst[nb] = cn;
                     const size_t ci = (size_t)brow * H + (size_t)blk * 4 + g;
@@ -2299,7 +2303,7 @@ hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bi
     dim3 grid(H / 4 * groups), block(256);
     // FC_LSTM_COOP=1: hipLaunchCooperativeKernel (the runtime validates the grid against the occupancy query at every launch,
     // +15-19 us of host time per launch); default: plain launch, residency validated once per engine by lstm_persist_supported()
-    static const int coop = getenv("FC_LSTM_COOP") ? atoi(getenv("FC_LSTM_COOP")) : 0;
+    static const int coop = ab_knob("FC_LSTM_COOP", 0);
     void* kargs[] = {(void*)&a};
 #define FC_LP(NS)                                                                                                \
     do {                                                                                                         \

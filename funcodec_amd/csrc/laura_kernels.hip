@@ -4,6 +4,7 @@
 // MFMA 16x16x4 operand layout (as used by the codec kernels): lane l = 16 g + r;  A operand = A[row r][k g];
 // B operand = B[k g][col r];  accumulator register v = D[row 4 g + v][col r].
 #include "laura_kernels.h"
+#include "kernels.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -687,13 +688,13 @@ __global__ __launch_bounds__(64 * KS) void gemv_kernel(GemvArgs a) {
 hipError_t launch_gemv(const Gemv& g, hipStream_t st) {
     if (g.B < 1 || g.B > 16 || g.K % 16 || g.K < 16) return hipErrorInvalidValue;
     const int nch = g.K / 16;
-    static const int ks_cap = getenv("FC_GEMV_KS") ? atoi(getenv("FC_GEMV_KS")) : 16;     // tuning aid: waves per workgroup
+    static const int ks_cap = fc::ab_knob("FC_GEMV_KS", 16);     // tuning aid: waves per workgroup
     int KS = ks_cap >= 1 && ks_cap <= 16 ? ks_cap : 16;
     while (KS > 1 && (nch % KS || nch / KS < 2)) KS >>= 1;     // >= 2 chunks per wave, K split evenly
     if (nch % KS) KS = 1;
     GemvArgs a{g.x, g.wf, g.bias, g.gamma, g.beta, g.eps, g.act, g.mode, g.y, g.ldy, g.kc, g.vc, g.pos, g.d, g.Tcap, g.B, g.K, g.N, g.K + 4,
                g.apart, g.H, g.DK, g.NS, 0};
-    static const int ablate = getenv("FC_GEMV_ABLATE") ? atoi(getenv("FC_GEMV_ABLATE")) : 0;
+    static const int ablate = fc::ab_knob("FC_GEMV_ABLATE", 0);
     a.ablate = ablate;
     if (g.apart && (g.H * g.DK != g.K || g.NS < 1 || g.NS > 8 || g.B * g.H * 8 > KS * 256)) return hipErrorInvalidValue;
     const size_t lds = ((size_t)(g.B + 1) * a.XS + (size_t)KS * 256) * sizeof(float);
