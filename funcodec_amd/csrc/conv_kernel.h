@@ -13,6 +13,8 @@ namespace fc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));     // 4-byte aligned vector stores (global memory takes them)
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 
 static inline __host__ __device__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
@@ -139,6 +141,12 @@ __device__ __forceinline__ void dma_piece_sbase(const void* sbase, unsigned voff
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte) : "memory");
+}
+template <typename T>
+__device__ __forceinline__ const T* sgpr_ptr(const T* q) {        // a wave-uniform pointer, pinned to a scalar register pair
+    const unsigned long long v = (unsigned long long)(size_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const T*)(size_t)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_byte_addr(const float* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
@@ -292,6 +300,9 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                     off[j] = 16u * (unsigned)(g4 * p.xq_Tp + q * p.stride + ph);
                 }
             }
+            // the piece form below needs its 64-bit bases in SGPRs: pinned (sgpr_ptr) once per item in dma_w / dma_slab -- when the epilogue's
+            // address arithmetic grows, hipcc otherwise moves the whole chain that starts at the utterance index to vector registers and
+            // hands the asm a VGPR pair ("invalid operand"); on an SGPR value the two v_readfirstlane fold away
             const char* xq_b = (const char*)p.src0 + (size_t)breal * (size_t)(p.Cin >> 2) * (size_t)p.xq_Tp * 16;
             const size_t chunk_bytes = (size_t)(p.CC >> 2) * (size_t)p.xq_Tp * 16;
             const int wid_s = __builtin_amdgcn_readfirstlane(wid);
@@ -304,12 +315,12 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             __builtin_amdgcn_s_setprio(3);
             auto dma_w = [&](const float* gsrc, int buf) __attribute__((always_inline)) {
                 if (p.ablate & 16) return;
-                const char* g = (const char*)gsrc;
+                const char* g = sgpr_ptr((const char*)gsrc);
                 unsigned l = smem_b + (unsigned)buf * (unsigned)p.Wbuf * 4u + (unsigned)wid_s * 1024u;
                 for (int i = 0; i < wpieces; ++i, g += 4096, l += 4096u) dma_piece_sbase(g, w_voff, l);
             };
             auto dma_slab = [&](int buf) __attribute__((always_inline)) {
-                const char* base = xq_b + (size_t)ld_chunk * chunk_bytes + (size_t)ld_tile * (size_t)(BN * p.stride) * 16;
+                const char* base = sgpr_ptr(xq_b + (size_t)ld_chunk * chunk_bytes + (size_t)ld_tile * (size_t)(BN * p.stride) * 16);
                 if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
                 if (p.ablate & 4) return;
                 const unsigned l = xs0_b + (unsigned)buf * (unsigned)XSF * 4u + (unsigned)wid_s * 1024u;
@@ -1092,6 +1103,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         const size_t out_off = out_off0;
         float s1 = 0.f, s2 = 0.f;
         const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2) && store_ok;
+        const bool up_vec = p.up_r >= 4 && (p.up_r & 3) == 0;     // ConvTranspose1d, stride % 4 == 0: vector stores below
         if (full) {
             // one 64-bit lane pointer for accumulator row 0; every other row / column tile is a wave-uniform offset
             const size_t sM = (size_t)p.out_sM;
@@ -1130,12 +1142,42 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         const float v = acc[i][j][r];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
-                        if ((p.ablate & 2) || !store_ok) continue;
+                        if ((p.ablate & 2) || !store_ok || up_vec) continue;
                         if (p.up_r) {
                             const int t = n * p.up_r + phs - p.trimL;
                             if (t >= 0 && t < p.Tfinal) rowp[t] = v;
                         } else {
                             rowp[(size_t)n * p.out_sT] = v;
+                        }
+                    }
+                }
+            }
+            // Transposed convs with a stride that is a multiple of 4: the 4 accumulator rows (r & 3) of a lane are 4 consecutive GEMM rows
+            // m = co * up_r + phase, i.e. 4 consecutive output samples of one channel: one 16-byte store instead of four scattered dwords
+            // (round 5: the scatter stores were 100 of the first ConvTranspose1d's 527 us, profiles/r05_conv_class_ablation.txt).  The statistics above keep their (row, column tile) order: same bits as before.
+            if (up_vec && !(p.ablate & 2) && store_ok) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int m = m0_l + wm * (TM * 32) + i * 32 + 8 * rq + 4 * hi;
+                        if (m >= p.M) continue;                       // M = C_out * up_r is a multiple of the group size
+                        const int co = (int)__umulhi((unsigned)m, p.magic_r), phs = m - co * p.up_r;
+                        float* __restrict__ rowp = p.out + out_off + (size_t)co * p.out_sM;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                            if (n >= p.Tout) continue;
+                            const float v0 = acc[i][j][4 * rq], v1 = acc[i][j][4 * rq + 1], v2 = acc[i][j][4 * rq + 2], v3 = acc[i][j][4 * rq + 3];
+                            const int t = n * p.up_r + phs - p.trimL;
+                            if (t >= 0 && t + 3 < p.Tfinal) {
+                                *(f32x4_u*)(rowp + t) = (f32x4_u){v0, v1, v2, v3};
+                            } else {
+                                if (t >= 0 && t < p.Tfinal) rowp[t] = v0;
+                                if (t + 1 >= 0 && t + 1 < p.Tfinal) rowp[t + 1] = v1;
+                                if (t + 2 >= 0 && t + 2 < p.Tfinal) rowp[t + 2] = v2;
+                                if (t + 3 >= 0 && t + 3 < p.Tfinal) rowp[t + 3] = v3;
+                            }
                         }
                     }
                 }
