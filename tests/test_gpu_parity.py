@@ -1199,6 +1199,35 @@ def test_full_size_determinism_and_batch_independence(config_b):
     assert torch.equal(sub["codes"], r["codes"][:, 5:8]) and torch.equal(sub["recon"], r["recon"][5:8])
 
 
+@pytest.mark.parametrize("kind,cfg,B,T", [("time", "ds640", 3, 24000), ("time", "ds320", 2, 6400), ("time", "tiny", 2, 2500),
+                                          ("freq", "freqmpgr1", 2, 16000), ("freq", "freqmpgr1", 3, 160000), ("freq", "freqmp", 1, 16000),
+                                          ("freq", "tinyfreqgr1", 3, 2500), ("time", "ds640", 2, 160000)])
+def test_results_do_not_depend_on_workspace_contents(kind, cfg, B, T):
+    """Every intermediate of a call lives in the caller's workspace (include/funcodec_amd.h), which the engine never clears: a kernel that
+    reads a location before this call has written it (a halo row, a padded column, the tail slack the unclamped edge loads of the grouped
+    convs may touch) would see whatever the previous call -- or nobody -- left there.  The same call on a workspace filled with 0xFF
+    bytes (fp32 NaN, int -1) and with zeros must give the bits of the first run."""
+    from helpers import freq_engine_for
+    m = (freq_engine_for if kind == "freq" else engine_for)(cfg, 0)
+    eng = m.engine
+    wav = audio(B, T, 77, "tones").cuda()
+    nq = m.arch.num_quantizers
+    ref = eng.encode_decode(wav, nq)
+    assert eng._ws is not None and torch.isfinite(ref["recon"]).all()
+    for fill in (0xFF, 0x00, 0x7F):
+        eng._ws.fill_(fill)
+        torch.cuda.synchronize()
+        out = eng.encode_decode(wav, nq)
+        eng.check_status()
+        assert torch.equal(out["codes"], ref["codes"]), (cfg, fill)
+        assert torch.equal(out["recon"], ref["recon"]), (cfg, fill)
+    tok = ref["codes"].permute(1, 2, 0).contiguous()
+    w0, _ = eng.decode_codes(tok)
+    eng._ws.fill_(0xFF)
+    w1, _ = eng.decode_codes(tok)
+    assert torch.equal(w0, w1)
+
+
 def test_full_size_encode_decode_round_trip_and_prefix(config_b):
     m, wav, r = config_b
     tok = r["codes"].permute(1, 2, 0).contiguous()
