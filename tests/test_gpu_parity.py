@@ -264,6 +264,27 @@ def test_rvq_two_row_set_form_is_bit_exact_vs_c_oracle():
     assert torch.equal(c16, codes[:, :4000]) and torch.equal(q16, quant[:4000])
 
 
+@pytest.mark.parametrize("cfg_name,seed,N", [("tiny", 7, 6000), ("tinyss", 7, 5003), ("fuzz10", 10, 4700), ("fuzz2", 2, 9000)])
+def test_rvq_two_row_set_form_small_codebook_dims_vs_c_oracle(cfg_name, seed, N):
+    """the two-row-set form (selected above 16 rows per CU) is instantiated for D = 16 / 32 / 64 too, and only D = 128 had a
+    bit-exactness test.  Codebooks of the tiny / SoundStream-shaped / pseudo-random configurations (K = 64 .. 256: waves without codes of
+    their own), row counts with a ragged last workgroup, against the plain-C restatement on every row and against the 16-row form."""
+    import c_oracle
+    m = engine_for(cfg_name, seed)
+    cfg, arch, sd = state_for(cfg_name, seed)
+    cb = sd["quantizer.rq.model.embed"]
+    nq = min(arch.num_quantizers, cb.shape[0])
+    rng = np.random.Generator(np.random.PCG64(900 + N))
+    x = (rng.standard_normal((N, arch.codebook_dim)) * 1.5).astype(np.float32)
+    x[5] = cb[0, 3]
+    codes, quant = m.engine.rvq_encode(torch.from_numpy(x), nq)
+    cc, cq = c_oracle.rvq_encode(x, cb, nq)
+    assert np.array_equal(codes.cpu().numpy(), cc)
+    assert np.array_equal(quant.cpu().numpy(), cq)
+    c16, q16 = m.engine.rvq_encode(torch.from_numpy(x[:3000]), nq)       # <= 16 rows per CU: the 16-row form
+    assert torch.equal(c16, codes[:, :3000]) and torch.equal(q16, quant[:3000])
+
+
 @pytest.mark.parametrize("cfg_name,seed,Tf,n_q", [("tinyq0", 7, 126, 6), ("tinyq0", 7, 127, 6), ("tinyq0", 7, 2, 6), ("tinyq0", 7, 3, 6),
                                                   ("ds320q0", 0, 501, 8), ("ss320q0", 0, 77, 4)])
 def test_rvq_q0_ds_ratio_is_bit_exact_vs_c_oracle(cfg_name, seed, Tf, n_q):
