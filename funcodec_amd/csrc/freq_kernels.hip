@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256) FC_GCONV_ATTR void gconv2d_kernel(const GConvA
 }
 
 
+#ifdef FC_AB_KNOBS      // measured slower than the direct form (see gconv2d_lds3): compiled only into A / B builds
 // -------------------------------------------------------------------------------------------------
 // Round 4: the 3 x 3 layers (stride 1) through LDS.  The direct form above activates every loaded input sample once per lane that reads
 // it: 4-column lanes overlap by 2 columns (1.5x) and 2-row lanes by 2 rows (2x), 3 activations per sample, and the layer is bound by
@@ -645,6 +646,8 @@ __global__ __launch_bounds__(256) void gconv2d_3x3_lds_kernel(const GConvArgs p)
     }
 }
 
+#endif
+
 static bool gconv2d_lds3(int kf, int kt, int st) {
     // OFF by default.  Measured on MI355X (freqmpgr1, 64 x 10 s, both forms in one call, all 42 FreqCodec tests green with either): the 8
     // launches of the 3 x 3 class take 3.04 ms through LDS against 2.58 ms direct.  The activations did drop from 3 to 1.26 per sample, but
@@ -652,8 +655,13 @@ static bool gconv2d_lds3(int kf, int kt, int st) {
     // only other workgroups can overlap, and 163 registers + 42 KB of LDS leave 3 of them per CU -- while the direct form has no barrier
     // and every wave streams on its own.  What would beat it is a persistent tile loop with a double-buffered patch; FC_GCONV_LDS3=1
     // selects this kernel for A / B runs.
+#ifdef FC_AB_KNOBS
     static const int env = ab_knob("FC_GCONV_LDS3", 0);
     return env && kf == 3 && kt == 3 && st == 1;
+#else
+    (void)kf; (void)kt; (void)st;
+    return false;
+#endif
 }
 
 bool gconv2d_ok(int cpg, int opg, int kf, int kt, int st) {
@@ -672,7 +680,9 @@ static int gconv2d_fo(int kf, int Fo) {
 }
 bool gconv2d_fuses_halo(int kf, int kt, int st, int Fo, int halo) { return halo > 0 && Fo > halo && !gconv2d_lds3(kf, kt, st); }
 int gconv2d_nblk(int Tout, int Fo, int G, int kf) {
+#ifdef FC_AB_KNOBS
     if (gconv2d_lds3(kf, kf, 1)) return cdiv(Tout, G3_TN) * cdiv(Fo, G3_RF) * G;       // (the grouped layers are square: kt == kf for kf == 3)
+#endif
     return cdiv(Tout, 1024) * cdiv(Fo, gconv2d_fo(kf, Fo)) * G;
 }
 
@@ -688,6 +698,7 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     a.out_halo = gconv2d_fuses_halo(c.kf, c.kt, c.st, c.Fo, c.out_halo) ? c.out_halo : 0;
     const int fo_n = gconv2d_fo(c.kf, c.Fo);
     if (c.kf >= 4 ? c.sf != c.kf / 2 : c.sf != 1) return hipErrorInvalidValue;          // the kernel's compile-time row stride
+#ifdef FC_AB_KNOBS
     if (gconv2d_lds3(c.kf, c.kt, c.st)) {
         const int cpg3 = c.C / c.G, opg3 = c.M / c.G;
         const int FoT = cdiv(c.Fo, G3_RF);
@@ -705,6 +716,7 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
 #undef FC_G3
         return hipErrorInvalidValue;
     }
+#endif
     if ((long long)c.B * cdiv(c.Fo, fo_n) > 65535 || c.G > 65535) return hipErrorInvalidValue;
     dim3 grid(cdiv(c.Tout, 1024), c.G, c.B * cdiv(c.Fo, fo_n)), block(256);
     const int cpg = c.C / c.G, opg = c.M / c.G;
@@ -729,11 +741,17 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
         else if (nm) hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, FO_, true>), grid, block, 0, st, a);           \
         else hipLaunchKernelGGL((gconv2d_kernel<CP, OP, KF_, KT_, ST_, false, FO_, false>), grid, block, 0, st, a);                  \
     } while (0)
+#ifdef FC_AB_KNOBS      // 3 / 4 output rows per lane (FC_GCONV_FO3): A / B builds only; the shipped library instantiates the tested 1 and 2
+#define FC_GC_AB(CP, OP, KF_, KT_, ST_)                                                                                      \
+        else if (fo_n == 3) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 3 : 1));                                               \
+        else if (fo_n == 4) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 4 : 1));
+#else
+#define FC_GC_AB(CP, OP, KF_, KT_, ST_)
+#endif
 #define FC_GC(CP, OP, KF_, KT_, ST_)                                                                                         \
     if (cpg == CP && opg == OP && c.kf == KF_ && c.kt == KT_ && c.st == ST_) {                                               \
         if (fo_n == 2) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 2 : 1));                                                    \
-        else if (fo_n == 3) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 3 : 1));                                               \
-        else if (fo_n == 4) FC_GCL(CP, OP, KF_, KT_, ST_, (KF_ == 3 ? 4 : 1));                                               \
+        FC_GC_AB(CP, OP, KF_, KT_, ST_)                                                                                      \
         else FC_GCL(CP, OP, KF_, KT_, ST_, 1);                                                                               \
         return hipGetLastError();                                                                                            \
     }
@@ -741,6 +759,7 @@ hipError_t launch_gconv2d(const GConvLaunch& c, hipStream_t st) {
     FC_GCS(1, 1, 1) FC_GCS(3, 3, 1) FC_GCS(8, 2, 1) FC_GCS(8, 4, 2)
 #undef FC_GCS
 #undef FC_GC
+#undef FC_GC_AB
 #undef FC_GCL
     return hipErrorInvalidValue;
 }
