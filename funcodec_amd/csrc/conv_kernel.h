@@ -65,6 +65,7 @@ struct ConvArgs {
                             // column t of the tensor sits at xq column padL + t, the padding values are already in place): MODE 5 DMA staging
     int quad;               // quad-k operand layout (CC % 4 == 0): A [quad][hi][BM][4], B [g4][column][4 channels]
     int nq2;                // quads per chunk, rounded up to an even count
+    int nq_odd;             // 1: the last quad of the pair count is padding only (k * CC / 4 half-quads = an odd number of quads): its MFMAs are skipped
     int cin_tail;           // Cin % CC != 0: the last chunk runs past the real channels
     // two-level batch addressing (2-D nets in frequency-major layout [B][F][C][T]: a frequency row of an utterance is one
     // "virtual utterance" of the 1-D conv): blockIdx.z = breal*Fo + fo.  1-D layers: Fo = 1, in_sB0 = Cin*Tin, affC = Cin.
@@ -1273,7 +1274,9 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 load_quad(q + 2, ko, qa0, qb0);
                 ko = kq[2 * q + 6];
                 __builtin_amdgcn_sched_barrier(0);
-                mfma_quad(qa1, qb1);
+                // an odd quad count (k = 10 taps x 4 channels = 5 quads: encoder.model.12 of the ds640 recipe) used to multiply a whole pad
+                // quad of zero weights: 16 x TM x TN MFMAs in 6 quads' worth, 17 % of that layer's matrix time
+                if (!(p.nq_odd && q + 2 >= p.nq2)) mfma_quad(qa1, qb1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (wleft > 0) {
                     __builtin_amdgcn_global_load_lds((gbl_ptr_t)wsrc, (lds_ptr_t)wdst, 16, 0, 0);

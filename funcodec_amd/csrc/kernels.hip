@@ -91,6 +91,7 @@ static ConvArgs make_args(const ConvLaunch& c) {
     a.koff_n = conv_koff_len(c.k, c.CC);
     a.quad = conv_quad(c.CC) ? 1 : 0;
     a.nq2 = conv_nquads(c.k, c.CC);
+    a.nq_odd = (conv_quad(c.CC) && ((((c.k * (c.CC / 4)) + 1) / 2) & 1)) ? 1 : 0;
     // quad element staging: units of (4 channels, slab column)
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.cin_tail = (c.Cin % c.CC) != 0;
