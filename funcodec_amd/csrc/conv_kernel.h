@@ -1105,6 +1105,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         float s1 = 0.f, s2 = 0.f;
         const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2) && store_ok;
         const bool up_vec = p.up_r >= 4 && (p.up_r & 3) == 0;     // ConvTranspose1d, stride % 4 == 0: vector stores below
+        const bool up_vec2 = p.up_r == 2;                         // ... stride 2: two 8-byte stores (two channels x two phases)
         if (full) {
             // one 64-bit lane pointer for accumulator row 0; every other row / column tile is a wave-uniform offset
             const size_t sM = (size_t)p.out_sM;
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         const float v = acc[i][j][r];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
-                        if ((p.ablate & 2) || !store_ok || up_vec) continue;
+                        if ((p.ablate & 2) || !store_ok || up_vec || up_vec2) continue;
                         if (p.up_r) {
                             const int t = n * p.up_r + phs - p.trimL;
                             if (t >= 0 && t < p.Tfinal) rowp[t] = v;
@@ -1155,7 +1156,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             }
             // Transposed convs with a stride that is a multiple of 4: the 4 accumulator rows (r & 3) of a lane are 4 consecutive GEMM rows
             // m = co * up_r + phase, i.e. 4 consecutive output samples of one channel: one 16-byte store instead of four scattered dwords
-            // (round 5: the scatter stores were 100 of the first ConvTranspose1d's 527 us, profiles/r05_conv_class_ablation.txt).  The statistics above keep their (row, column tile) order: same bits as before.
+            // (round 5, profiles/r05_conv_class_ablation.txt).  The statistics above keep their (row, column tile) order: same bits as before.
             if (up_vec && !(p.ablate & 2) && store_ok) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -1178,6 +1179,36 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                                 if (t + 1 >= 0 && t + 1 < p.Tfinal) rowp[t + 1] = v1;
                                 if (t + 2 >= 0 && t + 2 < p.Tfinal) rowp[t + 2] = v2;
                                 if (t + 3 >= 0 && t + 3 < p.Tfinal) rowp[t + 3] = v3;
+                            }
+                        }
+                    }
+                }
+            }
+            // stride 2 (the widest ConvTranspose1d of a SEANet decoder: 328 MB of output at the benchmark shape, its dword scatter was 100 of
+            // 527 us): rows m, m + 1 are the two phases of channel m / 2 -- two consecutive samples -- and rows m + 2, m + 3 those of the
+            // next channel: two 8-byte stores, and a wave's store covers 512 contiguous bytes instead of every other dword of 512
+            if (up_vec2 && !(p.ablate & 2) && store_ok) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int m = m0_l + wm * (TM * 32) + i * 32 + 8 * rq + 4 * hi;
+                        if (m >= p.M) continue;
+                        float* __restrict__ rowp = p.out + out_off + (size_t)(m >> 1) * p.out_sM;
+                        float* __restrict__ rowq = rowp + p.out_sM;
+                        const bool second = m + 2 < p.M;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                            if (n >= p.Tout) continue;
+                            const float v0 = acc[i][j][4 * rq], v1 = acc[i][j][4 * rq + 1], v2 = acc[i][j][4 * rq + 2], v3 = acc[i][j][4 * rq + 3];
+                            const int t = 2 * n - p.trimL;
+                            if (t >= 0 && t + 1 < p.Tfinal) {
+                                *(f32x2_u*)(rowp + t) = (f32x2_u){v0, v1};
+                                if (second) *(f32x2_u*)(rowq + t) = (f32x2_u){v2, v3};
+                            } else {
+                                if (t >= 0 && t < p.Tfinal) { rowp[t] = v0; if (second) rowq[t] = v2; }
+                                if (t + 1 >= 0 && t + 1 < p.Tfinal) { rowp[t + 1] = v1; if (second) rowq[t + 1] = v3; }
                             }
                         }
                     }
