@@ -1494,7 +1494,9 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
     const int codes_per_wave = (K >> 3) < 16 ? 16 : (K >> 3);   // 8 waves: two per SIMD hide the codebook-row load latency
     const bool wactive = wid * codes_per_wave < K;            // small codebooks keep only K/16 waves busy
 
+    constexpr bool DEEP = RS == 1;                                // one row set: codebook tiles two ahead (the two-row-set form has twice the MFMAs per tile)
     f32x4 b0[NQ4];                                               // first codebook fragment of the stage (requested one stage ahead)
+    f32x4 b1p[DEEP ? NQ4 : 1];                                   // DEEP: the second one
     for (int i = 0; i < nq; ++i) {
         __syncthreads();
         if (tid < 4 * ROWS) {   // |x|^2
@@ -1565,19 +1567,41 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
                 }
         };
         if (ntile > 0) {
-            f32x4 b1[NQ4];
-            if (i == 0) load_tile(0, 0, b0);
-            int t = 0;
-            for (; t + 2 <= ntile; t += 2) {
-                load_tile(i, t + 1, b1);
-                do_tile(t, b0);
-                if (t + 2 < ntile) load_tile(i, t + 2, b0);
-                do_tile(t + 1, b1);
+            if constexpr (DEEP) {
+                // Round 5: codebook tiles are requested TWO tiles ahead (three register buffers).  With one tile ahead the L2 round trip of a
+                // fragment (~1 us under this load) is as long as the 2 x 0.43 us of MFMAs of the two waves that share a SIMD.  Measured: 525 -> 517 us
+                // (of the 80 us the codebook loads cost on top of the MFMAs -- tools/ablate_rvq.py -- most is their issue time, not latency)
+                f32x4 b2[NQ4];
+                if (i == 0) { load_tile(0, 0, b0); if (ntile > 1) load_tile(0, 1, b1p); }
+                int t = 0;
+                for (; t + 3 <= ntile; t += 3) {
+                    load_tile(i, t + 2, b2);
+                    do_tile(t, b0);
+                    if (t + 3 < ntile) load_tile(i, t + 3, b0);
+                    do_tile(t + 1, b1p);
+                    if (t + 4 < ntile) load_tile(i, t + 4, b1p);
+                    do_tile(t + 2, b2);
+                }
+                if (t < ntile) do_tile(t, b0);                 // 0, 1 or 2 tiles left: already requested into b0 / b1p
+                if (t + 1 < ntile) do_tile(t + 1, b1p);
+                // the next stage's first fragments do not depend on this stage's result: requested now, the arg-max / residual-update tail
+                // of this stage hides their latency
+                if (i + 1 < nq) { load_tile(i + 1, 0, b0); if (ntile > 1) load_tile(i + 1, 1, b1p); }
+            } else {
+                f32x4 b1[NQ4];
+                if (i == 0) load_tile(0, 0, b0);
+                int t = 0;
+                for (; t + 2 <= ntile; t += 2) {
+                    load_tile(i, t + 1, b1);
+                    do_tile(t, b0);
+                    if (t + 2 < ntile) load_tile(i, t + 2, b0);
+                    do_tile(t + 1, b1);
+                }
+                if (t < ntile) do_tile(t, b0);
+                // the next stage's first fragment does not depend on this stage's result: request it now, the arg-max /
+                // residual-update tail of this stage hides its latency
+                if (i + 1 < nq) load_tile(i + 1, 0, b0);
             }
-            if (t < ntile) do_tile(t, b0);
-            // the next stage's first fragment does not depend on this stage's result: request it now, the arg-max /
-            // residual-update tail of this stage hides its latency
-            if (i + 1 < nq) load_tile(i + 1, 0, b0);
         }
 #pragma unroll
         for (int s2 = 0; s2 < RS; ++s2) {
