@@ -39,6 +39,12 @@ static inline __host__ __device__ int ceil_div(int a, int b) { return (a + b - 1
 //          Xs[2][CC][S][PL] input slab, double buffered, split by stride phase so the B fragment (lane -> column) is
 //                          conflict free for every stride (tau = n*S + kk -> [kk % S][n + kk / S]); stride-1 layers
 //                          use rows of BN + k - 1 columns padded to 16 bytes (ROW staging)
+//          QUAD-K form (round 5, QK = true: every chunking of a multiple of 4 channels, i.e. all but a net's first conv):
+//          Ws[2][quad][hi][BM][4]  a lane's weights of FOUR consecutive k-steps are one 16-byte piece (kernels.hip conv_pack_index)
+//          Xs[2][CC/4][S][PL][4]   slab planes of 4 channels, a tap = a column offset; half-quad h = tap * CC/4 + channel quad, quad q =
+//                          half-quads 2q (lanes 0-31) and 2q + 1 (lanes 32-63); one ds_read_b128 per operand tile per four k-steps
+//          MODE 5: the input arrives materialised as xq[b][C/4][padL + T + padR][4] (combine_xq_kernel) and slab + weights are staged
+//                          by LDS-DMA pieces with scalar bases: no vector instruction in the staging waves
 //          tab[Cin]        the producers' GroupNorm affine for this utterance
 //          kofs, bias, red the k-step -> slab offset table, the tile's bias, per-lane GroupNorm partials of two tiles
 // =================================================================================================
