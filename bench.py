@@ -215,8 +215,11 @@ def kernel_rooflines(prof, prof_steps):
                      "alg_gbs": round(gbs, 1) if gbs else None,
                      "bound": bound,
                      "f32_frac": round(tfl / PEAK_F32_TFLOPS, 4) if tfl else None,
-                     # a fraction above 1 can only come from an algorithmic byte count that is not one (never reported)
-                     "hbm_frac": round(gbs / 1e3 / PEAK_HBM_TBS, 4) if gbs and gbs / 1e3 <= PEAK_HBM_TBS else None})
+                     # a fraction above 1 can only come from an algorithmic byte count that is not one: the value stays visible and is
+                     # flagged (nulling it hid accounting errors); the line's `accounting_errors` lists such classes
+                     "hbm_frac": round(gbs / 1e3 / PEAK_HBM_TBS, 4) if gbs else None})
+        if gbs and gbs / 1e3 > PEAK_HBM_TBS:
+            kern[-1]["hbm_frac_invalid"] = True
     convs = [k for k in kern if k["kernel"].startswith(CONV_CLASSES)]
     mfma_bound = [k for k in convs if k["bound"] != "hbm"]
     if mfma_bound:
@@ -278,6 +281,7 @@ def kernel_rooflines(prof, prof_steps):
                                                               "alg_gbs": round(hb_by / (hb_ms * 1e-3) / 1e9, 1),
                                                               "frac": round(hb_by / (hb_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}}
     out["kernels"] = kern
+    out["accounting_errors"] = [k["kernel"] for k in kern if k.get("hbm_frac_invalid")]    # must be empty
     return out
 
 def config_c_shard_side(eng, n_q: int, utts: int = 128, micro: int = 32, steps: int = 3, warmup: int = 1):

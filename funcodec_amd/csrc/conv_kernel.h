@@ -18,6 +18,15 @@ typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
 
 static inline __host__ __device__ int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Ablation masks (ConvArgs::ablate and friends) exist in tuning builds only (FC_BUILD_DEFINES=FC_AB_KNOBS / FC_TIMELINE): in the shipped
+// library FC_ABL() is the constant 0, so no profiling branch sits around a load, a DMA piece or an MFMA block of the hot loops (a run-time
+// condition around a software-pipelined load is exactly what hipcc turns into exposed latency).
+#ifdef FC_AB_KNOBS
+#define FC_ABL(mask_, bits_) ((mask_) & (bits_))
+#else
+#define FC_ABL(mask_, bits_) (0)
+#endif
+
 // =================================================================================================
 // 1. Implicit-GEMM Conv1d / ConvTranspose1d with fused prologue and GroupNorm-statistics epilogue
 //
@@ -81,8 +90,8 @@ struct ConvArgs {
     long long out_sF;             // floats between consecutive fo of the output (out_sB: between real utterances)
     long long part_sB0;           // partial (sum, sumsq) pairs between real utterances; fo-th row at fo * nblk
     int store_lo, store_hi;       // only virtual utterances fo in [store_lo, store_hi) store their outputs (all contribute statistics)
-    int ablate;             // profiling aid (FC_ABLATE env): 1 no MFMA, 2 no stores, 4 no slab loads, 16 no weight DMA,
-                            // 128 no epilogue.  0 in production.
+    int ablate;             // profiling aid (FC_ABLATE env, FC_AB_KNOBS builds only): 1 no MFMA, 2 no stores, 4 no slab loads, 16 no weight DMA,
+                            // 128 no epilogue, 256 no prologue arithmetic (quad staging paths), 512 no slab write at all (quad staging paths)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -128,7 +137,7 @@ constexpr int SLAB_PER_THREAD = NU_BIG;      // register-staged slab elements pe
 // Direct global -> LDS copy of one packed weight chunk (contiguous, multiple of 4 KiB): each wave
 // instruction moves 1 KiB (64 lanes x 16 B) with no VGPR round trip.
 __device__ __forceinline__ void dma_weights(const float* __restrict__ gsrc, float* lds_dst, int nfloats, int tid, int ablate = 0) {
-    if (ablate & 16) return;
+    if (FC_ABL(ablate, 16)) return;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int off = 0; off < nfloats; off += 1024) {
         const float* g = gsrc + off + tid * 4;
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             // against the matrix waves whenever they have something to issue (a DMA requested late is a barrier wait for four matrix waves)
             __builtin_amdgcn_s_setprio(3);
             auto dma_w = [&](const float* gsrc, int buf) __attribute__((always_inline)) {
-                if (p.ablate & 16) return;
+                if FC_ABL(p.ablate, 16) return;
                 const char* g = sgpr_ptr((const char*)gsrc);
                 unsigned l = smem_b + (unsigned)buf * (unsigned)p.Wbuf * 4u + (unsigned)wid_s * 1024u;
                 for (int i = 0; i < wpieces; ++i, g += 4096, l += 4096u) dma_piece_sbase(g, w_voff, l);
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             auto dma_slab = [&](int buf) __attribute__((always_inline)) {
                 const char* base = sgpr_ptr(xq_b + (size_t)ld_chunk * chunk_bytes + (size_t)ld_tile * (size_t)(BN * p.stride) * 16);
                 if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
-                if (p.ablate & 4) return;
+                if FC_ABL(p.ablate, 4) return;
                 const unsigned l = xs0_b + (unsigned)buf * (unsigned)XSF * 4u + (unsigned)wid_s * 1024u;
 #pragma unroll
                 for (int j = 0; j < NU; ++j) dma_piece_sbase(base, off[j], l + (unsigned)j * 4096u);
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 const size_t cbase = (size_t)(ld_chunk * p.CC) * p.Tin;
                 if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
                 r_edge = ld_edge; r_emask = emask; r_tok = t_ok;
-                if (p.ablate & 4) return;
+                if FC_ABL(p.ablate, 4) return;
                 // the chunk's rows through buffer descriptors: scalar base + scalar (round, channel) offset + the lane's 32-bit offset
                 const __amdgpu_buffer_rsrc_t q0 = stage_rsrc(s0b + cbase), q1 = stage_rsrc(s1b + cbase);
                 const int ch_b = 4 * p.Tin, rd_b = 4 * (int)src_round;       // bytes between channels / rounds (< 2^31: launch_conv checks CC * Tin)
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 }
             };
             auto prologue = [&](float v, float w, float2 a, float2 a1) __attribute__((always_inline)) {
-                if (PLAIN) return v;
+                if (PLAIN || FC_ABL(p.ablate, 256)) return v;
                 v = fmaf(v, a.x, a.y);
                 if (DUAL) v = v + fmaf(w, a1.x, a1.y);
                 if (ELU) v = elu_f(v, p.alpha);
@@ -477,6 +486,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             auto write_slab = [&](char* Xd) __attribute__((always_inline)) {
                 const int c0 = wr_chunk * p.CC;
                 if (++wr_chunk == p.nchunk) wr_chunk = 0;
+                if (FC_ABL(p.ablate, 512)) return;
                 float2 a[PLAIN ? 1 : NR][4], a1[DUAL ? NR : 1][4], ta[4], ta1[4];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) { ta[s4] = make_float2(1.f, 0.f); ta1[s4] = make_float2(1.f, 0.f); }
@@ -609,7 +619,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 const size_t cbase = (size_t)(ld_chunk * p.CC) * p.Tin;
                 if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
                 r_edge = ld_edge; r_emask = emask; r_tok = t_ok;
-                if (p.ablate & 4) return;
+                if FC_ABL(p.ablate, 4) return;
                 const float* r0 = s0b + cbase;
                 const float* r1 = s1b + cbase;
                 if (!ld_edge) {
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 if (DUAL) tv1 = *(const float*)((const char*)r1 + t_off);
             };
             auto prologue = [&](float v, float w, float2 a, float2 a1) __attribute__((always_inline)) {
-                if (PLAIN) return v;
+                if (PLAIN || FC_ABL(p.ablate, 256)) return v;
                 v = fmaf(v, a.x, a.y);
                 if (DUAL) v = v + fmaf(w, a1.x, a1.y);
                 if (ELU) v = elu_f(v, p.alpha);
@@ -777,7 +787,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 const int c0 = ld_chunk * p.CC;
                 if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
                 vmask[S] = tile_mask;
-                if (p.ablate & 4) return;
+                if FC_ABL(p.ablate, 4) return;
                 all_valid[S] = ld_interior;
                 // the chunk (and, for interior tiles, the tile origin) goes into the buffer descriptors' scalar base, the channel of a slot's
                 // four loads into the scalar offset: the lane contributes its static 32-bit descriptor only
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
                         float v = v0[S][u][s4];
-                        if (!PLAIN) {
+                        if (!PLAIN && !FC_ABL(p.ablate, 256)) {
                             const float sc = s4 == 0 ? a0[u][0].x : s4 == 1 ? a0[u][0].z : s4 == 2 ? a0[u][1].x : a0[u][1].z;
                             const float sh = s4 == 0 ? a0[u][0].y : s4 == 1 ? a0[u][0].w : s4 == 2 ? a0[u][1].y : a0[u][1].w;
                             if (decltype(use_div)::value) v = v / divv;
@@ -855,6 +865,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             };
             auto write_slab = [&](auto set_tag, char* Xd) __attribute__((always_inline)) {
                 constexpr int S = decltype(set_tag)::value;
+                if (FC_ABL(p.ablate, 512)) { if (++wr_chunk == p.nchunk) wr_chunk = 0; return; }
                 if (MODE == 1 && p.div0) write_slab_t(set_tag, Xd, std::true_type(), std::true_type());
                 else if (all_valid[S]) write_slab_t(set_tag, Xd, std::false_type(), std::false_type());
                 else write_slab_t(set_tag, Xd, std::false_type(), std::true_type());
@@ -978,7 +989,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             const int c0 = ld_chunk * p.CC;
             if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
             vmask[S] = tile_mask;
-            if (p.ablate & 4) return;
+            if FC_ABL(p.ablate, 4) return;
             all_valid[S] = ld_interior;
             // lanes without an element (base0 = 0) read the origin: in bounds, value goes to the dummy slot / is masked
             const unsigned ubase = 4u * (unsigned)(c0 * p.Tin + (ld_interior ? tbase : 0));
@@ -1109,7 +1120,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         asm volatile("" : "+s"(m0_l));
         const size_t out_off = out_off0;
         float s1 = 0.f, s2 = 0.f;
-        const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !(p.ablate & 2) && store_ok;
+        const bool full = !p.up_r && p.out_sT == 1 && n0 + BN <= p.Tout && m0_l + BM <= p.M && !FC_ABL(p.ablate, 2) && store_ok;
         const bool up_vec = p.up_r >= 4 && (p.up_r & 3) == 0;     // ConvTranspose1d, stride % 4 == 0: vector stores below
         const bool up_vec2 = p.up_r == 2;                         // ... stride 2: two 8-byte stores (two channels x two phases)
         if (full) {
@@ -1150,7 +1161,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         const float v = acc[i][j][r];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
-                        if ((p.ablate & 2) || !store_ok || up_vec || up_vec2) continue;
+                        if (FC_ABL(p.ablate, 2) || !store_ok || up_vec || up_vec2) continue;
                         if (p.up_r) {
                             const int t = n * p.up_r + phs - p.trimL;
                             if (t >= 0 && t < p.Tfinal) rowp[t] = v;
@@ -1163,7 +1174,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             // Transposed convs with a stride that is a multiple of 4: the 4 accumulator rows (r & 3) of a lane are 4 consecutive GEMM rows
             // m = co * up_r + phase, i.e. 4 consecutive output samples of one channel: one 16-byte store instead of four scattered dwords
             // (round 5, profiles/r05_conv_class_ablation.txt).  The statistics above keep their (row, column tile) order: same bits as before.
-            if (up_vec && !(p.ablate & 2) && store_ok) {
+            if (up_vec && !FC_ABL(p.ablate, 2) && store_ok) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1193,7 +1204,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             // stride 2 (the widest ConvTranspose1d of a SEANet decoder: 328 MB of output at the benchmark shape, its dword scatter was 100 of
             // 527 us): rows m, m + 1 are the two phases of channel m / 2 -- two consecutive samples -- and rows m + 2, m + 3 those of the
             // next channel: two 8-byte stores, and a wave's store covers 512 contiguous bytes instead of every other dword of 512
-            if (up_vec2 && !(p.ablate & 2) && store_ok) {
+            if (up_vec2 && !FC_ABL(p.ablate, 2) && store_ok) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -1241,7 +1252,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         // the next weight chunk streams in as 1 KiB DMA pieces issued BETWEEN MFMA groups (one per loop trip): a piece
         // costs the issuing wave ~100 cycles, which is free while its previous MFMAs are still executing but not when
         // all pieces are issued back to back ahead of the loop
-        const bool stream_w = !STAGING_DMA && f + 1 < nitems && !resident && !(p.ablate & 16);
+        const bool stream_w = !STAGING_DMA && f + 1 < nitems && !resident && !FC_ABL(p.ablate, 16);
         const int nc = chunk + 1 == p.nchunk ? 0 : chunk + 1;
         const float* wsrc = wt_tile + (size_t)nc * p.Wbuf + rtid * 4;
         float* wdst = smem + ((f + 1) & 1) * p.Wbuf + __builtin_amdgcn_readfirstlane(wid) * 256;
@@ -1273,7 +1284,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], bb[u][j], acc[i][j], 0, 0, 0);
         };
         if constexpr (QK) {
-          if (!(p.ablate & 1)) {
+          if (!FC_ABL(p.ablate, 1)) {
             // quad-k feed: per quad (4 k-steps) ONE 16-byte LDS read per operand tile, 4 x TM x TN MFMAs; the reads of quad q + 1 are issued
             // ahead of the MFMAs of quad q (fenced, as below).  The quad count is even (a zero-weight pad quad with table offset 0 if needed);
             // the table has entries for the two quads the pipeline reads ahead.
@@ -1322,7 +1333,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             }
           }
         } else
-        if (!(p.ablate & 1)) {
+        if (!FC_ABL(p.ablate, 1)) {
             // the packed weight image is zero-padded to a multiple of 4 k-steps (conv_wbuf_floats) and the offset
             // table to two groups more, so there is no tail: padded k-steps multiply zeros into the accumulators
             const int2* kofs2 = (const int2*)kofs;
@@ -1351,7 +1362,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
         FC_STAMP(0, f, 1);
         const bool tile_done = chunk == p.nchunk - 1;
         if (tile_done) {
-            if (!(p.ablate & 128)) epilogue(tile, tile & 1);
+            if (!FC_ABL(p.ablate, 128)) epilogue(tile, tile & 1);
             zero_acc();
         }
         FC_STAMP(0, f, 2);

@@ -589,7 +589,7 @@ void choose_tiling(ConvLayer& L) {  // NOLINT
     }
     // stride-1 layers: row staging (16-byte loads and LDS stores) lifts the register bound on the chunk; take it when
     // it allows at least the same chunk
-    static const int row_env = getenv("FC_ROW") ? atoi(getenv("FC_ROW")) : 1;
+    static const int row_env = fc::deploy_switch("FC_ROW", 1);
     L.row = false;
     if (row_env && L.gstride == 1) {
         int best = 0;
@@ -1013,7 +1013,7 @@ Act run_lstm(fc_engine* e, Ctx& cx, const LstmBlock& lb, const Act& in, int T) {
     const int H = lb.H, B = cx.B, L = (int)lb.layers.size();
     float* xproj = cx.alloc<float>((size_t)T * B * 4 * H);
     run_conv(e, cx, lb.layers[0].inproj, src_of(in), fc::Src(), 0, T, xproj, (long long)4 * H, 1, (long long)B * 4 * H);
-    static const int persist_env = getenv("FC_LSTM_PERSIST") ? atoi(getenv("FC_LSTM_PERSIST")) : 1;
+    static const int persist_env = fc::deploy_switch("FC_LSTM_PERSIST", 1);
     bool persist = false;
     if (persist_env && e->lstm_persist_ok) {
         const int key = B * 4096 + H;            // the occupancy query is cached per (B, H)

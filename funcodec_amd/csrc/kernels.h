@@ -21,6 +21,20 @@ inline int ab_knob(const char* name, int dflt) {
 #endif
 }
 
+// Deployment switches: the ONLY environment variables the shipped library reads besides the test hooks below.  Every value of each selects a
+// code path whose results are tested against the default's (tests/test_gpu_parity.py::test_staging_scheme_and_workgroup_count_do_not_change_results,
+// ::test_lstm_launch_wavefront_fallback_matches_persistent_kernel; tests/test_laura.py persistent == chain), so none can select an untested variant:
+//   FC_LSTM_PERSIST=0   per-step LSTM launches instead of the persistent recurrence (shared-GPU deployments: no co-residency requirement)
+//   FC_ROW=0            element staging for the stride-1 conv layers too
+//   FC_TARGET_WGS=<n>   workgroups a conv launch aims for (default 2 per CU)
+//   FC_LAURA_PERSIST=0 / FC_LAURA_GRAPH=0   LauraTTS decoding step as the kernel chain / without the HIP graph (laura.hip)
+// Test hooks (change behaviour on purpose, documented where they are read): FC_ABLATE_LSTM=64, FC_LAURA_PERSIST_TEST=timeout.
+// Diagnostics (print / dump only): FC_DUMP_PLAN, FC_LAURA_TRACE.
+inline int deploy_switch(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 // One input of a fused prologue:  v = src[b][c][t];  optional /div[b];  optional per-(b,c) affine
 // (GroupNorm apply: v*aff[b][c][0] + aff[b][c][1]).
 struct Src {

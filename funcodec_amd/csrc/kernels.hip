@@ -238,7 +238,7 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     }
     // one resident wave of workgroups (2 per CU): each takes a contiguous range of N tiles
     const int ntiles = ceil_div(c.Tout, c.BN), mtiles = ceil_div(c.M, c.BM);
-    static const int target_env = getenv("FC_TARGET_WGS") ? atoi(getenv("FC_TARGET_WGS")) : 0;
+    static const int target_env = deploy_switch("FC_TARGET_WGS", 0);
     const int target_wgs = target_env ? target_env : 256 * conv_wgs_per_cu(c.BM);
     int G = target_wgs / (mtiles * c.B);
     if (G < 1) G = 1;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_fewout_rows_kernel(const Cout1Args p
         }
     }
     auto act = [&](float v, float w, float2 A, float2 A1) __attribute__((always_inline)) {
-        if (p.ablate & 8) return v;
+        if FC_ABL(p.ablate, 8) return v;
         v = fmaf(v, A.x, A.y);
         if (DUAL) v = v + fmaf(w, A1.x, A1.y);
         if (p.elu) v = elu_f(v, p.alpha);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void conv_fewout_rows_kernel(const Cout1Args p
 #pragma unroll
         for (int r = 0; r < C1L_CH; ++r) {
             const int c = c0 + r;
-            if (c >= p.Cin || (p.ablate & 1)) break;                   // uniform
+            if (c >= p.Cin || FC_ABL(p.ablate, 1)) break;                   // uniform
             const f32x4 q0 = *(const f32x4*)&Xs[r][4 * tid];
             const f32x4 q1 = *(const f32x4*)&Xs[r][4 * tid + 4];
             const f32x4 q2 = *(const f32x4*)&Xs[r][4 * tid + 8];
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = w0[j];
-                if (!(p.ablate & 8)) {
+                if (!FC_ABL(p.ablate, 8)) {
                     v = fmaf(v, A.x, A.y);
                     if (DUAL) v = v + fmaf(w1[j], A1.x, A1.y);
                     if (p.elu) v = elu_f(v, p.alpha);
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
             for (int j = 0; j < 4; ++j) x[4 + j] = wave_shl1(x[j]);               // samples of lane + 1
 #pragma unroll
             for (int j = 0; j < 2; ++j) x[8 + j] = wave_shl1(x[4 + j]);           // first two samples of lane + 2
-            if (p.ablate & 1) continue;
+            if FC_ABL(p.ablate, 1) continue;
 #pragma unroll
             for (int m = 0; m < MO; ++m) {
                 const float* wr = p.w + ((size_t)m * p.Cin + c) * K;             // uniform address: scalar loads
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const Cout1Args p) {
             o[j] = acc[m][j] + bm;
             if (out_lane && n0 + j < p.T) { s1v += o[j]; s2v = fmaf(o[j], o[j], s2v); }
         }
-        if ((p.ablate & 2) || !out_lane) continue;
+        if (FC_ABL(p.ablate, 2) || !out_lane) continue;
         float* orow = p.out + (size_t)breal * p.out_sB + (size_t)fo * p.out_sF + (size_t)m * p.out_sM + n0;
         if (n0 + 3 < p.T) *(f32x4u*)orow = (f32x4){o[0], o[1], o[2], o[3]};
         else
@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
         auto load_tile = [&](int stage, int t, f32x4 (&bq)[NQ4]) __attribute__((always_inline)) {
             const float* e0 = frag_ptr(stage, t);
 #pragma unroll
-            for (int q = 0; q < NQ4; ++q) bq[q] = (ablate & 2) ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(e0 + qstep * q);
+            for (int q = 0; q < NQ4; ++q) bq[q] = FC_ABL(ablate, 2) ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(e0 + qstep * q);
         };
         auto do_tile = [&](int t, const f32x4 (&bq)[NQ4]) __attribute__((always_inline)) {
             const int code = code0 + 16 * t + r16;
@@ -1549,7 +1549,7 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
             f32x4 acc[RS];
 #pragma unroll
             for (int s2 = 0; s2 < RS; ++s2) acc[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (!(ablate & 1)) {
+            if (!FC_ABL(ablate, 1)) {
 #pragma unroll
                 for (int q = 0; q < NQ4; ++q)
 #pragma unroll
@@ -1636,7 +1636,7 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
         for (int it = 0; it < NEL; ++it) {
             const int e = tid + 512 * it, r = e / D, d = e - r * D;
             qv[it] = 0.f;
-            if (ROWS * D % 512 == 0 || e < ROWS * D) qv[it] = (ablate & 8) ? 0.001f : cbi[(size_t)sel[r] * D + d];
+            if (ROWS * D % 512 == 0 || e < ROWS * D) qv[it] = FC_ABL(ablate, 8) ? 0.001f : cbi[(size_t)sel[r] * D + d];
         }
 #pragma unroll
         for (int it = 0; it < NEL; ++it) {
@@ -1647,7 +1647,7 @@ __global__ __launch_bounds__(512) void rvq_encode_kernel(const float* __restrict
             if (Q0 && i == 0 && n < N) res = x[(size_t)n * D + d];
             R[r][d] = res - qv[it];
             qreg[it] = qreg[it] + qv[it];
-            if (subq && n < N && !(ablate & 4)) {
+            if (subq && n < N && !FC_ABL(ablate, 4)) {
                 const int bb = n / Tf, t = n - bb * Tf;
                 const int Bn = N / Tf;
                 subq[(((size_t)i * Bn + bb) * D + d) * Tf + t] = qv[it];
@@ -2089,7 +2089,8 @@ struct LstmPersistArgs {
     unsigned* sync;      // 16 counters at [32*i], error flag at [512]; zeroed by the caller before every launch
     unsigned* status;    // host-visible engine status words (kernels.h FC_STATUS_*), or null
     int B, H, T;
-    int ablate;          // FC_ABLATE_LSTM env: 1 no grid barrier (profiling aid), 64 test hook: behave as if the grid barrier had timed out
+    int ablate;          // FC_ABLATE_LSTM in FC_AB_KNOBS builds: 1 no grid barrier (profiling aid, wrong results).  Ignored (FC_ABL) in the shipped library
+    int test_timeout;    // test hook (FC_ABLATE_LSTM=64, the only value the shipped library honours): behave as if the grid barrier had timed out
     int tile_base, tiles;   // first 16-row batch tile of this launch / tiles of the whole call (history slot size, barrier word block)
     int groups;          // independent recurrences in one launch: group j = workgroups [j*H/4, (j+1)*H/4) owns batch rows [16j, 16j+16) with
                          // its own barrier words (H = 512 fills only half of the chip: two batch tiles then advance side by side)
@@ -2242,7 +2243,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
             __syncthreads();
         }
         if (s > T) break;
-        const bool do_sync = !(p.ablate & 1);
+        const bool do_sync = !FC_ABL(p.ablate, 1);
         if (do_sync) lstm_barrier_arrive(sync, blk);
         // ---- barrier shadow: P for the next step's layer-1 timestep t = s - 1 (needs h0(s-1), already visible)
         if (s >= 1) {
@@ -2271,7 +2272,7 @@ __global__ __launch_bounds__(256, 1) void lstm_persist_kernel(const LstmPersistA
     }
     // a barrier that timed out (some workgroup was not resident) must not pass for a result: poison this workgroup's
     // outputs so that the failure is loud downstream (the engine's per-step launch path is the supported fallback)
-    if (__hip_atomic_load(sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || (p.ablate & 64)) {
+    if (__hip_atomic_load(sync + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || p.test_timeout) {
         if (p.status && tid == 0) *(volatile unsigned*)(p.status + FC_STATUS_LSTM_TIMEOUT) = 1u;   // read by the host at its next fc_* call
         for (int i = tid; i < 4 * B * T; i += 256) {
             const int t = i % T, bu = i / T;
@@ -2320,8 +2321,12 @@ hipError_t launch_lstm_persist(const float* w0, const float* w1, const float* bi
     const int tiles = lstm_persist_tiles(B);
     a.w0 = w0; a.w1 = w1; a.bias1 = bias1; a.xproj = xproj; a.hist = state + (size_t)kLstmSyncWords * tiles; a.y = y;
     a.sync = (unsigned*)state; a.status = status; a.B = B; a.H = H; a.T = T; a.groups = groups; a.tile_base = 0; a.tiles = tiles;
-    static const int ablate = getenv("FC_ABLATE_LSTM") ? atoi(getenv("FC_ABLATE_LSTM")) : 0;
-    a.ablate = ablate;
+    // FC_ABLATE_LSTM: the profiling masks are tuning-build knobs (ab_knob); the shipped library honours exactly one value, 64 = the barrier-timeout
+    // TEST hook of tests/test_gpu_parity.py (every other value is ignored: mask 1 removes the grid barrier and gives wrong results)
+    static const int ablate = ab_knob("FC_ABLATE_LSTM", 0);
+    static const int hook = getenv("FC_ABLATE_LSTM") ? atoi(getenv("FC_ABLATE_LSTM")) : 0;
+    a.ablate = ablate & ~64;
+    a.test_timeout = (hook == 64 || (ablate & 64)) ? 1 : 0;
     // H = 1024 fills the chip with ONE batch tile: a second tile (17 .. 32 utterances) is a second launch of the same kernel on its own
     // history columns and barrier words (round 3: 2 x 1.26 ms; the two-tiles-per-step instantiation needed 3.14 ms with the new history
     // layout).  H = 512: two tiles side by side as two groups of 128 workgroups in one launch.

@@ -120,10 +120,13 @@ def test_segmented_mode_against_reference_golden(name):
             seg = wav[..., f * m.arch.segment_stride: f * m.arch.segment_stride + m.arch.segment_length]
             own = m.engine.encode(seg, c["n_q"], want_enc_out=True)
             assert torch.equal(own["codes"], idx)
-            if unexplained.any():
-                keep = torch.from_numpy(np.where(unexplained[None], got, ref_idx))
-                _assert_flips_are_near_ties(sd_["quantizer.rq.model.embed"], o["encoder_out"][f], ref_idx, keep, got_enc=own["enc_out"], max_frames=1)
-            record_report(name, segment=f, engine_frames_differing=np.argwhere((got != ref_idx).any(0)).tolist(),
+            # EVERY differing frame takes the tie proof -- also one where this box's oracle run disagrees with the fixture: such a
+            # frame is a reference self-disagreement, i.e. a near-tie, and the proof (fixture code vs our code under the oracle's encoder
+            # output) must then hold as well; an engine error that happened to land on it would not pass
+            differing = (got != ref_idx).any(0)
+            if differing.any():
+                _assert_flips_are_near_ties(sd_["quantizer.rq.model.embed"], o["encoder_out"][f], ref_idx, got, got_enc=own["enc_out"], max_frames=1)
+            record_report(name, segment=f, unexplained_by_oracle_rerun=int(unexplained.sum()), engine_frames_differing=np.argwhere((got != ref_idx).any(0)).tolist(),
                           oracle_on_this_box_differs_from_fixture=np.argwhere(ref_disagrees).tolist())
             bad_b = (idx.cpu().numpy() != ref_idx).any(0).any(-1)
             tied += [(f, int(b)) for b in np.nonzero(bad_b)[0]]
@@ -861,7 +864,9 @@ def test_freq_codec_against_reference_golden(name):
         print(f"{name}: ill-conditioned STFT fixture: {facts}")
         assert variants, "the ill-conditioned fixture needs its committed reference variants"
         assert facts["first_stage_agreement_with_set"] >= 0.99, facts
-        assert frames_total - frames_equal_some_run <= max(8, 4 * ref_self), facts
+        # the reference's own exact-STFT variant moves `ref_self` frames; the engine may not scatter more than that + 2 frames from the best single
+        # reference run (measured: 6 against ref_self = 7; rounds 4-5 allowed max(8, 4 * ref_self) = 28, which was a tolerance, not a pin)
+        assert frames_total - frames_equal_some_run <= ref_self + 2, facts
         # what follows (decode path) runs from the REFERENCE's codes
         r = dict(r, codes=torch.from_numpy(ref).to(r["codes"].device), quantized=torch.from_numpy(g["quantized"]))
     else:
