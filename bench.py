@@ -116,6 +116,7 @@ def cpu_baseline(utts: int = MICRO_BATCH):
     audio_s = utts * SAMPLES / 16000.0
     return {"value": round(audio_s / med, 3), "unit": "audio-s/s", "cores": best, "kind": "port",
             "physical_cores": cores, "logical_cpus": os.cpu_count(), "torch": torch.__version__,
+            "port_over_reference": port_over_reference(),
             "runs_s": [round(r, 3) for r in runs], "median_s": round(med, 3),
             "probe_audio_s_per_s": {str(k): round(2 * SAMPLES / 16000.0 / v, 2) for k, v in probe.items()},
             "seconds": round(time.perf_counter() - t_all, 1),
@@ -125,13 +126,30 @@ def cpu_baseline(utts: int = MICRO_BATCH):
                       f"2-utterance probe over physical-core / 32 / 16 threads)"}
 
 
-def pmc_traffic(kernel: str):
+def port_over_reference():
+    """The reference's own Speech2Token(device="cpu") cannot travel to the GPU box; the ratio port / reference (audio-s/s of
+    oracle/torch_oracle.py over audio-s/s of the real reference, same 4 x 10 s batch, threads and box) was measured once in the build
+    container by tools/port_over_reference.py and is carried here from the committed record (VERDICT r5 #6b)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_port_over_reference.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {"ratio": d["port_over_reference"], "reference_audio_s_per_s": d["reference_audio_s_per_s"],
+                "port_audio_s_per_s": d["port_audio_s_per_s"], "threads": d["threads"], "utterances": d["utterances"],
+                "where": "build container (the reference does not exist on the GPU box)", "source": os.path.basename(files[-1])}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def pmc_traffic(kernel: str, tag: str = ""):
     """HBM bytes per launch of `kernel` from the committed PMC passes (tools/collect_profiles.sh: FETCH_SIZE and WRITE_SIZE in
     separate rocprofv3 --pmc runs of this same benchmark).  Correction per MI355X_MICROARCH.md: FETCH_SIZE x 2 on gfx950
     (checked here on the 32->32 k=1 convs whose byte count is known: 0.320 GB reported for 0.656 GB read), WRITE_SIZE x 1
     (0.641 GB reported for 0.656 GB written).  None if the committed profile has no entry for this instantiation."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_pmc{tag}.json")))      # tag "_freqcodec": the FreqCodec side's passes
     if not files:
         return None
     try:
@@ -146,10 +164,10 @@ def pmc_traffic(kernel: str):
     return None
 
 
-def pmc_step_traffic():
+def pmc_step_traffic(tag: str = ""):
     """Whole-step HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE over every kernel of the last benchmark step) from the committed PMC passes."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_pmc{tag}.json")))
     try:
         t = json.load(open(files[-1]))["step_total"]
         return {"bytes_per_step": round((t["fetch_gb_x2"] + t["write_gb"]) * 1e9), "source": os.path.basename(files[-1])}
@@ -193,7 +211,7 @@ def laura_step_pmc_traffic():
     return {"bytes_per_step": round(tot / steps), "source": os.path.basename(files[-1])} if steps else None
 
 
-def kernel_rooflines(prof, prof_steps):
+def kernel_rooflines(prof, prof_steps, pmc_tag: str = ""):
     """Per-kernel-class table of a fc_engine_profile pass + the two roofline objects (dominant MFMA-bound conv class against the
     fp32 matrix peak; the HBM-bound thin classes against 8 TB/s)."""
     out = {}
@@ -226,7 +244,7 @@ def kernel_rooflines(prof, prof_steps):
         dom = max(mfma_bound, key=lambda k: k["ms_per_step"])
         conv_ms = sum(k["ms_per_step"] for k in convs)
         conv_fl = sum(p["flops"] for p in prof if p["kernel"].startswith(CONV_CLASSES)) / prof_steps
-        traffic = pmc_traffic(dom["kernel"])
+        traffic = pmc_traffic(dom["kernel"], pmc_tag)
         out["roofline"] = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"],
                            "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(dom["tflops"] / PEAK_F32_TFLOPS, 4),
@@ -246,7 +264,7 @@ def kernel_rooflines(prof, prof_steps):
     top = max(kern, key=lambda k: k["ms_per_step"]) if kern else None
     if top is not None and "roofline" in out and top["kernel"] != out["roofline"]["kernel"] and top["tflops"]:
         out["roofline_conv"] = out["roofline"]
-        ttr = pmc_traffic(top["kernel"])
+        ttr = pmc_traffic(top["kernel"], pmc_tag)
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(top["tflops"] / PEAK_F32_TFLOPS, 4), "traffic": (ttr or {}).get("bytes_per_launch"),
                            "traffic_detail": ttr,
@@ -273,7 +291,7 @@ def kernel_rooflines(prof, prof_steps):
         hdom = max(hbm, key=lambda k: k["ms_per_step"])
         hb_ms = sum(k["ms_per_step"] for k in hbm)
         hb_by = sum(p["bytes"] for p in prof if any(p["kernel"] == k["kernel"] for k in hbm)) / prof_steps
-        htr = pmc_traffic(hdom["kernel"])
+        htr = pmc_traffic(hdom["kernel"], pmc_tag)
         out["roofline_hbm"] = {"bound": "hbm", "kernel": hdom["kernel"], "achieved": hdom["alg_gbs"], "peak": PEAK_HBM_TBS * 1e3,
                                "unit": "GB/s", "frac": hdom["hbm_frac"], "traffic": (htr or {}).get("bytes_per_launch"),
                                "avg_us_per_launch": hdom["avg_us_per_launch"], "launches_per_step": hdom["launches_per_step"],
@@ -362,7 +380,7 @@ def freqcodec_side(config: str = "freqmpgr1", utts: int = 64, micro: int = 32, s
     eng.set_profiling(False)
     work = eng.work(micro, SAMPLES, n_q)
     nmb = utts / micro
-    tab = kernel_rooflines(prof, psteps)
+    tab = kernel_rooflines(prof, psteps, "_freqcodec")
     out = {"workload": f"BASELINE.json configs[3] shape: FreqCodec mag_phase recipe + conv_group_ratio = tr_conv_group_ratio = 1 ({config}), "
                        f"{utts} x 10 s on one GPU in engine calls of {micro}, n_q=32, run_mod=inference",
            "value": round(utts * SAMPLES / 16000.0 / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
@@ -371,6 +389,11 @@ def freqcodec_side(config: str = "freqmpgr1", utts: int = 64, micro: int = 32, s
                           "frac_of_hbm_peak": round(work["total_bytes"] * nmb / dt / 1e12 / PEAK_HBM_TBS, 4)},
            "roofline_hbm": tab.get("roofline_hbm"), "roofline": tab.get("roofline"),
            "kernels": sorted(tab["kernels"], key=lambda k: -k["ms_per_step"])[:12]}
+    ptr = pmc_step_traffic("_freqcodec")          # PMC passes of ONE engine call of `micro` utterances (tools/collect_profiles.sh)
+    if ptr and micro == 32:
+        out["whole_step"]["traffic"] = round(ptr["bytes_per_step"] * nmb)
+        out["whole_step"]["traffic_over_algorithmic"] = round(ptr["bytes_per_step"] / work["total_bytes"], 2)
+        out["whole_step"]["traffic_source"] = ptr["source"]
     del model, eng
     torch.cuda.empty_cache()
     return out

@@ -21,6 +21,12 @@ static inline __host__ __device__ int ceil_div(int a, int b) { return (a + b - 1
 // Ablation masks (ConvArgs::ablate and friends) exist in tuning builds only (FC_BUILD_DEFINES=FC_AB_KNOBS / FC_TIMELINE): in the shipped
 // library FC_ABL() is the constant 0, so no profiling branch sits around a load, a DMA piece or an MFMA block of the hot loops (a run-time
 // condition around a software-pipelined load is exactly what hipcc turns into exposed latency).
+#ifndef FC_ELEM_NSET
+#define FC_ELEM_NSET 1      // ... of the quad element staging of the prologue modes (plain layers always keep two); 2 measured: slower (below)
+#endif
+#ifndef FC_ROW_NSET
+#define FC_ROW_NSET 1       // register sets of the quad row staging (A / B builds: FC_BUILD_DEFINES="FC_ROW_NSET=2 FC_ELEM_NSET=2")
+#endif
 #ifdef FC_AB_KNOBS
 #define FC_ABL(mask_, bits_) ((mask_) & (bits_))
 #else
@@ -393,9 +399,15 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             const unsigned t_slot = 16u * (unsigned)(t_g * p.rowStride + BN + t_j);
             unsigned src_off = 0, eoff[CW], emask = 0, t_off = 0;
             bool ld_edge = false, t_ok = true;
-            bool r_edge = false, r_tok = true; unsigned r_emask = 0;
-            f32x4 v0[NR][4], v1[DUAL ? NR : 1][4];
-            float tv0[4] = {0.f, 0.f, 0.f, 0.f}, tv1[4] = {0.f, 0.f, 0.f, 0.f};
+            // Register sets in flight (FC_ROW_NSET, default 1).  Round 6 measured what the fused-prologue classes wait for
+            // (profiles/r06_prologue_ablation.txt, profiles/r06_two_register_sets.txt): with the prologue ARITHMETIC removed they do not move
+            // (11.51 vs 11.47 ms of conv time per step), with the slab WRITE removed altogether they gain 5 - 17 % (0.51 ms per step in total:
+            // the upper bound of any staging rework), and a second register set (loads of item f + 3 in flight while item f + 2's values wait)
+            // returns nothing on the row-staged classes and loses 4 - 12 % on the element-staged ones (8 spilled registers): 15.04 vs 14.96 ms.
+            constexpr int NSET = FC_ROW_NSET;
+            bool r_edge[NSET] = {}, r_tok[NSET] = {}; unsigned r_emask[NSET] = {};
+            f32x4 v0[NSET][NR][4], v1[NSET][DUAL ? NR : 1][4];
+            float tv0[NSET][4] = {}, tv1[NSET][4] = {};
             int ld_tile = t_begin, ld_chunk = 0, wr_chunk = 0;
             const int hi_lim = p.Tin + p.padR, refl = 2 * (p.Leff - 1);
             auto resolve = [&](int g, bool& ok) __attribute__((always_inline)) {
@@ -425,12 +437,13 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                     t_off = 4u * (unsigned)(4 * (has_tail ? t_g : g0) * p.Tin + src);
                 }
             };
-            auto load_slab = [&]() __attribute__((always_inline)) {
+            auto load_slab = [&](auto set_tag) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_tag)::value;
                 const int tbase = ld_tile * BN - p.padL;
                 if (ld_chunk == 0) setup_tile(tbase);
                 const size_t cbase = (size_t)(ld_chunk * p.CC) * p.Tin;
                 if (++ld_chunk == p.nchunk) { ld_chunk = 0; ++ld_tile; }
-                r_edge = ld_edge; r_emask = emask; r_tok = t_ok;
+                r_edge[S] = ld_edge; r_emask[S] = emask; r_tok[S] = t_ok;
                 if FC_ABL(p.ablate, 4) return;
                 // the chunk's rows through buffer descriptors: scalar base + scalar (round, channel) offset + the lane's 32-bit offset
                 const __amdgpu_buffer_rsrc_t q0 = stage_rsrc(s0b + cbase), q1 = stage_rsrc(s1b + cbase);
@@ -442,15 +455,15 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         for (int s4 = 0; s4 < 4; ++s4) {
                             const int so = r * rd_b + s4 * ch_b;
                             if constexpr (CW == 4) {
-                                v0[r][s4] = buf_ld4(q0, src_off, so);
-                                if (DUAL) v1[r][s4] = buf_ld4(q1, src_off, so);
+                                v0[S][r][s4] = buf_ld4(q0, src_off, so);
+                                if (DUAL) v1[S][r][s4] = buf_ld4(q1, src_off, so);
                             } else if constexpr (CW == 2) {
                                 const f32x2_ld t0 = buf_ld2(q0, src_off, so);
-                                v0[r][s4][0] = t0[0]; v0[r][s4][1] = t0[1];
-                                if (DUAL) { const f32x2_ld t1 = buf_ld2(q1, src_off, so); v1[r][s4][0] = t1[0]; v1[r][s4][1] = t1[1]; }
+                                v0[S][r][s4][0] = t0[0]; v0[S][r][s4][1] = t0[1];
+                                if (DUAL) { const f32x2_ld t1 = buf_ld2(q1, src_off, so); v1[S][r][s4][0] = t1[0]; v1[S][r][s4][1] = t1[1]; }
                             } else {
-                                v0[r][s4][0] = buf_ld1(q0, src_off, so);
-                                if (DUAL) v1[r][s4][0] = buf_ld1(q1, src_off, so);
+                                v0[S][r][s4][0] = buf_ld1(q0, src_off, so);
+                                if (DUAL) v1[S][r][s4][0] = buf_ld1(q1, src_off, so);
                             }
                         }
                 } else {
@@ -460,14 +473,14 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
                             for (int j = 0; j < CW; ++j) {
-                                v0[r][s4][j] = buf_ld1(q0, eoff[j], r * rd_b + s4 * ch_b);
-                                if (DUAL) v1[r][s4][j] = buf_ld1(q1, eoff[j], r * rd_b + s4 * ch_b);
+                                v0[S][r][s4][j] = buf_ld1(q0, eoff[j], r * rd_b + s4 * ch_b);
+                                if (DUAL) v1[S][r][s4][j] = buf_ld1(q1, eoff[j], r * rd_b + s4 * ch_b);
                             }
                 }
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    tv0[s4] = buf_ld1(q0, t_off, s4 * ch_b);
-                    if (DUAL) tv1[s4] = buf_ld1(q1, t_off, s4 * ch_b);
+                    tv0[S][s4] = buf_ld1(q0, t_off, s4 * ch_b);
+                    if (DUAL) tv1[S][s4] = buf_ld1(q1, t_off, s4 * ch_b);
                 }
             };
             auto prologue = [&](float v, float w, float2 a, float2 a1) __attribute__((always_inline)) {
@@ -483,7 +496,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 a[0] = make_float2(lo.x, lo.y); a[1] = make_float2(lo.z, lo.w);
                 a[2] = make_float2(hi4.x, hi4.y); a[3] = make_float2(hi4.z, hi4.w);
             };
-            auto write_slab = [&](char* Xd) __attribute__((always_inline)) {
+            auto write_slab = [&](auto set_tag, char* Xd) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_tag)::value;
                 const int c0 = wr_chunk * p.CC;
                 if (++wr_chunk == p.nchunk) wr_chunk = 0;
                 if (FC_ABL(p.ablate, 512)) return;
@@ -507,8 +521,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                             f32x4 o;
 #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
-                                o[s4] = prologue(v0[r][s4][j], DUAL ? v1[r][s4][j] : 0.f, PLAIN ? ta[s4] : a[r][s4], DUAL ? a1[r][s4] : ta1[s4]);
-                                if (r_edge) o[s4] = ((r_emask >> j) & 1u) ? o[s4] : 0.f;
+                                o[s4] = prologue(v0[S][r][s4][j], DUAL ? v1[S][r][s4][j] : 0.f, PLAIN ? ta[s4] : a[r][s4], DUAL ? a1[r][s4] : ta1[s4]);
+                                if (r_edge[S]) o[s4] = ((r_emask[S] >> j) & 1u) ? o[s4] : 0.f;
                             }
                             *(f32x4*)(Xd + slot0 + r * lds_round + 16 * j) = o;
                         }
@@ -517,33 +531,49 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                     f32x4 o;
 #pragma unroll
                     for (int s4 = 0; s4 < 4; ++s4) {
-                        o[s4] = prologue(tv0[s4], tv1[s4], ta[s4], ta1[s4]);
-                        o[s4] = r_tok ? o[s4] : 0.f;
+                        o[s4] = prologue(tv0[S][s4], tv1[S][s4], ta[s4], ta1[s4]);
+                        o[s4] = r_tok[S] ? o[s4] : 0.f;
                     }
                     *(f32x4*)(Xd + t_slot) = o;
                 }
             };
-            load_slab();
-            write_slab((char*)Xs0);
-            if (nitems > 1) load_slab();
-            __syncthreads();                              // B0
+            using Set0 = std::integral_constant<int, 0>;
+            using Set1 = std::integral_constant<int, NSET == 2 ? 1 : 0>;
             int st_tile = t_begin, st_chunk = 0;
-            for (int f = 0; f < nitems; ++f) {
+            // one pipeline step: item f + 1 (held in register set wr_set) becomes its slab, that set is refilled with item f + 1 + NSET
+            auto step = [&](int f, auto wr_set) __attribute__((always_inline)) {
                 FC_STAMP(1, f, 0);
                 if (STAGING_DMA && f + 1 < nitems && !resident) {
                     const int nc = st_chunk + 1 == p.nchunk ? 0 : st_chunk + 1;
                     dma_weights(wt_tile + (size_t)nc * p.Wbuf, smem + ((f + 1) & 1) * p.Wbuf, p.Wbuf, rtid, p.ablate);
                 }
                 if (f + 1 < nitems) {
-                    write_slab((char*)(Xs0 + ((f + 1) & 1) * XSF));
+                    write_slab(wr_set, (char*)(Xs0 + ((f + 1) & 1) * XSF));
                     FC_STAMP(1, f, 1);
-                    if (f + 2 < nitems) load_slab();
+                    if (f + 1 + NSET < nitems) load_slab(wr_set);
                     FC_STAMP(1, f, 2);
                 }
                 __syncthreads();                          // B(f+1)
                 FC_STAMP(1, f, 3);
                 if (++st_chunk == p.nchunk) { st_chunk = 0; flush_stats(st_tile); ++st_tile; }
                 FC_STAMP(1, f, 4);
+            };
+            load_slab(Set0());
+            write_slab(Set0(), (char*)Xs0);
+            if (NSET == 2) {
+                if (nitems > 1) load_slab(Set1());        // item 1
+                if (nitems > 2) load_slab(Set0());        // item 2
+            } else {
+                if (nitems > 1) load_slab(Set0());
+            }
+            __syncthreads();                              // B0
+            if (NSET == 2) {
+                for (int f = 0; f < nitems; f += 2) {     // item f + 1 lives in set 1, item f + 2 in set 0
+                    step(f, Set1());
+                    if (f + 1 < nitems) step(f + 1, Set0());
+                }
+            } else {
+                for (int f = 0; f < nitems; ++f) step(f, Set0());
             }
             __syncthreads();                              // final (kept symmetric with the matrix role)
             return;
@@ -723,7 +753,8 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             const int totalq = (p.CC >> 2) * p.slabW;
             const float divv = (MODE == 1 && p.div0) ? p.div0[breal] : 1.f;
             unsigned base0[NU], slot[NU], cl32[PLAIN ? 1 : NU];
-            constexpr int NSET = DEEP ? 2 : 1;
+            constexpr bool DEEPQ = DEEP || FC_ELEM_NSET == 2;     // round 6: two register sets for the prologue modes as well (see the row staging above)
+            constexpr int NSET = DEEPQ ? 2 : 1;
             float v0[NSET][NU][4], v1[NSET][DUAL ? NU : 1][4];
             unsigned inmask = 0, vmask[NSET] = {};
 #pragma unroll
@@ -871,7 +902,7 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
                 else write_slab_t(set_tag, Xd, std::false_type(), std::true_type());
             };
             using Set0 = std::integral_constant<int, 0>;
-            using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
+            using Set1 = std::integral_constant<int, DEEPQ ? 1 : 0>;
             int st_tile = t_begin, st_chunk = 0;
             auto step = [&](int f, auto wr_set) __attribute__((always_inline)) {
                 FC_STAMP(1, f, 0);
@@ -892,14 +923,14 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             };
             load_slab(Set0());
             write_slab(Set0(), (char*)Xs0);
-            if (DEEP) {
+            if (DEEPQ) {
                 if (nitems > 1) load_slab(Set1());
                 if (nitems > 2) load_slab(Set0());
             } else {
                 if (nitems > 1) load_slab(Set0());
             }
             __syncthreads();                              // B0
-            if (DEEP) {
+            if (DEEPQ) {
                 for (int f = 0; f < nitems; f += 2) {
                     step(f, Set1());
                     if (f + 1 < nitems) step(f + 1, Set0());

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <vector>
@@ -16,7 +17,9 @@ inline int ab_knob(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 #else
-    (void)name;
+    // a tuning variable set against the shipped library is IGNORED, and says so once (A / B scripts run against the default
+    // build compared identical configurations silently)
+    if (getenv(name)) fprintf(stderr, "funcodec_amd: %s is set but ignored by this build (tuning knobs need FC_BUILD_DEFINES=FC_AB_KNOBS)\n", name);
     return dflt;
 #endif
 }

@@ -22,9 +22,13 @@ def per_kernel(path, counter):
     return acc, n
 
 
-f = glob.glob(os.path.join(out, "pmc_fetch", "*counter_collection.csv"))
-w = glob.glob(os.path.join(out, "pmc_write", "*counter_collection.csv"))
-res = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes, last benchmark step (ds640, 16 x 10 s); "
+# optional second argument: a tag -- "freqcodec" reads pmc_fetch_freqcodec / pmc_write_freqcodec (the same two passes over
+# `bench.py --workload freqcodec_gr1`) and writes hbm_traffic_pmc_freqcodec.json (one step = one 32-utterance engine call)
+tag = ("_" + sys.argv[2]) if len(sys.argv) > 2 else ""
+f = glob.glob(os.path.join(out, "pmc_fetch" + tag, "*counter_collection.csv"))
+w = glob.glob(os.path.join(out, "pmc_write" + tag, "*counter_collection.csv"))
+res = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes, last benchmark step ("
+               + ("FreqCodec gr1, one 32 x 10 s engine call" if tag else "ds640, 16 x 10 s") + "); "
                "raw counter units are KB.  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) "
                "coalesced reads -> fetch_gb_x2 doubles it; dword reads and WRITE_SIZE are uncalibrated there, so both raw and "
                "doubled read figures are given.", "per_kernel": []}
@@ -37,8 +41,8 @@ if f and w:
         tot_f += fa[k]
         tot_w += wa.get(k, 0.0)
     res["step_total"] = {"fetch_gb_raw": tot_f / 1e6, "fetch_gb_x2": 2 * tot_f / 1e6, "write_gb": tot_w / 1e6}
-json.dump(res, open(os.path.join(out, "hbm_traffic_pmc.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, "hbm_traffic_pmc" + tag + ".json"), "w"), indent=1)
 st = glob.glob(os.path.join(out, "rp", "*kernel_stats.csv"))
-if st:
+if st and not tag:
     open(os.path.join(out, "kernel_stats.csv"), "w").write(open(st[0]).read())
 print(json.dumps(res.get("step_total", {})))
