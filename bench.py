@@ -154,8 +154,12 @@ def pmc_traffic(kernel: str, tag: str = ""):
         return None
     try:
         base = kernel.split("<")[0]
+        # the engine's class names carry the leading template arguments only (gconv2d_kernel<4, 2, 3, 3, 1, false>); rocprofv3 prints all of
+        # them (..., false, 2, false>): a class matches the instantiations it is a prefix of
+        stem = kernel[:-1] + "," if kernel.endswith(">") else None
         for k in json.load(open(files[-1]))["per_kernel"]:
-            if (k["kernel"] == kernel or (base == "lstm_persist_kernel" and k["kernel"].startswith(base))) and k["launches"]:
+            if (k["kernel"] == kernel or (stem and k["kernel"].startswith(stem)) or
+                    (base == "lstm_persist_kernel" and k["kernel"].startswith(base))) and k["launches"]:
                 return {"bytes_per_launch": round((2.0 * k["fetch_kb"] + k["write_kb"]) * 1024.0 / k["launches"]),
                         "fetch_x2_gb": round(2.0 * k["fetch_kb"] * 1024.0 / 1e9, 3), "write_gb": round(k["write_kb"] * 1024.0 / 1e9, 3),
                         "launches": k["launches"], "source": os.path.basename(files[-1])}
@@ -380,7 +384,7 @@ def freqcodec_side(config: str = "freqmpgr1", utts: int = 64, micro: int = 32, s
     eng.set_profiling(False)
     work = eng.work(micro, SAMPLES, n_q)
     nmb = utts / micro
-    tab = kernel_rooflines(prof, psteps, "_freqcodec")
+    tab = kernel_rooflines(prof, psteps, "_freqcodec" if config == "freqmpgr1" else "_none")
     out = {"workload": f"BASELINE.json configs[3] shape: FreqCodec mag_phase recipe + conv_group_ratio = tr_conv_group_ratio = 1 ({config}), "
                        f"{utts} x 10 s on one GPU in engine calls of {micro}, n_q=32, run_mod=inference",
            "value": round(utts * SAMPLES / 16000.0 / dt, 1), "unit": "audio-s/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
@@ -389,7 +393,7 @@ def freqcodec_side(config: str = "freqmpgr1", utts: int = 64, micro: int = 32, s
                           "frac_of_hbm_peak": round(work["total_bytes"] * nmb / dt / 1e12 / PEAK_HBM_TBS, 4)},
            "roofline_hbm": tab.get("roofline_hbm"), "roofline": tab.get("roofline"),
            "kernels": sorted(tab["kernels"], key=lambda k: -k["ms_per_step"])[:12]}
-    ptr = pmc_step_traffic("_freqcodec")          # PMC passes of ONE engine call of `micro` utterances (tools/collect_profiles.sh)
+    ptr = pmc_step_traffic("_freqcodec") if config == "freqmpgr1" else None     # PMC passes of ONE engine call of `micro` utterances
     if ptr and micro == 32:
         out["whole_step"]["traffic"] = round(ptr["bytes_per_step"] * nmb)
         out["whole_step"]["traffic_over_algorithmic"] = round(ptr["bytes_per_step"] / work["total_bytes"], 2)
@@ -880,7 +884,11 @@ def main():
                 sec["config_c_shard_b128"] = {"error": f"{type(ex).__name__}: {ex}"}
             del model, eng
             torch.cuda.empty_cache()
-            for key, fn in (("freqcodec_gr1_b64", lambda: freqcodec_side()), ("laura_tts_b8", lambda: laura_side(cpu_sample=not args.no_cpu_baseline))):
+            # freqcodec_gr1rel_b64: the candidate for the RELEASED gr1 architecture (n_filters 8, one LSTM layer: the README's 0.52 M parameters;
+            # DESIGN.md) timed next to the recipe-sized gr1 net; its H = 128 one-layer LSTM runs on the per-step launches
+            for key, fn in (("freqcodec_gr1_b64", lambda: freqcodec_side()),
+                            ("freqcodec_gr1rel_b64", lambda: freqcodec_side(config="freqmpgr1rel", steps=3, warmup=1)),
+                            ("laura_tts_b8", lambda: laura_side(cpu_sample=not args.no_cpu_baseline))):
                 try:
                     sec[key] = fn()
                 except Exception as ex:      # a side measurement must never take the contract line down with it

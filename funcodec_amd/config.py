@@ -444,6 +444,8 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
     name = name[:-3] if seg else name
     angle = name.endswith("ang")                      # freqcodec_mag_angle_16k_n32_600k_step.yaml: codec_domain [mag_angle, mag_angle], 2 channels
     name = name[:-3] if angle else name
+    rel = name.endswith("rel")                        # "freqmpgr1rel": the one net of a hyper-parameter search that reproduces the README's
+    name = name[:-3] if rel else name                 # 0.52 M parameters for the released gr1 model: n_filters 8, ONE LSTM layer
     gr = -1
     if "gr" in name:                                  # e.g. "freqmpgr1", "tinyfreqgr2": conv_group_ratio = tr_conv_group_ratio = N
         name, grs = name.split("gr")
@@ -466,6 +468,9 @@ def freq_recipe_config(name: str) -> Dict[str, Any]:
             dec.update(n_filters=8)
         enc.update(conv_group_ratio=gr)
         dec.update(conv_group_ratio=gr, tr_conv_group_ratio=gr)
+    if rel:
+        enc.update(n_filters=8, seq_model="lstm", seq_layer_num=1)
+        dec.update(n_filters=8, seq_model="lstm", seq_layer_num=1)
     qc = {"codebook_size": 64 if tiny else 1024, "num_quantizers": 4 if tiny else 32, "ema_decay": 0.99,
           "kmeans_init": True, "sampling_rate": 16000, "quantize_dropout": True,
           "rand_num_quant": [1, 2, 4], "use_ddp": True, "encoder_hop_length": 640 if ds640 else 320}

@@ -146,6 +146,10 @@ FREQ_CASES = [
     # length against the 16-byte pieces of the direct kernels)
     ("freqmpgr1_b1_t16000", "freqmpgr1", 0, "noise", 140, 1, 16000),
     ("freqmpgr1_b2_t48000", "freqmpgr1", 0, "tones", 141, 2, 48000),
+    # "freqmpgr1rel": n_filters 8 + ONE LSTM layer (H = 128) + conv_group_ratio = tr_conv_group_ratio = 1 -- the configuration of a search over
+    # the reference's own SEANetEncoder2d / SEANetDecoder2d classes that reproduces the README's 0.52 M parameters of the released gr1 model
+    # (517 937; README.md:28); its config.yaml is not in the reference tree, so this is a candidate, not the released net
+    ("freqmpgr1rel_b2_t16000", "freqmpgr1rel", 0, "tones", 150, 2, 16000),
 ]
 # segmented overlap-add cases: (name, config, weight seed, audio kind, audio seed, B, T)
 SEG_CASES = [
