@@ -243,6 +243,17 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
     int G = target_wgs / (mtiles * c.B);
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
+    if (!target_env) {
+        // One resident wave of workgroups walks max ceil(ntiles / G) tiles each; when that split is uneven (decoder.model.6.convtr of the
+        // ds640 recipe: 16 column tiles over 3 workgroups per (utterance, M tile) = 6 / 5 / 5, i.e. 6 tile times for 5.33 tiles of work), MORE and
+        // shorter ranges dispatched over several rounds balance better: rounds x (tiles per workgroup + ~6 % start-up per workgroup).  Taken
+        // only when the model predicts >= 5 % (round 6; results do not depend on G: FC_TARGET_WGS test).
+        auto cost = [&](int g) { return (long long)ceil_div(g * mtiles * c.B, target_wgs) * (100ll * ceil_div(ntiles, g) + 6); };
+        int best = G;
+        for (int g = G + 1; g <= ntiles; ++g)
+            if (cost(g) < cost(best)) best = g;
+        if (cost(best) * 100 <= cost(G) * 95) G = best;
+    }
     dim3 grid(G, mtiles, c.B);
     if (a.quad) {
         if (c.BM == 128 && c.BN == 128) return launch_conv_tile_q<128, 128, 2, 2>(c, a, grid, lds, st);
