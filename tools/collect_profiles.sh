@@ -18,10 +18,15 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o out --output-form
 python $R/tools/trace_summary.py $(ls $OUT/rp/*kernel_trace.csv | head -1) > $OUT/last_step_per_launch.txt 2>&1
 python $R/tools/profile_post.py $OUT
 # side measurements of the next scope rows on their own (BASELINE.json configs[3] shape with grouped convs, configs[4])
-python $R/bench.py --workload freqcodec_gr1 --steps 5 --warmup 2 > $OUT/bench_freqcodec_gr1.json 2> $OUT/bench_freqcodec_gr1.err
+python $R/bench.py --workload freqcodec_gr1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_freqcodec_gr1.json 2> $OUT/bench_freqcodec_gr1.err
 rocprofv3 --kernel-trace --stats -d $OUT/rpf -o out --output-format csv -- python $R/bench.py --workload freqcodec_gr1 --steps 2 --warmup 1 > /dev/null 2> $OUT/rpf.err
 cp $(ls $OUT/rpf/*kernel_stats.csv | head -1) $OUT/kernel_stats_freqcodec_gr1.csv
 rm -rf $OUT/rpf
+# FreqCodec HBM traffic (round 6): the same two separate PMC passes over the gr1 side measurement -> hbm_traffic_pmc_freqcodec.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch_freqcodec -o out --output-format csv -- python $R/bench.py --workload freqcodec_gr1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch_freqcodec.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write_freqcodec -o out --output-format csv -- python $R/bench.py --workload freqcodec_gr1 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write_freqcodec.err
+python $R/tools/profile_post.py $OUT freqcodec
+rm -rf $OUT/pmc_fetch_freqcodec $OUT/pmc_write_freqcodec
 python $R/bench.py --workload laura --steps 5 --warmup 2 > $OUT/bench_laura.json 2> $OUT/bench_laura.err
 rocprofv3 --kernel-trace --stats -d $OUT/rpl -o out --output-format csv -- python $R/bench.py --workload laura --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/rpl.err
 cp $(ls $OUT/rpl/*kernel_stats.csv | head -1) $OUT/kernel_stats_laura.csv

@@ -10,8 +10,14 @@ def main(path, nsteps):
     lo = starts[-1]
     hi = len(rows)
     out = []
-    for r in rows[lo:hi]:
+    gaps = []                                          # (gap before this launch in us, kernel, previous kernel)
+    prev_end, prev_nm = None, ""
+    for r in sorted(rows[lo:hi], key=lambda r: int(r["Start_Timestamp"])):
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        if prev_end is not None:
+            gaps.append(((int(r["Start_Timestamp"]) - prev_end) / 1e3, r["Kernel_Name"].replace("void fc::", "").split("(")[0][:40], prev_nm))
+        prev_end = max(prev_end or 0, int(r["End_Timestamp"]))
+        prev_nm = r["Kernel_Name"].replace("void fc::", "").split("(")[0][:40]
         nm = r["Kernel_Name"].replace("void fc::", "").replace("fc::", "").split("(")[0]
         g = (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
         if out and out[-1][0] == nm and "lstm" in nm:
@@ -28,6 +34,11 @@ def main(path, nsteps):
         if "gn_finalize" in o[0]:
             continue
         print(f"{o[0][:44]:44s} {o[1]:9.1f} us grid={o[2]} n={o[3]} lds={o[4]} vgpr={o[5]}+{o[6]}")
+    pos = [g for g in gaps if g[0] > 0]
+    print("--- gaps between consecutive launches: n=%d sum=%.1f us, median %.2f us, > 10 us: %d" % (
+        len(pos), sum(g[0] for g in pos), sorted(g[0] for g in pos)[len(pos) // 2] if pos else 0.0, sum(1 for g in pos if g[0] > 10)))
+    for g in sorted(gaps, key=lambda g: -g[0])[:8]:
+        print("   %7.1f us before %-40s (after %s)" % g)
     print("--- totals")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
         print(f"{k[:60]:60s} {v:10.1f} us")
