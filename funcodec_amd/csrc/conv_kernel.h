@@ -385,7 +385,12 @@ __global__ __launch_bounds__(512, 4) void conv_mfma_kernel(const ConvArgs p) {
             // ---------------------------------------------------------------------------------------------
             typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
             typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
-            constexpr int CW = NU == 12 ? 2 : (NU == 11 ? 1 : 4), NR = NU >= 11 ? 1 : NU;
+            // NU 14 / 13 (round 6): ONE full round of 256 (4 channels x 4 columns) units re-cut as 4 rounds of 1-column units / 2 rounds of 2-column
+            // units.  Why: a `ds_write_b128` is serviced in groups of 8 consecutive lanes over 32 banks (MI355X_MICROARCH.md), and with 4 columns
+            // per lane the lanes of a group are 64 bytes apart -- two distinct 16-byte slots for eight lanes, a 4-way bank conflict on every slab
+            // store (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.35 - 0.38 on the k = 1 row-staged classes, 0.00 on the DMA-staged ones,
+            // profiles/r06_pmc_step.txt).  One column per lane makes the stores conflict-free at the price of dword instead of 16-byte loads.
+            constexpr int CW = (NU == 12 || NU == 13) ? 2 : ((NU == 11 || NU == 14) ? 1 : 4), NR = NU == 14 ? 4 : (NU == 13 ? 2 : (NU >= 11 ? 1 : NU));
             constexpr int LPR = BN / CW, GPR = 256 / LPR;
             const int nq4 = p.CC >> 2;
             const bool has_main = rtid / LPR < nq4;        // wave-uniform (LPR >= 32); false only when the chunk has < 256 units (NR == 1)
@@ -1445,6 +1450,9 @@ static int conv_nuq_for(int totalq, int mode) {
 // quad layout, row staging: rounds of 256 (4 channels x 4 columns) units per item (1 also covers chunks with fewer units than one round)
 static int conv_rowq_rounds(int CC, int BN) {
     const int units = (CC / 4) * (BN / 4);
+    static const int cw = ab_knob("FC_ROW_CW", 4);        // A / B: 1 / 2 = narrower units for chunks of exactly one round (see NU 14 / 13 in the kernel)
+    if (units == 256 && cw == 1) return 14;
+    if (units == 256 && cw == 2) return 13;
     if (units * 4 <= 256) return 11;          // units of 4 channels x 1 column
     if (units * 2 <= 256) return 12;          // ... x 2 columns: all four staging waves share the chunk
     return units <= 256 ? 1 : units / 256;
@@ -1492,6 +1500,10 @@ static hipError_t launch_conv_mq(const ConvArgs& a, dim3 grid, size_t lds, hipSt
         if (nr == 1) return launch_conv_k<BM, BN, WM, WN, MODE, 1, true, true>(a, grid, lds, st);
         if (nr == 12) return launch_conv_k<BM, BN, WM, WN, MODE, 12, true, true>(a, grid, lds, st);
         if (nr == 11) return launch_conv_k<BM, BN, WM, WN, MODE, 11, true, true>(a, grid, lds, st);
+#ifdef FC_AB_KNOBS
+        if (nr == 13) return launch_conv_k<BM, BN, WM, WN, MODE, 13, true, true>(a, grid, lds, st);
+        if (nr == 14) return launch_conv_k<BM, BN, WM, WN, MODE, 14, true, true>(a, grid, lds, st);
+#endif
         if constexpr (MODE < 3) {
             if (nr == 2) return launch_conv_k<BM, BN, WM, WN, MODE, 2, true, true>(a, grid, lds, st);
         }
