@@ -27,6 +27,12 @@ def gather_codes(codes: torch.Tensor, dist=None, shard_sizes=None) -> torch.Tens
     host synchronisation of the call, so the gather stays asynchronous on the stream."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return codes
+    return _gather_ranks(codes, dist, shard_sizes)
+
+
+def _gather_ranks(codes: torch.Tensor, dist, shard_sizes=None) -> torch.Tensor:
+    """The collective itself, for any world size >= 1 (a 1-rank communicator takes exactly the N-rank code path: this is what the
+    hardware smoke test on the 1-GPU boxes runs, tests/test_multigpu_gpu.py)."""
     world = dist.get_world_size()
     n_q, b_local, tf = codes.shape
     if shard_sizes is not None:
