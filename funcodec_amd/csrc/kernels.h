@@ -85,7 +85,7 @@ size_t conv_lds_bytes(const ConvLaunch& c);
 int conv_wbuf_floats(int k, int CC, int BM);                // floats per packed weight chunk (4 KiB multiple)
 bool conv_quad(int CC);                                     // this chunking uses the quad-k operand layout (kernels.hip)
 size_t conv_pack_index(int k, int CC, int BM, int kk, int cl, int mm);   // float index of W[row mm][chunk channel cl][tap kk] in a chunk image
-size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row);
+size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row, int dma_rounds = -1);
 bool conv_row_ok(int k, int stride, int dil, int CC, int BM, int BN, int Cin, bool dual);   // row staging usable with this chunking?
 bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dual);
 int conv_wgs_per_cu(int BM);

@@ -84,8 +84,9 @@ static ConvArgs make_args(const ConvLaunch& c) {
     // slot of lanes without an element)
     a.xsf = c.row ? c.CC * a.rowStride + 4 : ceil_div(c.CC * a.rowStride, 256) * 256 + 4;
     a.xq_Tp = c.xq_Tp;
-    if (conv_quad(c.CC) && !c.s1.ptr && !c.s0.aff && !c.s0.div && !c.elu)
-        a.xsf = ceil_div(c.CC * a.rowStride, 1024) * 1024 + 4;      // plain quad layers: whole 256-piece DMA rounds (conv_lds_bytes_for, ntab = 0)
+    if (conv_quad(c.CC) && c.xq_Tp > 0)
+        a.xsf = ceil_div(c.CC * a.rowStride, 1024) * 1024 + 4;      // DMA-staged slabs (MODE 5): whole 256-piece rounds.  Only there: a
+                                                                    // register-staged plain launch must not use more LDS than its layer was budgeted
     a.magic_slabW = (unsigned)(0x100000000ull / (unsigned long long)a.slabW) + 1u;
     a.koff = c.koff;
     a.koff_n = conv_koff_len(c.k, c.CC);
@@ -169,12 +170,14 @@ bool conv_row_ok(int k, int stride, int dil, int CC, int BM, int BN, int Cin, bo
     return CC * (k - 1) * dil <= 256 && (size_t)conv_wbuf_floats(k, CC, BM) <= 8192;
 }
 
-size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row) {
+size_t conv_lds_bytes_for(int k, int stride, int dil, int CC, int BM, int BN, int Cin, int ntab, int row, int dma_rounds) {
     const int slabW = (BN - 1) * stride + (k - 1) * dil + 1;
     const int rowStride = row ? ((slabW + 3) & ~3) : ceil_div(slabW, stride) * stride;
     const int img = CC * rowStride;
     int xs = row ? img + 4 : ceil_div(img, 256) * 256 + 4;   // make_args(): xsf
-    if (conv_quad(CC) && ntab == 0) xs = ceil_div(img, 1024) * 1024 + 4;
+    // dma_rounds: the slab buffer holds whole DMA rounds (MODE 5).  -1 (the planner's budget): assumed for every layer without tables, so
+    // that the budget is an upper bound of what any launch of the layer takes
+    if (conv_quad(CC) && (dma_rounds > 0 || (dma_rounds < 0 && ntab == 0))) xs = ceil_div(img, 1024) * 1024 + 4;
     const size_t koff_bytes = (size_t)conv_koff_len(k, CC) * sizeof(int);
     return (size_t)(2 * conv_wbuf_floats(k, CC, BM) + 2 * xs) * sizeof(float) + (size_t)((Cin + 1) & ~1) * 8 * ntab + koff_bytes +
            (size_t)BM * sizeof(float) + 2 * 256 * 8;
@@ -193,7 +196,7 @@ bool conv_slab_fits(int k, int stride, int dil, int CC, int BN, int BM, bool dua
 
 size_t conv_lds_bytes(const ConvLaunch& c) {
     const int ntab = c.s1.ptr ? 2 : ((c.s0.aff || c.s0.div || c.elu) ? 1 : 0);
-    return conv_lds_bytes_for(c.k, c.stride, c.dil, c.CC, c.BM, c.BN, c.Cin, ntab, c.row);
+    return conv_lds_bytes_for(c.k, c.stride, c.dil, c.CC, c.BM, c.BN, c.Cin, ntab, c.row, c.xq_Tp > 0 ? 1 : 0);
 }
 
 void conv_variant(const ConvLaunch& c, int* mode, int* nu, int* row) {
