@@ -1461,6 +1461,10 @@ static int conv_rowq_rounds(int CC, int BN) {
 template <int BM, int BN, int WM, int WN, int MODE>
 static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t lds, hipStream_t st) {
     if (a.row) {   // row staging: NU = rounds per item (2 / 4 / 8 specialised, 1 = run-time count)
+#ifdef FC_AB_KNOBS
+        // Round-4 operand layout with row staging: reachable only with FC_QUAD=0 (a tuning-build knob).  In the shipped library every chunk
+        // of >= 4 channels takes the quad layout and a 2-channel chunk never qualifies for row staging (conv_row_ok), so these ~80
+        // instantiations are compiled into tuning builds only (round 6: -20 % library size and build time).
         const int nr = a.CC / (4 * (64 / (BN / 4)));
         if (nr == 2) return launch_conv_k<BM, BN, WM, WN, MODE, 2, true>(a, grid, lds, st);
         if (nr == 4) return launch_conv_k<BM, BN, WM, WN, MODE, 4, true>(a, grid, lds, st);
@@ -1468,6 +1472,9 @@ static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t 
             if (nr == 8) return launch_conv_k<BM, BN, WM, WN, MODE, 8, true>(a, grid, lds, st);
         }
         return launch_conv_k<BM, BN, WM, WN, MODE, 1, true>(a, grid, lds, st);
+#else
+        return hipErrorInvalidValue;
+#endif
     }
     const int nu = conv_nu_for(total, MODE);
     if (nu == 5) return launch_conv_k<BM, BN, WM, WN, MODE, 5, false>(a, grid, lds, st);
