@@ -251,9 +251,13 @@ hipError_t launch_conv(const ConvLaunch& c, hipStream_t st) {
         // ds640 recipe: 16 column tiles over 3 workgroups per (utterance, M tile) = 6 / 5 / 5, i.e. 6 tile times for 5.33 tiles of work), MORE and
         // shorter ranges dispatched over several rounds balance better: rounds x (tiles per workgroup + ~6 % start-up per workgroup).  Taken
         // only when the model predicts >= 5 % (round 6; results do not depend on G: FC_TARGET_WGS test).
-        auto cost = [&](int g) { return (long long)ceil_div(g * mtiles * c.B, target_wgs) * (100ll * ceil_div(ntiles, g) + 6); };
+        auto cost = [&](int g) {
+            const long long wgs = (long long)g * mtiles * c.B;
+            return ((wgs + target_wgs - 1) / target_wgs) * (100ll * ceil_div(ntiles, g) + 6);
+        };
         int best = G;
-        for (int g = G + 1; g <= ntiles; ++g)
+        const int g_hi = ntiles < 8 * G + 16 ? ntiles : 8 * G + 16;      // a bounded host-side search: the candidates that matter are small multiples
+        for (int g = G + 1; g <= g_hi; ++g)
             if (cost(g) < cost(best)) best = g;
         if (cost(best) * 100 <= cost(G) * 95) G = best;
     }
