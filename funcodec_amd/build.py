@@ -19,7 +19,11 @@ HEADERS = ["kernels.h", "conv_kernel.h", "laura_kernels.h", os.path.join("..", "
 
 
 def sources():
-    return ["kernels.hip", "engine.hip", "freq_kernels.hip", "laura.hip", "laura_kernels.hip", "laura_persist.hip"] + sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "conv_tile*_*.hip")))
+    # longest translation units first (the pool starts them in this order): the quad-layout tile units, then the rest
+    tiles = sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "conv_tile*_*.hip")))
+    heavy = [t for t in tiles if t.startswith("conv_tileq_") and "_m" not in t] + [t for t in tiles if t.endswith("_m01.hip")]
+    rest = [t for t in tiles if t not in heavy]
+    return heavy + ["kernels.hip", "laura_persist.hip", "laura_kernels.hip", "freq_kernels.hip", "engine.hip", "laura.hip"] + rest
 
 
 def _hipcc() -> str:

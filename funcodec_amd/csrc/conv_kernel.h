@@ -1489,9 +1489,11 @@ static hipError_t launch_conv_m(const ConvArgs& a, int total, dim3 grid, size_t 
     return hipErrorInvalidValue;
 }
 
-// quad-layout instantiations (their own translation units: conv_tileq_*.hip)
+// quad-layout instantiations (their own translation units: conv_tileq_*.hip).  Round 6: the 40 instantiations of a tile shape are spread over
+// THREE translation units by prologue mode (conv_tileq_<tile>.hip: the launcher + modes 5, 3, 4; _m01.hip: modes 0, 1; _m2.hip: mode 2) --
+// the 128 x 128 unit alone was 95 s of a 156 s cold build.  FC_TIMELINE builds keep one unit per tile (the stamps live in a per-unit symbol).
 template <int BM, int BN, int WM, int WN, int MODE>
-static hipError_t launch_conv_mq(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+hipError_t launch_conv_mq(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     if constexpr (MODE == 5) {      // DMA-staged slab: NU = 16-byte pieces per lane of a staging wave (256 per round)
         const int nj = ((a.CC / 4) * a.rowStride + 255) / 256;
         if (nj == 1) return launch_conv_k<BM, BN, WM, WN, 5, 1, false, true>(a, grid, lds, st);
@@ -1526,6 +1528,14 @@ static hipError_t launch_conv_mq(const ConvArgs& a, dim3 grid, size_t lds, hipSt
     return hipErrorInvalidValue;
     }
 }
+
+#ifndef FC_TIMELINE
+#define FC_CONVQ_ELSEWHERE(BM, BN, WM, WN, MODE) extern template hipError_t launch_conv_mq<BM, BN, WM, WN, MODE>(const ConvArgs&, dim3, size_t, hipStream_t);
+#define FC_CONVQ_HERE(BM, BN, WM, WN, MODE) template hipError_t launch_conv_mq<BM, BN, WM, WN, MODE>(const ConvArgs&, dim3, size_t, hipStream_t);
+#else
+#define FC_CONVQ_ELSEWHERE(BM, BN, WM, WN, MODE)
+#define FC_CONVQ_HERE(BM, BN, WM, WN, MODE)
+#endif
 
 // one explicit instantiation per tile shape, each in its own translation unit (conv_tile_*.hip) so that they compile in parallel
 template <int BM, int BN, int WM, int WN>

@@ -2,6 +2,10 @@
 #include "conv_kernel.h"
 
 namespace fc {
+// prologue modes 0, 1 (conv_tileq_128x128_m01.hip) and 2 (_m2.hip) are instantiated in their own units; 5, 3, 4 here
+FC_CONVQ_ELSEWHERE(128, 128, 2, 2, 0)
+FC_CONVQ_ELSEWHERE(128, 128, 2, 2, 1)
+FC_CONVQ_ELSEWHERE(128, 128, 2, 2, 2)
 template hipError_t launch_conv_tile_q<128, 128, 2, 2>(const ConvLaunch&, const ConvArgs&, dim3, size_t, hipStream_t);
 
 // copy of the timeline stamps of a profiling build (zeros otherwise): [role][item][slot]

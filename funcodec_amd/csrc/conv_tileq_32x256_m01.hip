@@ -1,0 +1,7 @@
+// Quad-layout instantiations of the 32 x 256 tile, prologue modes 0 (plain) and 1 (affine): see conv_kernel.h launch_conv_mq.
+#include "conv_kernel.h"
+
+namespace fc {
+FC_CONVQ_HERE(32, 256, 1, 4, 0)
+FC_CONVQ_HERE(32, 256, 1, 4, 1)
+}  // namespace fc

@@ -1,0 +1,6 @@
+// Quad-layout instantiations of the 64 x 256 tile, prologue mode 2 (affine + ELU): see conv_kernel.h launch_conv_mq.
+#include "conv_kernel.h"
+
+namespace fc {
+FC_CONVQ_HERE(64, 256, 1, 4, 2)
+}  // namespace fc
