@@ -348,7 +348,7 @@ def main():
             ref_shim.install_torchaudio_transforms()
             import yaml
             from freq_oracle import FreqOracle
-            from freq_synth import freq_recipe_config, make_freq_state_dict
+            from funcodec_amd.config import freq_recipe_config; from funcodec_amd.synth import make_freq_state_dict
             from funcodec.bin.codec_inference import Speech2Token
             cfg = freq_recipe_config(cfg_name)
             sd = make_freq_state_dict(cfg, wseed)
@@ -459,7 +459,7 @@ def main():
             ref_shim.install_torchaudio_transforms()
             import torchaudio
             import yaml
-            from freq_synth import freq_recipe_config, make_freq_state_dict
+            from funcodec_amd.config import freq_recipe_config; from funcodec_amd.synth import make_freq_state_dict
             from funcodec.bin.codec_inference import Speech2Token
             name, cfg_name, wseed, akind, aseed, B, T = next(c for c in FREQ_CASES if c[0] == base)
             cfg = freq_recipe_config(cfg_name)

@@ -46,8 +46,8 @@ def oracle_for(cfg_name, seed, decay=1.0):
 
 @functools.lru_cache(maxsize=4)
 def freq_state_for(cfg_name, seed):
-    """FreqCodec cases: recipe config, ArchSpec and the seeded 2-D checkpoint (oracle/freq_synth.py)."""
-    from freq_synth import freq_recipe_config, make_freq_state_dict
+    """FreqCodec cases: recipe config, ArchSpec and the seeded 2-D checkpoint (funcodec_amd/synth.py)."""
+    from funcodec_amd.config import freq_recipe_config; from funcodec_amd.synth import make_freq_state_dict
     cfg = freq_recipe_config(cfg_name)
     return cfg, arch_from_config(cfg), make_freq_state_dict(cfg, seed)
 

@@ -50,7 +50,7 @@ def test_freq_codec_checkpoint_contract_matches_reference_keys():
     """FreqCodec (2-D SEANet): Conv2d weights [out, in, k_frequency, k_time], same key scheme."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(GOLD), "..", "oracle"))
-    from freq_synth import freq_recipe_config
+    from funcodec_amd.config import freq_recipe_config
     arch = arch_from_config(freq_recipe_config("freqmp"))
     ref = json.load(open(os.path.join(GOLD, "state_dict_keys_freqmp.json")))
     want = expected_tensors(arch)

@@ -59,7 +59,7 @@ def test_freq_oracle_matches_reference_golden(name):
     """FreqCodec (STFT-domain 2-D SEANet): the restatement oracle/freq_oracle.py against the real reference's
     outputs (the engine is held to the same fixtures in tests/test_gpu_parity.py)."""
     from freq_oracle import FreqOracle
-    from freq_synth import freq_recipe_config, make_freq_state_dict
+    from funcodec_amd.config import freq_recipe_config; from funcodec_amd.synth import make_freq_state_dict
     c = MAN["cases"][name]
     cfg = freq_recipe_config(c["config"])
     orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, c["weight_seed"]).items()})
@@ -93,7 +93,7 @@ def test_freq_oracle_matches_reference_golden(name):
 def test_freq_oracle_segmented_mode_matches_reference_golden(name):
     """FreqCodec with model_conf.segment_dur set (codec_freq.py:303-328,390-404): per-frame codec + triangle overlap-add."""
     from freq_oracle import FreqOracle
-    from freq_synth import freq_recipe_config, make_freq_state_dict
+    from funcodec_amd.config import freq_recipe_config; from funcodec_amd.synth import make_freq_state_dict
     c = MAN["cases"][name]
     cfg = freq_recipe_config(c["config"])
     orc = FreqOracle(cfg, {k: torch.from_numpy(v) for k, v in make_freq_state_dict(cfg, c["weight_seed"]).items()})

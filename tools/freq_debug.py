@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 from helpers import manifest, golden, audio, rms, index_report
 from freq_oracle import FreqOracle
-from freq_synth import freq_recipe_config, make_freq_state_dict
+from funcodec_amd.config import freq_recipe_config; from funcodec_amd.synth import make_freq_state_dict
 from funcodec_amd.config import arch_from_config
 from funcodec_amd.model import EncodecMI355X
 
