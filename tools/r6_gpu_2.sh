@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: FC_ROW_NSET / FC_ELEM_NSET are BUILD defines now (the nset1 library of this script = the default build; "default" here was FC_ROW_NSET=2 FC_ELEM_NSET=2).
 # round 6, call 2: two register sets in the quad staging paths (default build) against the one-set form (libfc_nset1.so): parity subset on the
 # default build, per-class tables and the headline bench of both in the same call; FreqCodec PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs)
 set -u

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the kernels these switches select (FC_LSTM_ROLES / FC_LSTM_VARIANT / FC_LSTM_ASLEEP ...) are archived, not compiled: tools/experiments/lstm_two_roles.hip.txt
+# (drop them back into csrc/kernels.hip with their launch wiring to re-run); kept as the record of how profiles/r06_lstm_two_role.txt was produced.
 # round 6, call 3: the two-role persistent LSTM (default) against the single-role kernel (FC_LSTM_ROLES=0) -- parity first, then the recurrence
 # alone at the benchmark shape (B = 16, H = 1024, T = 250) and H = 512 (FreqCodec), then the headline bench of both in the same call
 set -u

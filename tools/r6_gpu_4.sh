@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the kernels these switches select (FC_LSTM_ROLES / FC_LSTM_VARIANT / FC_LSTM_ASLEEP ...) are archived, not compiled: tools/experiments/lstm_two_roles.hip.txt
+# (drop them back into csrc/kernels.hip with their launch wiring to re-run); kept as the record of how profiles/r06_lstm_two_role.txt was produced.
 # round 6, call 4: two-role LSTM, sleep of chain A's gate wave between arrival and first poll (FC_LSTM_ASLEEP, units of 8 x 64 cycles; AB build)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}

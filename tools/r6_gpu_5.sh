@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the kernels these switches select (FC_LSTM_ROLES / FC_LSTM_VARIANT / FC_LSTM_ASLEEP ...) are archived, not compiled: tools/experiments/lstm_two_roles.hip.txt
+# (drop them back into csrc/kernels.hip with their launch wiring to re-run); kept as the record of how profiles/r06_lstm_two_role.txt was produced.
 # round 6, call 5: two-role LSTM variants (AB build): P in chain B (variant 0) vs P in chain A through an LDS ring (variant 1), sleeps and poll gaps
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
