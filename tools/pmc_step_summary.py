@@ -6,7 +6,8 @@ cycles summed over SIMDs, GRBM_GUI_ACTIVE is summed over the 8 XCDs.  Columns:
   stall%  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   (issue stalls: MFMA read-after-write / pipe busy);  of which LDS-issue stall: SQ_WAIT_INST_LDS
   act%    SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES (cycles in which a wave issues something)
   ldsconf SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra LDS cycles over all LDS-array cycles)
-  valu/mfma, lds/mfma  instruction ratios (SQ_INSTS_VALU excludes MFMA)"""
+  valu/mfma, lds/mfma  instruction ratios (SQ_INSTS_VALU excludes MFMA)
+  GHz     GRBM_GUI_ACTIVE / 8 / kernel time: the shader clock the chip sustained inside the class (the 157.3 TFLOP/s roof assumes 2.4)"""
 import csv
 import glob
 import os
@@ -40,18 +41,19 @@ def main():
     a, na, dur = load(os.path.join(root, "a"))
     b, nb, _ = load(os.path.join(root, "b"))
     print(__doc__)
-    print("%-56s %3s %8s %6s %7s %6s %6s %5s %7s %9s %8s" % ("kernel class (last step)", "n", "us/launch", "mfma%", "parked%", "stall%", "ldsst%", "act%", "ldsconf", "valu/mfma", "lds/mfma"))
+    print("%-56s %3s %8s %6s %7s %6s %6s %5s %7s %9s %8s %5s" % ("kernel class (last step)", "n", "us/launch", "mfma%", "parked%", "stall%", "ldsst%", "act%", "ldsconf", "valu/mfma", "lds/mfma", "GHz"))
     for k in sorted(a, key=lambda k: -dur[k]):
         c, d = a[k], b.get(k, {})
         wave = c.get("SQ_WAVE_CYCLES", 0.0) or 1.0
         kc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 or 1.0
         mf = d.get("SQ_INSTS_MFMA", 0.0)
-        print("%-56s %3d %8.1f %6.1f %7.1f %6.1f %6.1f %5.1f %7.3f %9s %8s" % (
+        print("%-56s %3d %8.1f %6.1f %7.1f %6.1f %6.1f %5.1f %7.3f %9s %8s %5.2f" % (
             k[:56], na[k], dur[k] / na[k], 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * kc),
             100.0 * c.get("SQ_WAIT_ANY", 0.0) / wave, 100.0 * c.get("SQ_WAIT_INST_ANY", 0.0) / wave, 100.0 * c.get("SQ_WAIT_INST_LDS", 0.0) / wave,
             100.0 * c.get("SQ_ACTIVE_INST_ANY", 0.0) / wave,
             d.get("SQ_LDS_BANK_CONFLICT", 0.0) / (d.get("SQ_LDS_IDX_ACTIVE", 0.0) or 1.0),
-            ("%.2f" % (d.get("SQ_INSTS_VALU", 0.0) / mf)) if mf else "-", ("%.2f" % (d.get("SQ_INSTS_LDS", 0.0) / mf)) if mf else "-"))
+            ("%.2f" % (d.get("SQ_INSTS_VALU", 0.0) / mf)) if mf else "-", ("%.2f" % (d.get("SQ_INSTS_LDS", 0.0) / mf)) if mf else "-",
+            kc / (dur[k] * 1e3) if dur[k] else 0.0))
 
 
 if __name__ == "__main__":
